@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""Headline benchmark: latent-frames/sec of the latent-NeRF render path, forward + backward,
+at 64x64x4 latents with a 128^3 occupancy grid (BASELINE.json metric / configs[1]).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one optimisation step on one synthetic view per GPU, through the drop-in surface
+(`NeRFNetwork.render()` -> `image.backward(gradient=g)`): HIP ray generation, AABB test,
+occupancy-pruned march, hash-grid gather, sigma/latent MLP, compositing, their backward kernels,
+the gradient all-reduce (N > 1, RCCL) and the fused Adam update of every parameter.  Inputs are
+synthetic and resident in HBM before the timed region: table ~ N(0, 0.1),
+nn.Linear-default MLP, analytic sphere occupancy (|x| < 0.5), camera r=1.25, theta=60 deg,
+phi = 45 deg * rank, fovy 55 deg, upstream gradient g = randn * sqrt(a)(1-a), a = 0.5
+(the SDS weighting form of the reference's src/stable_diffusion.py:320-321).
+
+Prints ONE JSON line (rank 0).  `roofline` is the hash-grid gather (the kernel the metric names):
+algorithmic bytes (1164 B/sample f32 table, 588 B/sample bf16) x samples / the
+kernel's duration measured with HIP events inside the timed steps.  `cpu_baseline` is the oracle
+(oracle/nerf_oracle.py, pure PyTorch fp32) doing the same step on the host cores.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "latent-nerf-test_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+H = W = 64
+GRID = 128
+FOVY = 55.0
+LR = 1e-3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--precision", default=os.environ.get("LNERF_BENCH_PRECISION", "f32"), choices=["f32", "bf16"],
+                    help="f32: f32 table + exact-f32 MFMA MLP; bf16: bf16 shadow table + bf16 MFMA MLP")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--gather-variant", type=int, default=1)
+    ap.add_argument("--breakdown", action="store_true", help="extra untimed pass: per-kernel event timings")
+    return ap.parse_args()
+
+
+def build(dev, precision, variant, rank):
+    from oracle import nerf_oracle as O  # scene construction only (analytic occupancy), not measured
+    from src.latent_nerf.configs.render_config import RenderConfig
+    from src.latent_nerf.models.network_grid import NeRFNetwork
+    from src.latent_nerf.models.nerf_utils import intrinsics_from_fov, pose_from_angles
+
+    torch.manual_seed(0)
+    cfg = RenderConfig(grid_size=GRID, train_h=H, train_w=W, mlp_precision=precision,
+                       table_dtype="bf16" if precision == "bf16" else "f32", gather_variant=variant)
+    net = NeRFNetwork(cfg)
+    net.encoder.embeddings.data.normal_(0, 0.1)
+    net = net.to(dev).train()
+    grid = O.sphere_density_grid(G=GRID, radius=0.5)
+    net.density_grid.copy_(grid.to(dev))
+    net.density_bitfield.copy_(O.packbits(grid.reshape(-1), 0.01).to(dev))
+    pose = pose_from_angles(math.radians(60.0), math.radians(45.0 * rank), 1.25)[None].to(dev)
+    intr = intrinsics_from_fov(FOVY, H, W)
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    bg = torch.rand(H * W, 4, generator=g).to(dev)
+    grad = (torch.randn(1, H * W, 4, generator=g) * math.sqrt(0.5) * 0.5).to(dev)
+    return net, pose, intr, bg, grad
+
+
+class AdamState:
+    """Fused HIP Adam over every parameter tensor (betas/eps of the reference's trainer.py:93-95)."""
+
+    def __init__(self, net, lr):
+        self.items = []
+        for group in net.get_params(lr):
+            for p in group["params"]:
+                self.items.append((p, torch.zeros_like(p), torch.zeros_like(p), group["lr"]))
+        self.step_no = 0
+        self.net = net
+
+    def step(self, grad_scale):
+        from src.latent_nerf.raymarching import backend as B
+        from src.latent_nerf.raymarching.raymarching import _p, _stream
+        self.step_no += 1
+        enc = self.net.encoder
+        for p, m, v, lr in self.items:
+            # the kernel rewrites the bf16 shadow in the same pass (the ctypes write does not bump the
+            # tensor version, so GridEncoder keeps treating the shadow as current -- which it is)
+            shadow = enc.shadow() if p is enc.embeddings else None
+            B.call("lnerf_adam_step", _p(p.data), _p(p.grad), _p(m), _p(v), _p(shadow), p.numel(), lr, 0.9, 0.99, 1e-15,
+                   self.step_no, grad_scale, 0, _stream())
+            p.grad = None
+
+
+def make_step(net, pose, intr, bg, grad, opt, world):
+    from src.latent_nerf.raymarching import raymarching as rm
+    import torch.distributed as dist
+    small = [p for p in net.parameters() if p is not net.encoder.embeddings]
+
+    def step():
+        rays_o, rays_d = rm.get_rays(pose, intr, H, W)
+        out = net.render(rays_o, rays_d, bg_color=bg, perturb=True)
+        out["image"].backward(gradient=grad)
+        if world > 1:
+            dist.all_reduce(net.encoder.embeddings.grad)
+            flat = torch.cat([p.grad.reshape(-1) for p in small])
+            dist.all_reduce(flat)
+            o = 0
+            for p in small:
+                p.grad.copy_(flat[o:o + p.numel()].view_as(p))
+                o += p.numel()
+        opt.step(1.0 / world)
+        return out
+
+    return step
+
+
+class KernelTimer:
+    """HIP events around selected C-ABI calls (same stream the kernels are launched on)."""
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.pairs = {n: [] for n in names}
+        self._open = {}
+
+    def hook(self, name, when):
+        if name not in self.names:
+            return
+        if when == "pre":
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._open[name] = e
+        else:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.pairs[name].append((self._open.pop(name), e))
+
+    def mean_ms(self, name):
+        p = self.pairs[name]
+        return sum(a.elapsed_time(b) for a, b in p) / max(len(p), 1)
+
+
+def cpu_baseline(frames):
+    """The oracle's pure-PyTorch fp32 step (render fwd+bwd + Adam) on the host cores."""
+    from oracle import nerf_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    lv = O.make_grid_levels()
+    table = (torch.randn(lv.n_rows, 2) * 0.1).requires_grad_()
+    mp = {k: v.requires_grad_() for k, v in O.init_mlp_params().items()}
+    grid = O.sphere_density_grid(G=GRID, radius=0.5)
+    bits = O.packbits(grid.reshape(-1), 0.01)
+    f = H / (2 * math.tan(math.radians(FOVY) / 2))
+    c2w = O.pose_from_angles(math.radians(60.0), 0.0, 1.25)
+    bg = torch.rand(H * W, 4)
+    g = torch.randn(H * W, 4) * math.sqrt(0.5) * 0.5
+    opt = torch.optim.Adam([{"params": [table], "lr": LR * 10}, {"params": list(mp.values()), "lr": LR}],
+                           betas=(0.9, 0.99), eps=1e-15)
+    times = []
+    M = 0
+    for i in range(frames + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        ro, rd = O.get_rays(c2w, f, f, W / 2, H / 2, H, W)
+        out = O.render_frame(ro[0], rd[0], table, mp, lv, bits, G=GRID, noises=torch.rand(H * W), bg_color=bg)
+        out["image"].backward(g)
+        opt.step()
+        dt = time.perf_counter() - t0
+        M = out["M"]
+        if i > 0:
+            times.append(dt)
+    med = sorted(times)[len(times) // 2]
+    return {"value": 1.0 / med, "unit": "latent-frames/sec", "cores": cores, "kind": "port",
+            "sample": "%d timed frames (+1 warm-up) of the same 64x64x4 / 128^3 step, M=%d samples/frame, "
+                      "oracle/nerf_oracle.py fp32 PyTorch, %d threads" % (len(times), M, cores)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d ...`"
+                             % (args.gpus, args.gpus))
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from src.latent_nerf.raymarching import backend as B
+    B.get_lib()  # no fallback: raise here if the HIP library is missing
+    net, pose, intr, bg, grad = build(dev, args.precision, args.gather_variant, rank)
+    opt = AdamState(net, LR)
+    step = make_step(net, pose, intr, bg, grad, opt, world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    timer = KernelTimer(["lnerf_grid_encode_forward", "lnerf_grid_encode_backward"])
+    B.set_profile_hook(timer.hook)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    B.set_profile_hook(None)
+    M = int(out["counter"][0].item())
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    breakdown = None
+    if args.breakdown and rank == 0:
+        names = ["lnerf_get_rays", "lnerf_near_far_from_aabb", "lnerf_march_rays_train", "lnerf_grid_encode_forward",
+                 "lnerf_mlp_forward", "lnerf_composite_rays_train_forward", "lnerf_composite_rays_train_backward",
+                 "lnerf_mlp_backward", "lnerf_grid_encode_backward", "lnerf_adam_step"]
+        bt = KernelTimer(names)
+        B.set_profile_hook(bt.hook)
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        B.set_profile_hook(None)
+        breakdown = {n.replace("lnerf_", ""): round(bt.mean_ms(n) * (len(bt.pairs[n]) / 20.0), 4) for n in names}
+
+    if rank == 0:
+        bytes_per_sample = 588 if args.precision == "bf16" else 1164
+        g_ms = timer.mean_ms("lnerf_grid_encode_forward")
+        s_ms = timer.mean_ms("lnerf_grid_encode_backward")
+        achieved = M * bytes_per_sample / (g_ms * 1e-3) / 1e9
+        scatter = M * 1164 / (s_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_gather_latest.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "latent-frames/sec (64x64x4, 128^3 grid), render forward+backward",
+            "value": world * args.steps / elapsed,
+            "unit": "latent-frames/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.precision,
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: unconstrained latent-NeRF 64x64x4, 128^3 occupancy grid, hash grid "
+                                   "L=16 F=2 T=2^19, 1 view/GPU/step, fwd+bwd+grad all-reduce+Adam",
+                       "rays_per_view": H * W, "samples_per_view": M, "views_per_step": world,
+                       "parallelism": "dp%d (1 view per GPU, RCCL all-reduce of gradients)" % world},
+            "roofline": {"kernel": "k_grid_forward (hash-grid gather, H5)", "bound": "hbm", "achieved": achieved,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "bytes_per_sample": bytes_per_sample, "samples_per_launch": M, "kernel_ms": g_ms},
+            "scatter": {"kernel": "grid_encode_backward (H6)", "algorithmic_GBps": scatter, "kernel_ms": s_ms,
+                        "note": "global float atomics; chip-wide atomic ceiling ~1300 GB/s of added bytes"},
+        }
+        if breakdown:
+            res["kernel_ms_per_step"] = breakdown
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(args.cpu_frames)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,183 @@
+/* lnerf_hip.h -- C ABI of the MI355X (gfx950) latent-NeRF render kernels.
+ *
+ * This is the drop-in boundary of the hot path named by BASELINE.json `north_star`
+ * (SURVEY.md §8): everything `NeRFRenderer.render()/run_cuda()` needs per optimisation step.
+ * The reference checkout calls this path at scripts/train_latent_nerf.py:3-4,10-14
+ * (`from src.latent_nerf... import Trainer` -> trainer -> renderer) but does not contain it
+ * (README.md:152-156 lists `src/latent_nerf/raymarching`, "The CUDA ray marching modules");
+ * each entry point below names the extension op of that absent module it stands in for, as
+ * enumerated in SURVEY.md §8(b).  The caller-side contract that IS present in the reference --
+ * the renderer hands the trainer `{'image': [B,4,H,W]}` and receives the SDS gradient through
+ * `pred.backward(gradient=grad)` -- is src/latent_paint/models/textured_mesh.py:181-220 and
+ * src/latent_paint_mesh/training/trainer.py:657-658; the Python host side above this ABI
+ * (latent-nerf-test_amd/src/latent_nerf) honours it.
+ *
+ * Conventions
+ *   - plain C: device pointers, sizes, a stream handle.  No torch types.  All pointers are
+ *     DEVICE pointers unless the name ends in `_host`.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Every call only
+ *     enqueues work; none synchronises, allocates or frees (all are hipGraph-capturable).
+ *   - return value: LNERF_OK (0) or a negative LNERF_ERR_*; lnerf_last_error() gives a
+ *     thread-local message.  Arguments are validated on the host before any launch.
+ *   - data-dependent sizes (the number of samples M a march produced) stay on the device:
+ *     kernels that consume samples take `m_host` (an upper bound, usually the buffer
+ *     capacity) and an optional device pointer `m_dev`; they process min(m_host, *m_dev).
+ *   - sample-major feature tensors are stored LEVEL-MAJOR: feat[(l*F+f)] lives at
+ *     base + (l * level_stride + m) * F + f  (F = 2), so every wave writes/reads 512 contiguous
+ *     bytes per level.  `level_stride` is in samples (normally the buffer capacity).
+ */
+#ifndef LNERF_HIP_H
+#define LNERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LNERF_ABI_VERSION 1
+
+#define LNERF_OK 0
+#define LNERF_ERR_INVALID_ARG (-1)
+#define LNERF_ERR_HIP (-2)
+#define LNERF_ERR_UNSUPPORTED (-3)
+
+/* dtype tags for `void*` tensors */
+#define LNERF_F32 0
+#define LNERF_BF16 1
+
+#define LNERF_MAX_LEVELS 32
+
+typedef void *lnerf_stream_t;
+
+int lnerf_abi_version(void);
+const char *lnerf_last_error(void);
+/* "gfx950;<git or build tag>" -- lets the host side assert what it loaded */
+const char *lnerf_build_info(void);
+
+/* ---- H1: ray generation (absent upstream: `get_rays` of nerf_utils; camera convention
+ * src/latent_paint/models/render.py:19-31).  c2w [B,4,4] row-major, columns (right,down,forward,eye).
+ * rays_o, rays_d [B, H*W, 3]. */
+int lnerf_get_rays(const float *c2w, int B, int H, int W, float fx, float fy, float cx, float cy,
+                   float *rays_o, float *rays_d, lnerf_stream_t stream);
+
+/* ---- H2: `raymarching.near_far_from_aabb`.  aabb = (xmin,ymin,zmin,xmax,ymax,zmax) by value.
+ * Misses get near = far = FLT_MAX. */
+int lnerf_near_far_from_aabb(const float *rays_o, const float *rays_d, int64_t N, float xmin, float ymin, float zmin,
+                             float xmax, float ymax, float zmax, float min_near, float *nears, float *fars,
+                             lnerf_stream_t stream);
+
+/* ---- H3: `raymarching.morton3D`, `morton3D_invert`, `packbits`. */
+int lnerf_morton3d(const int32_t *coords, int64_t n, uint32_t *indices, lnerf_stream_t stream);
+int lnerf_morton3d_invert(const uint32_t *indices, int64_t n, int32_t *coords, lnerf_stream_t stream);
+/* bit k of byte b = grid[8b+k] > min(thresh, *mean_dev)  (mean_dev may be NULL) */
+int lnerf_packbits(const float *grid, int64_t n_cells, float thresh, const float *mean_dev, uint8_t *bitfield,
+                   lnerf_stream_t stream);
+
+/* ---- H4: `raymarching.march_rays_train`.
+ * Three launches: per-ray count (one wavefront per ray, ballot + popcount over 64 lattice
+ * points at a time), single-workgroup exclusive scan, per-ray write (ballot prefix-sum
+ * compaction).  Output order is deterministic: samples of ray n follow those of ray n-1.
+ *   rays    int32 [N,3]  (ray id, offset, count)
+ *   counter int32 [4]    [0]=M total samples written, [1]=number of rays with count>0,
+ *                        [2]=rays dropped because offset+count exceeded `capacity`, [3]=reserved
+ *   noises  [N] in [0,1) or NULL (no jitter)
+ *   xyzs [capacity,3], dirs [capacity,3], deltas [capacity,2] = (dt, t). */
+int lnerf_march_rays_train(const float *rays_o, const float *rays_d, const float *nears, const float *fars, int64_t N,
+                           const uint8_t *bitfield, float bound, int cascade, int grid_size, int max_steps,
+                           float dt_gamma, const float *noises, int64_t capacity, float *xyzs, float *dirs,
+                           float *deltas, int32_t *rays, int32_t *counter, lnerf_stream_t stream);
+
+/* ---- H4 (inference): `raymarching.march_rays` / `composite_rays` and the live-ray compaction
+ * the upstream renderer does on the host (`rays_alive = rays_alive[rays_alive >= 0]`). */
+int lnerf_march_rays(int64_t n_alive, int n_step, const int32_t *rays_alive, const float *rays_t, const float *rays_o,
+                     const float *rays_d, const float *fars, const uint8_t *bitfield, float bound, int cascade,
+                     int grid_size, int max_steps, float dt_gamma, float *xyzs, float *dirs, float *deltas,
+                     lnerf_stream_t stream);
+int lnerf_composite_rays(int64_t n_alive, int n_step, int32_t *rays_alive, float *rays_t, const float *sigmas,
+                         const float *rgbs, const float *deltas, int C, float T_thresh, float *weights_sum,
+                         float *depth, float *image, float *transmittance, lnerf_stream_t stream);
+/* alive_out[0..n) = entries of alive_in that are >= 0, order preserved; n -> *n_alive_dev.
+ * Wave ballot + prefix-sum compaction, one launch. */
+int lnerf_compact_rays(const int32_t *alive_in, int64_t n, int32_t *alive_out, int32_t *n_alive_dev,
+                       lnerf_stream_t stream);
+
+/* ---- H5/H6: `gridencoder.grid_encode_forward/backward` (multiresolution hash grid, F = 2).
+ * Level metadata is passed from the host (num_levels <= LNERF_MAX_LEVELS):
+ *   offsets_host [L+1] row offsets, scales_host [L] per-level scale, res_host [L] resolution.
+ * xyzs are world positions; the kernels normalise x01 = (x + bound) / (2*bound).
+ * `variant` selects the workgroup->(level,tile) mapping: 0 = level on blockIdx.y,
+ * 1 = XCD-aware (levels pinned to XCDs so each XCD's L2 holds two levels). */
+int lnerf_grid_encode_forward(const float *xyzs, float bound, const void *table, int table_dtype, int num_levels,
+                              int level_dim, const int32_t *offsets_host, const float *scales_host,
+                              const int32_t *res_host, int64_t m_host, const int32_t *m_dev, int64_t level_stride,
+                              void *feat, int feat_dtype, int variant, lnerf_stream_t stream);
+/* dtable (f32, [rows, F]) is ACCUMULATED into (+=).  variant 0 = global float atomics. */
+int lnerf_grid_encode_backward(const float *xyzs, float bound, const void *dfeat, int dfeat_dtype, int num_levels,
+                               int level_dim, const int32_t *offsets_host, const float *scales_host,
+                               const int32_t *res_host, int64_t m_host, const int32_t *m_dev, int64_t level_stride,
+                               float *dtable, int variant, lnerf_stream_t stream);
+
+/* ---- H7: fused sigma/latent MLP  32 -> 64 -> 64 -> out_dim (= 1 + C), ReLU hidden.
+ * Weights are PyTorch nn.Linear layout: w1 [64,32], b1 [64], w2 [64,64], b2 [64], w3 [out_dim,64],
+ * b3 [out_dim], all f32.  sigma = exp(h0 + blob_scale*exp(-|x|^2/(2 blob_std^2))), rgbs = h[1:].
+ * precision: LNERF_F32 -> exact-f32 MFMA (v_mfma_f32_16x16x4_f32), LNERF_BF16 -> bf16 MFMA, f32 acc. */
+int lnerf_mlp_forward(const void *feat, int feat_dtype, int64_t level_stride, const float *xyzs, const float *w1,
+                      const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, int out_dim,
+                      float blob_scale, float blob_std, int64_t m_host, const int32_t *m_dev, float *sigmas,
+                      float *rgbs, int precision, lnerf_stream_t stream);
+/* Recomputes the hidden activations.  dfeat is written (level-major, f32); d* parameter
+ * gradients are ACCUMULATED (+=) deterministically: per-workgroup partial slabs in `workspace`
+ * (lnerf_mlp_backward_workspace_bytes()) followed by one reduction launch. */
+size_t lnerf_mlp_backward_workspace_bytes(int out_dim);
+int lnerf_mlp_backward(const void *feat, int feat_dtype, int64_t level_stride, const float *xyzs, const float *w1,
+                       const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, int out_dim,
+                       float blob_scale, float blob_std, int64_t m_host, const int32_t *m_dev, const float *sigmas,
+                       const float *dsigmas, const float *drgbs, float *dfeat, float *dw1, float *db1, float *dw2,
+                       float *db2, float *dw3, float *db3, void *workspace, size_t workspace_bytes, int precision,
+                       lnerf_stream_t stream);
+
+/* ---- H8/H9: `raymarching.composite_rays_train_forward/backward`.  One wavefront per ray,
+ * log-space prefix scan of sigma*dt across lanes.  C = colour channels (3 or 4).
+ * bg_color [N,C] or NULL: image += (1 - weights_sum) * bg. */
+int lnerf_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas,
+                                       const int32_t *rays, int64_t N, int C, float T_thresh, const float *bg_color,
+                                       float *weights_sum, float *depth, float *image, lnerf_stream_t stream);
+/* grad_weights_sum / grad_depth / grad_bg may be NULL.  grad_sigmas [.], grad_rgbs [.,C] are
+ * written for every sample inside a ray's span (zeros after early termination). */
+int lnerf_composite_rays_train_backward(const float *grad_weights_sum, const float *grad_depth,
+                                        const float *grad_image, const float *sigmas, const float *rgbs,
+                                        const float *deltas, const int32_t *rays, const float *weights_sum,
+                                        const float *depth, const float *image, const float *bg_color, int64_t N,
+                                        int C, float T_thresh, float *grad_sigmas, float *grad_rgbs, float *grad_bg,
+                                        lnerf_stream_t stream);
+
+/* ---- H10: occupancy grid refresh pieces (`update_extra_state`): cell sample points,
+ * decayed max update, mean, then lnerf_packbits. */
+int lnerf_occ_cell_points(const uint32_t *indices, int64_t n, int cascade_level, int grid_size, float bound,
+                          const float *noise, float *xyzs, lnerf_stream_t stream);
+/* indices == NULL means cells 0..n-1 */
+int lnerf_occ_update(float *grid_level, const uint32_t *indices, int64_t n, const float *new_sigmas, float decay,
+                     lnerf_stream_t stream);
+/* mean of max(grid,0) over n cells -> *mean_dev ; scratch2: 2 floats of device scratch */
+int lnerf_occ_mean(const float *grid, int64_t n, float *mean_dev, float *scratch2, lnerf_stream_t stream);
+
+/* ---- H11: background net, frequency encoding (degree 6: 39 dims) -> 64 -> C, one thread per ray. */
+int lnerf_bg_forward(const float *dirs, int64_t N, const float *w1, const float *b1, const float *w2, const float *b2,
+                     int C, float *out, lnerf_stream_t stream);
+int lnerf_bg_backward(const float *dirs, int64_t N, const float *w1, const float *b1, const float *w2, const float *b2,
+                      int C, const float *dout, float *dw1, float *db1, float *dw2, float *db2, lnerf_stream_t stream);
+
+/* ---- optimiser step used by the bench/trainer (Adam, src/latent_paint/training/trainer.py:93-95:
+ * betas (0.9, 0.99), eps 1e-15).  g is multiplied by grad_scale (1/world_size) first; if
+ * zero_grad != 0 the gradient is cleared in the same pass; if shadow_bf16 != NULL the bf16
+ * copy read by the gather is refreshed in the same pass. */
+int lnerf_adam_step(float *p, float *g, float *m, float *v, void *shadow_bf16, int64_t n, float lr, float beta1,
+                    float beta2, float eps, int step, float grad_scale, int zero_grad, lnerf_stream_t stream);
+int lnerf_cast_f32_to_bf16(const float *src, void *dst, int64_t n, lnerf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LNERF_HIP_H */

@@ -1,0 +1,64 @@
+"""Build liblnerf_hip.so (the C-ABI HIP library, include/lnerf_hip.h) for gfx950 with hipcc.
+
+    python latent-nerf-test_amd/build.py [--force]
+
+No GPU is needed to build (hipcc cross-compiles).  The .so is written in-tree under
+latent-nerf-test_amd/lib/ so that it travels with the repository snapshot to the GPU box.
+-ffp-contract=off: fused multiply-adds are only the ones written explicitly (see DESIGN.md,
+"Arithmetic contract").
+"""
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "liblnerf_hip.so")
+SOURCES = ["api.cc", "rays.hip", "grid.hip", "mlp.hip", "composite.hip", "optim.hip", "bg.hip"]
+DEPS = ["common.h", os.path.join("..", "..", "include", "lnerf_hip.h")]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def _digest():
+    h = hashlib.sha256()
+    for f in SOURCES + DEPS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    tag = _digest()
+    stamp = os.path.join(LIBDIR, "build.stamp")
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == tag:
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        cmd = [hipcc] + FLAGS + ['-DLNERF_BUILD_TAG="%s"' % tag, "-c", os.path.join(CSRC, src), "-o", obj]
+        if src.endswith(".cc"):
+            cmd = [c for c in cmd if not c.startswith("--offload-arch")]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed on %s" % src)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(tag)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,110 @@
+// Shared host/device helpers for the gfx950 latent-NeRF kernels.
+// Compiled with -ffp-contract=off: every fused multiply-add in this library is written
+// explicitly (fmaf / __builtin_fmaf) so that the discrete decisions of the ray march are
+// reproducible against the CPU oracle (DESIGN.md "Arithmetic contract").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/lnerf_hip.h"
+
+#define LNERF_WAVE 64
+
+namespace lnerf {
+
+void set_error(const char *fmt, ...);
+
+inline hipStream_t as_stream(lnerf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define LNERF_REQUIRE(cond, ...)                \
+    do {                                        \
+        if (!(cond)) {                          \
+            ::lnerf::set_error(__VA_ARGS__);    \
+            return LNERF_ERR_INVALID_ARG;       \
+        }                                       \
+    } while (0)
+
+#define LNERF_CHECK_LAUNCH(name)                                                         \
+    do {                                                                                 \
+        hipError_t e__ = hipGetLastError();                                              \
+        if (e__ != hipSuccess) {                                                         \
+            ::lnerf::set_error("%s: launch failed: %s", name, hipGetErrorString(e__));   \
+            return LNERF_ERR_HIP;                                                        \
+        }                                                                                \
+    } while (0)
+
+static inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------- device helpers
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t compact_bits(uint32_t x) {
+    x &= 0x49249249u;
+    x = (x | (x >> 2)) & 0xC30C30C3u;
+    x = (x | (x >> 4)) & 0x0F00F00Fu;
+    x = (x | (x >> 8)) & 0xFF0000FFu;
+    x = (x | (x >> 16)) & 0x0000FFFFu;
+    return x;
+}
+__device__ __forceinline__ uint32_t morton3d(uint32_t x, uint32_t y, uint32_t z) {
+    return expand_bits(x) | (expand_bits(y) << 1) | (expand_bits(z) << 2);
+}
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// number of set bits of `mask` strictly below this lane (wave64)
+__device__ __forceinline__ int mbcnt(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+}
+
+// inclusive wave scan (sum) over 64 lanes
+__device__ __forceinline__ float wave_inclusive_sum(float v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        float o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_inclusive_sum_i(int v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// round-to-nearest-even f32 -> bf16 (NaN preserved as quiet NaN)
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x0040u);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+struct GridMeta {
+    int num_levels;
+    int offsets[LNERF_MAX_LEVELS + 1];
+    float scales[LNERF_MAX_LEVELS];
+    int res[LNERF_MAX_LEVELS];
+};
+
+}  // namespace lnerf

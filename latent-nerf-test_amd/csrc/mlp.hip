@@ -1,0 +1,450 @@
+// H7 fused sigma/latent MLP  32 -> 64 -> 64 -> out_dim, forward and backward, on the matrix cores.
+//
+// precision LNERF_F32: v_mfma_f32_16x16x4_f32 (exact f32 fma chains, the parity path).
+// One wavefront owns 16 samples per step; a 256-thread workgroup owns a 64-sample tile and
+// walks tiles persistently.  Activations change from the MFMA C/D layout (sample on
+// registers, feature on lanes) to the A layout (sample on lanes) through a per-wave LDS tile.
+//
+// MFMA 16x16x4 f32 lane maps (guide §3):  A[i = l&15][k = l>>4],  B[k = l>>4][j = l&15],
+// C/D[i = (l>>4)*4 + reg][j = l&15].
+#include "common.h"
+
+namespace lnerf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+constexpr int IN = 32, HID = 64, OUTP = 16;  // OUTP: padded output width (one 16-wide tile)
+constexpr int LDX = IN + 1, LDH = HID + 1;   // padded LDS leading dimensions
+
+struct MlpArgs {
+    const void *feat;
+    int feat_bf16;
+    int64_t level_stride;
+    const float *xyzs;
+    const float *w1, *b1, *w2, *b2, *w3, *b3;
+    int out_dim;
+    float blob_scale, blob_denom;  // blob = scale * exp(-|x|^2 / denom), denom = 2 std^2
+    int64_t m_host;
+    const int32_t *m_dev;
+};
+
+__device__ __forceinline__ float load_feat(const MlpArgs &a, int level, int f, int64_t m) {
+    const int64_t i = ((int64_t)level * a.level_stride + m) * 2 + f;
+    if (a.feat_bf16) return bf16_to_f32(reinterpret_cast<const uint16_t *>(a.feat)[i]);
+    return reinterpret_cast<const float *>(a.feat)[i];
+}
+
+__device__ __forceinline__ float blob_of(const MlpArgs &a, int64_t m) {
+    const float x = a.xyzs[m * 3], y = a.xyzs[m * 3 + 1], z = a.xyzs[m * 3 + 2];
+    const float d2 = (x * x + y * y) + z * z;
+    return a.blob_scale * expf(-d2 / a.blob_denom);
+}
+
+// ------------------------------------------------------------------ forward
+__global__ void __launch_bounds__(256)
+k_mlp_forward_f32(MlpArgs a, float *__restrict__ sigmas, float *__restrict__ rgbs) {
+    __shared__ float sAct[4][16 * LDH];
+    int64_t M = a.m_host;
+    if (a.m_dev) { const int64_t md = *a.m_dev; M = md < M ? md : M; }
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    float *act = sAct[w];
+
+    // weights as B operands, held in registers for the whole kernel: B[k][n] = W[n][k]
+    float w1r[8][4], w2r[16][4], w3r[16];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) w1r[kk][nt] = a.w1[(nt * 16 + j) * IN + 4 * kk + q];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) w2r[kk][nt] = a.w2[(nt * 16 + j) * HID + 4 * kk + q];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) w3r[kk] = (j < a.out_dim) ? a.w3[j * HID + 4 * kk + q] : 0.f;
+    float b1r[4], b2r[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) { b1r[nt] = a.b1[nt * 16 + j]; b2r[nt] = a.b2[nt * 16 + j]; }
+    const float b3r = (j < a.out_dim) ? a.b3[j] : 0.f;
+
+    for (int64_t tile = blockIdx.x; tile * 64 < M; tile += gridDim.x) {
+        const int64_t m0 = tile * 64 + w * 16;
+        // ---- layer 1: A[s][k] straight from the level-major feature tensor
+        f32x4 acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = (f32x4){b1r[nt], b1r[nt], b1r[nt], b1r[nt]};
+        {
+            const int64_t m = m0 + j;
+            const bool in = m < M;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const float x = in ? load_feat(a, 2 * kk + (q >> 1), q & 1, m) : 0.f;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[nt] = MFMA4(x, w1r[kk][nt], acc[nt]);
+            }
+        }
+        __syncthreads();  // previous tile's readers of `act` are done
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) act[(q * 4 + r) * LDH + nt * 16 + j] = fmaxf(acc[nt][r], 0.f);
+        __syncthreads();
+        // ---- layer 2
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = (f32x4){b2r[nt], b2r[nt], b2r[nt], b2r[nt]};
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const float x = act[j * LDH + 4 * kk + q];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = MFMA4(x, w2r[kk][nt], acc[nt]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) act[(q * 4 + r) * LDH + nt * 16 + j] = fmaxf(acc[nt][r], 0.f);
+        __syncthreads();
+        // ---- layer 3 (one 16-wide output tile, columns >= out_dim are zero)
+        f32x4 o = (f32x4){b3r, b3r, b3r, b3r};
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) o = MFMA4(act[j * LDH + 4 * kk + q], w3r[kk], o);
+        // ---- epilogue: lane holds h[s = q*4 + r][n = j]
+        if (j < a.out_dim) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t m = m0 + q * 4 + r;
+                if (m < M) {
+                    if (j == 0) sigmas[m] = expf(o[r] + blob_of(a, m));
+                    else rgbs[m * (a.out_dim - 1) + (j - 1)] = o[r];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ backward
+// slab layout (floats): dW1 [64*32] | db1 [64] | dW2 [64*64] | db2 [64] | dW3 [16*64] | db3 [16]
+constexpr int SL_W1 = 0, SL_B1 = SL_W1 + HID * IN, SL_W2 = SL_B1 + HID, SL_B2 = SL_W2 + HID * HID,
+              SL_W3 = SL_B2 + HID, SL_B3 = SL_W3 + OUTP * HID, SLAB = SL_B3 + OUTP;
+constexpr int BWD_MAX_BLOCKS = 512;
+
+__global__ void __launch_bounds__(256, 2)
+k_mlp_backward_f32(MlpArgs a, const float *__restrict__ sigmas, const float *__restrict__ dsigmas,
+                   const float *__restrict__ drgbs, float *__restrict__ dfeat, float *__restrict__ slabs) {
+    __shared__ float sW1[HID * LDX];
+    __shared__ float sW2[HID * LDH];
+    __shared__ float sW3[OUTP * LDH];
+    __shared__ float sB1[HID], sB2[HID];
+    __shared__ float sX[4][16 * LDX];
+    __shared__ float sP[4][16 * LDH];  // A1, later dZ1
+    __shared__ float sQ[4][16 * LDH];  // A2, later dZ2
+    int64_t M = a.m_host;
+    if (a.m_dev) { const int64_t md = *a.m_dev; M = md < M ? md : M; }
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int nrgb = a.out_dim - 1;
+    for (int i = tid; i < HID * IN; i += 256) sW1[(i / IN) * LDX + (i % IN)] = a.w1[i];
+    for (int i = tid; i < HID * HID; i += 256) sW2[(i / HID) * LDH + (i % HID)] = a.w2[i];
+    for (int i = tid; i < OUTP * HID; i += 256)
+        sW3[(i / HID) * LDH + (i % HID)] = (i / HID) < a.out_dim ? a.w3[i] : 0.f;
+    if (tid < HID) { sB1[tid] = a.b1[tid]; sB2[tid] = a.b2[tid]; }
+    __syncthreads();
+    float *X = sX[w], *P = sP[w], *Q = sQ[w];
+    const float e15 = 3269017.3724721107f;  // exp(15)
+
+    f32x4 gW2[4][4], gW1[4][2], gW3[4];
+    float gb1[4] = {0.f, 0.f, 0.f, 0.f}, gb2[4] = {0.f, 0.f, 0.f, 0.f}, gb3[2] = {0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) gW2[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        gW1[mt][0] = gW1[mt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        gW3[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int64_t tile = blockIdx.x; tile * 64 < M; tile += gridDim.x) {
+        const int64_t m0 = tile * 64 + w * 16;
+        __syncthreads();  // previous tile's LDS readers are done
+        // ---- recompute layer 1; keep X in LDS ([s][k]) for dW1
+        f32x4 z[4], a1c[4], a2c[4];
+        {
+            const int64_t m = m0 + j;
+            const bool in = m < M;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) { const float b = sB1[nt * 16 + j]; z[nt] = (f32x4){b, b, b, b}; }
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const float x = in ? load_feat(a, 2 * kk + (q >> 1), q & 1, m) : 0.f;
+                X[j * LDX + 4 * kk + q] = x;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) z[nt] = MFMA4(x, sW1[(nt * 16 + j) * LDX + 4 * kk + q], z[nt]);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a1c[nt][r] = fmaxf(z[nt][r], 0.f);
+                P[(q * 4 + r) * LDH + nt * 16 + j] = a1c[nt][r];
+            }
+        __syncthreads();
+        // ---- recompute layer 2
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) { const float b = sB2[nt * 16 + j]; z[nt] = (f32x4){b, b, b, b}; }
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const float x = P[j * LDH + 4 * kk + q];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) z[nt] = MFMA4(x, sW2[(nt * 16 + j) * LDH + 4 * kk + q], z[nt]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a2c[nt][r] = fmaxf(z[nt][r], 0.f);
+                Q[(q * 4 + r) * LDH + nt * 16 + j] = a2c[nt][r];
+            }
+        __syncthreads();
+        // ---- dZ3 in A layout: lane (s = j, k = 4kk + q), kk = 0,1
+        float dz3[2];
+        {
+            const int64_t m = m0 + j;
+            const bool in = m < M;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int k = 4 * kk + q;
+                float v = 0.f;
+                if (in && k < a.out_dim) {
+                    if (k == 0) v = dsigmas[m] * fminf(sigmas[m], e15);
+                    else v = drgbs[m * nrgb + (k - 1)];
+                }
+                dz3[kk] = v;
+                gb3[kk] += v;  // reduced over the 16 samples (lanes j) at the end
+            }
+        }
+        // ---- dW3[n3][h] += sum_s dZ3[s][n3] A2[s][h] : A[i = n3][k = s] from global, B = A2 rows
+        {
+            const int k = j;  // output row n3
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int64_t m = m0 + 4 * kk + q;
+                float v = 0.f;
+                if (m < M && k < a.out_dim) {
+                    if (k == 0) v = dsigmas[m] * fminf(sigmas[m], e15);
+                    else v = drgbs[m * nrgb + (k - 1)];
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) gW3[nt] = MFMA4(v, Q[(4 * kk + q) * LDH + nt * 16 + j], gW3[nt]);
+            }
+        }
+        // ---- dA2 = dZ3 W3 ; dZ2 = dA2 * (A2 > 0)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) z[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) z[nt] = MFMA4(dz3[kk], sW3[(4 * kk + q) * LDH + nt * 16 + j], z[nt]);
+        __syncthreads();  // all reads of A2 from Q are done
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = a2c[nt][r] > 0.f ? z[nt][r] : 0.f;
+                Q[(q * 4 + r) * LDH + nt * 16 + j] = d;  // Q now holds dZ2 [s][o]
+                gb2[nt] += d;
+            }
+        __syncthreads();
+        // ---- dW2[o][i] += sum_s dZ2[s][o] A1[s][i]
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                av[t] = Q[(4 * kk + q) * LDH + t * 16 + j];
+                bv[t] = P[(4 * kk + q) * LDH + t * 16 + j];
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) gW2[mt][nt] = MFMA4(av[mt], bv[nt], gW2[mt][nt]);
+        }
+        // ---- dA1 = dZ2 W2 : A from Q (sample on lanes), B[k = o][n = i] = W2[o][i]
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) z[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const float x = Q[j * LDH + 4 * kk + q];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) z[nt] = MFMA4(x, sW2[(4 * kk + q) * LDH + nt * 16 + j], z[nt]);
+        }
+        __syncthreads();  // all reads of A1 from P are done
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = a1c[nt][r] > 0.f ? z[nt][r] : 0.f;
+                P[(q * 4 + r) * LDH + nt * 16 + j] = d;  // P now holds dZ1 [s][o]
+                gb1[nt] += d;
+            }
+        __syncthreads();
+        // ---- dW1[o][i] += sum_s dZ1[s][o] X[s][i]
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float av[4], bv[2];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) av[t] = P[(4 * kk + q) * LDH + t * 16 + j];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) bv[t] = X[(4 * kk + q) * LDX + t * 16 + j];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                gW1[mt][0] = MFMA4(av[mt], bv[0], gW1[mt][0]);
+                gW1[mt][1] = MFMA4(av[mt], bv[1], gW1[mt][1]);
+            }
+        }
+        // ---- dX = dZ1 W1 : B[k = o][n = i] = W1[o][i]
+        f32x4 dx[2];
+        dx[0] = dx[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const float x = P[j * LDH + 4 * kk + q];
+            dx[0] = MFMA4(x, sW1[(4 * kk + q) * LDX + j], dx[0]);
+            dx[1] = MFMA4(x, sW1[(4 * kk + q) * LDX + 16 + j], dx[1]);
+        }
+        // lane holds dX[s = q*4 + r][i = nt*16 + j] -> level-major dfeat
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int i = nt * 16 + j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t m = m0 + q * 4 + r;
+                if (m < M) dfeat[((int64_t)(i >> 1) * a.level_stride + m) * 2 + (i & 1)] = dx[nt][r];
+            }
+        }
+    }
+
+    // ---- one slab per wavefront (deterministic; summed by k_mlp_reduce_slabs)
+    float *slab = slabs + ((int64_t)blockIdx.x * 4 + w) * SLAB;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = mt * 16 + q * 4 + r;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) slab[SL_W2 + o * HID + nt * 16 + j] = gW2[mt][nt][r];
+            slab[SL_W1 + o * IN + j] = gW1[mt][0][r];
+            slab[SL_W1 + o * IN + 16 + j] = gW1[mt][1][r];
+        }
+    // dW3: C rows = n3 (q*4 + r), cols = h (nt*16 + j)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[SL_W3 + (q * 4 + r) * HID + nt * 16 + j] = gW3[nt][r];
+    // biases: gb1/gb2 hold per-lane sums over this lane's 4 rows; add the 4 lane groups (q)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        float v1 = gb1[nt], v2 = gb2[nt];
+        v1 += __shfl_xor(v1, 16, 64); v1 += __shfl_xor(v1, 32, 64);
+        v2 += __shfl_xor(v2, 16, 64); v2 += __shfl_xor(v2, 32, 64);
+        if (q == 0) { slab[SL_B1 + nt * 16 + j] = v1; slab[SL_B2 + nt * 16 + j] = v2; }
+    }
+    // gb3[kk]: lane (s = j, k = 4kk + q) -> sum over the 16 lanes j
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        float v = gb3[kk];
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+        if (j == 0) slab[SL_B3 + 4 * kk + q] = v;
+    }
+    if (lane < 8) slab[SL_B3 + 8 + lane] = 0.f;
+}
+
+__global__ void __launch_bounds__(256)
+k_mlp_reduce_slabs(const float *__restrict__ slabs, int n_slabs, int out_dim, float *__restrict__ dw1,
+                   float *__restrict__ db1, float *__restrict__ dw2, float *__restrict__ db2, float *__restrict__ dw3,
+                   float *__restrict__ db3) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= SLAB) return;
+    float s = 0.f;
+    for (int b = 0; b < n_slabs; ++b) s += slabs[(int64_t)b * SLAB + p];
+    if (p < SL_B1) dw1[p - SL_W1] += s;
+    else if (p < SL_W2) db1[p - SL_B1] += s;
+    else if (p < SL_B2) dw2[p - SL_W2] += s;
+    else if (p < SL_W3) db2[p - SL_B2] += s;
+    else if (p < SL_B3) { if ((p - SL_W3) / HID < out_dim) dw3[p - SL_W3] += s; }
+    else { if (p - SL_B3 < out_dim) db3[p - SL_B3] += s; }
+}
+
+static int mlp_common_checks(const char *who, const void *feat, int feat_dtype, int64_t level_stride, const float *xyzs,
+                             const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
+                             const float *b3, int out_dim, float blob_std, int64_t m_host, int precision) {
+    LNERF_REQUIRE(m_host >= 0 && level_stride >= m_host, "%s: need 0 <= m_host <= level_stride", who);
+    LNERF_REQUIRE(out_dim >= 2 && out_dim <= 8, "%s: out_dim must be in [2,8] (got %d)", who, out_dim);
+    LNERF_REQUIRE(feat_dtype == LNERF_F32 || feat_dtype == LNERF_BF16, "%s: bad feat dtype", who);
+    LNERF_REQUIRE(precision == LNERF_F32 || precision == LNERF_BF16, "%s: bad precision tag", who);
+    LNERF_REQUIRE(blob_std > 0.f, "%s: blob_std must be > 0", who);
+    if (m_host > 0) LNERF_REQUIRE(feat && xyzs && w1 && b1 && w2 && b2 && w3 && b3, "%s: null pointer", who);
+    return LNERF_OK;
+}
+
+}  // namespace lnerf
+
+using namespace lnerf;
+
+extern "C" {
+
+int lnerf_mlp_forward(const void *feat, int feat_dtype, int64_t level_stride, const float *xyzs, const float *w1,
+                      const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, int out_dim,
+                      float blob_scale, float blob_std, int64_t m_host, const int32_t *m_dev, float *sigmas,
+                      float *rgbs, int precision, lnerf_stream_t stream) {
+    int rc = mlp_common_checks("mlp_forward", feat, feat_dtype, level_stride, xyzs, w1, b1, w2, b2, w3, b3, out_dim,
+                               blob_std, m_host, precision);
+    if (rc) return rc;
+    if (m_host == 0) return LNERF_OK;
+    LNERF_REQUIRE(sigmas && rgbs, "mlp_forward: null output");
+    LNERF_REQUIRE(precision == LNERF_F32, "mlp_forward: bf16 precision is not built yet");
+    MlpArgs a{feat, feat_dtype == LNERF_BF16, level_stride, xyzs, w1, b1, w2, b2, w3, b3, out_dim, blob_scale,
+              2.0f * blob_std * blob_std, m_host, m_dev};
+    int64_t blocks = div_up(m_host, 64);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_mlp_forward_f32, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a, sigmas, rgbs);
+    LNERF_CHECK_LAUNCH("mlp_forward");
+    return LNERF_OK;
+}
+
+size_t lnerf_mlp_backward_workspace_bytes(int out_dim) {
+    (void)out_dim;
+    return (size_t)BWD_MAX_BLOCKS * 4 * SLAB * sizeof(float);
+}
+
+int lnerf_mlp_backward(const void *feat, int feat_dtype, int64_t level_stride, const float *xyzs, const float *w1,
+                       const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, int out_dim,
+                       float blob_scale, float blob_std, int64_t m_host, const int32_t *m_dev, const float *sigmas,
+                       const float *dsigmas, const float *drgbs, float *dfeat, float *dw1, float *db1, float *dw2,
+                       float *db2, float *dw3, float *db3, void *workspace, size_t workspace_bytes, int precision,
+                       lnerf_stream_t stream) {
+    int rc = mlp_common_checks("mlp_backward", feat, feat_dtype, level_stride, xyzs, w1, b1, w2, b2, w3, b3, out_dim,
+                               blob_std, m_host, precision);
+    if (rc) return rc;
+    if (m_host == 0) return LNERF_OK;
+    LNERF_REQUIRE(sigmas && dsigmas && drgbs && dfeat && dw1 && db1 && dw2 && db2 && dw3 && db3,
+                  "mlp_backward: null pointer");
+    LNERF_REQUIRE(precision == LNERF_F32, "mlp_backward: bf16 precision is not built yet");
+    LNERF_REQUIRE(workspace && workspace_bytes >= lnerf_mlp_backward_workspace_bytes(out_dim),
+                  "mlp_backward: workspace too small (%zu < %zu)", workspace_bytes,
+                  lnerf_mlp_backward_workspace_bytes(out_dim));
+    MlpArgs a{feat, feat_dtype == LNERF_BF16, level_stride, xyzs, w1, b1, w2, b2, w3, b3, out_dim, blob_scale,
+              2.0f * blob_std * blob_std, m_host, m_dev};
+    int64_t blocks = div_up(m_host, 64);
+    if (blocks > BWD_MAX_BLOCKS) blocks = BWD_MAX_BLOCKS;
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(k_mlp_backward_f32, dim3((unsigned)blocks), dim3(256), 0, s, a, sigmas, dsigmas, drgbs, dfeat,
+                       (float *)workspace);
+    LNERF_CHECK_LAUNCH("mlp_backward");
+    hipLaunchKernelGGL(k_mlp_reduce_slabs, dim3((unsigned)div_up(SLAB, 256)), dim3(256), 0, s,
+                       (const float *)workspace, (int)blocks * 4, out_dim, dw1, db1, dw2, db2, dw3, db3);
+    LNERF_CHECK_LAUNCH("mlp_backward(reduce)");
+    return LNERF_OK;
+}
+
+}  // extern "C"

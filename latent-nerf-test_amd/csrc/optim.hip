@@ -1,0 +1,113 @@
+// Fused Adam step (betas/eps as src/latent_paint/training/trainer.py:93-95 configures torch.optim.Adam)
+// over a flat f32 parameter buffer: one pass reads p,g,m,v and writes p,m,v, optionally clears g
+// and refreshes the bf16 shadow copy that the hash gather reads.  Pure HBM streaming: 16 B/lane.
+#include "common.h"
+
+namespace lnerf {
+
+struct AdamArgs {
+    float lr, beta1, beta2, eps, bc1, bc2, grad_scale;
+    int zero_grad;
+};
+
+__device__ __forceinline__ void adam_one(float &p, float &g, float &m, float &v, const AdamArgs &a) {
+    const float gs = g * a.grad_scale;
+    m = fmaf(a.beta1, m, (1.0f - a.beta1) * gs);
+    v = fmaf(a.beta2, v, (1.0f - a.beta2) * gs * gs);
+    const float mhat = m / a.bc1;
+    const float vhat = v / a.bc2;
+    p = p - a.lr * mhat / (sqrtf(vhat) + a.eps);
+    if (a.zero_grad) g = 0.f;
+}
+
+__global__ void __launch_bounds__(256)
+k_adam(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+       uint16_t *__restrict__ shadow, int64_t n, AdamArgs a) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 P = reinterpret_cast<float4 *>(p)[i], G = reinterpret_cast<float4 *>(g)[i];
+        float4 Mv = reinterpret_cast<float4 *>(m)[i], V = reinterpret_cast<float4 *>(v)[i];
+        adam_one(P.x, G.x, Mv.x, V.x, a);
+        adam_one(P.y, G.y, Mv.y, V.y, a);
+        adam_one(P.z, G.z, Mv.z, V.z, a);
+        adam_one(P.w, G.w, Mv.w, V.w, a);
+        reinterpret_cast<float4 *>(p)[i] = P;
+        reinterpret_cast<float4 *>(m)[i] = Mv;
+        reinterpret_cast<float4 *>(v)[i] = V;
+        if (a.zero_grad) reinterpret_cast<float4 *>(g)[i] = G;
+        if (shadow) {
+            uint2 s;
+            s.x = (uint32_t)f32_to_bf16(P.x) | ((uint32_t)f32_to_bf16(P.y) << 16);
+            s.y = (uint32_t)f32_to_bf16(P.z) | ((uint32_t)f32_to_bf16(P.w) << 16);
+            reinterpret_cast<uint2 *>(shadow)[i] = s;
+        }
+    }
+    // tail (n % 4 elements)
+    const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && t < n) {
+        float P = p[t], G = g[t], Mv = m[t], V = v[t];
+        adam_one(P, G, Mv, V, a);
+        p[t] = P; m[t] = Mv; v[t] = V;
+        if (a.zero_grad) g[t] = G;
+        if (shadow) shadow[t] = f32_to_bf16(P);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_cast_bf16(const float *__restrict__ src, uint16_t *__restrict__ dst, int64_t n) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 P = reinterpret_cast<const float4 *>(src)[i];
+        uint2 s;
+        s.x = (uint32_t)f32_to_bf16(P.x) | ((uint32_t)f32_to_bf16(P.y) << 16);
+        s.y = (uint32_t)f32_to_bf16(P.z) | ((uint32_t)f32_to_bf16(P.w) << 16);
+        reinterpret_cast<uint2 *>(dst)[i] = s;
+    }
+    const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && t < n) dst[t] = f32_to_bf16(src[t]);
+}
+
+}  // namespace lnerf
+
+using namespace lnerf;
+
+extern "C" {
+
+int lnerf_adam_step(float *p, float *g, float *m, float *v, void *shadow_bf16, int64_t n, float lr, float beta1,
+                    float beta2, float eps, int step, float grad_scale, int zero_grad, lnerf_stream_t stream) {
+    LNERF_REQUIRE(n >= 0, "adam_step: negative n");
+    LNERF_REQUIRE(step >= 1, "adam_step: step must be >= 1 (got %d)", step);
+    LNERF_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "adam_step: betas must be in [0,1)");
+    if (n == 0) return LNERF_OK;
+    LNERF_REQUIRE(p && g && m && v, "adam_step: null pointer");
+    LNERF_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
+                  "adam_step: buffers must be 16-byte aligned");
+    LNERF_REQUIRE(!shadow_bf16 || ((uintptr_t)shadow_bf16 & 7) == 0, "adam_step: shadow must be 8-byte aligned");
+    AdamArgs a;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+    a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    a.bc2 = (float)(1.0 - pow((double)beta2, (double)step));
+    a.grad_scale = grad_scale;
+    a.zero_grad = zero_grad;
+    int64_t blocks = div_up(div_up(n, 4), 256);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, g, m, v,
+                       (uint16_t *)shadow_bf16, n, a);
+    LNERF_CHECK_LAUNCH("adam_step");
+    return LNERF_OK;
+}
+
+int lnerf_cast_f32_to_bf16(const float *src, void *dst, int64_t n, lnerf_stream_t stream) {
+    LNERF_REQUIRE(n >= 0, "cast_f32_to_bf16: negative n");
+    if (n == 0) return LNERF_OK;
+    LNERF_REQUIRE(src && dst, "cast_f32_to_bf16: null pointer");
+    LNERF_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 7) == 0, "cast_f32_to_bf16: misaligned buffers");
+    int64_t blocks = div_up(div_up(n, 4), 256);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_cast_bf16, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), src, (uint16_t *)dst, n);
+    LNERF_CHECK_LAUNCH("cast_f32_to_bf16");
+    return LNERF_OK;
+}
+
+}  // extern "C"

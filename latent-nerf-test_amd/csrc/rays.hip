@@ -1,0 +1,623 @@
+// H1 ray generation, H2 AABB slab test, H3 Morton/bitfield, H4 occupancy-pruned march
+// (training: count -> scan -> write; inference: march_rays / compact_rays).
+// gfx950 only: wave64 ballot / mbcnt compaction, one wavefront per ray.
+#include "common.h"
+
+#include <math.h>
+
+namespace lnerf {
+
+// ------------------------------------------------------------------ H1
+__global__ void __launch_bounds__(256) k_get_rays(const float *__restrict__ c2w, int B, int H, int W, float fx,
+                                                  float fy, float cx, float cy, float *__restrict__ rays_o,
+                                                  float *__restrict__ rays_d) {
+    const int64_t total = (int64_t)B * H * W;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(g / ((int64_t)H * W));
+        const int p = (int)(g - (int64_t)b * H * W);
+        const int j = p / W, i = p - j * W;
+        const float *m = c2w + (int64_t)b * 16;
+        const float xs = ((float)i + 0.5f - cx) / fx;
+        const float ys = ((float)j + 0.5f - cy) / fy;
+        const float inv = 1.0f / sqrtf(xs * xs + ys * ys + 1.0f);
+        const float d0 = xs * inv, d1 = ys * inv, d2 = inv;
+        float *o = rays_o + g * 3, *d = rays_d + g * 3;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            d[r] = d0 * m[r * 4 + 0] + d1 * m[r * 4 + 1] + d2 * m[r * 4 + 2];
+            o[r] = m[r * 4 + 3];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ H2
+__global__ void __launch_bounds__(256) k_near_far(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                  int64_t N, float xmin, float ymin, float zmin, float xmax, float ymax,
+                                                  float zmax, float min_near, float *__restrict__ nears,
+                                                  float *__restrict__ fars) {
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+        const float rdx = 1.0f / rays_d[n * 3], rdy = 1.0f / rays_d[n * 3 + 1], rdz = 1.0f / rays_d[n * 3 + 2];
+        const float ax = (xmin - ox) * rdx, bx = (xmax - ox) * rdx;
+        const float ay = (ymin - oy) * rdy, by = (ymax - oy) * rdy;
+        const float az = (zmin - oz) * rdz, bz = (zmax - oz) * rdz;
+        float near = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+        float far = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+        bool miss = !(far >= near);
+        near = fmaxf(near, min_near);
+        miss = miss || !(far >= near);
+        if (miss) near = far = 3.4028234663852886e38f;
+        nears[n] = near;
+        fars[n] = far;
+    }
+}
+
+// ------------------------------------------------------------------ H3
+__global__ void __launch_bounds__(256) k_morton3d(const int32_t *__restrict__ coords, int64_t n,
+                                                  uint32_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = morton3d((uint32_t)coords[i * 3], (uint32_t)coords[i * 3 + 1], (uint32_t)coords[i * 3 + 2]);
+}
+__global__ void __launch_bounds__(256) k_morton3d_invert(const uint32_t *__restrict__ idx, int64_t n,
+                                                         int32_t *__restrict__ coords) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t v = idx[i];
+        coords[i * 3] = (int32_t)compact_bits(v);
+        coords[i * 3 + 1] = (int32_t)compact_bits(v >> 1);
+        coords[i * 3 + 2] = (int32_t)compact_bits(v >> 2);
+    }
+}
+// one thread per output byte; the 8 cells of a byte are two aligned float4 loads
+__global__ void __launch_bounds__(256) k_packbits(const float *__restrict__ grid, int64_t n_bytes, float thresh,
+                                                  const float *__restrict__ mean_dev, uint8_t *__restrict__ bits) {
+    const float th = mean_dev ? fminf(thresh, *mean_dev) : thresh;
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_bytes; b += (int64_t)gridDim.x * blockDim.x) {
+        const float4 lo = reinterpret_cast<const float4 *>(grid)[b * 2];
+        const float4 hi = reinterpret_cast<const float4 *>(grid)[b * 2 + 1];
+        uint32_t v = 0;
+        v |= (lo.x > th) ? 1u : 0u;
+        v |= (lo.y > th) ? 2u : 0u;
+        v |= (lo.z > th) ? 4u : 0u;
+        v |= (lo.w > th) ? 8u : 0u;
+        v |= (hi.x > th) ? 16u : 0u;
+        v |= (hi.y > th) ? 32u : 0u;
+        v |= (hi.z > th) ? 64u : 0u;
+        v |= (hi.w > th) ? 128u : 0u;
+        bits[b] = (uint8_t)v;
+    }
+}
+
+// ------------------------------------------------------------------ H4 occupancy test
+struct MarchParams {
+    float bound;
+    int cascade;
+    int G;
+    int max_steps;
+    float dt_gamma;
+    float dt_min;
+    float dt_max;
+};
+
+// x already clamped to [-bound, bound].  Op order mirrors oracle/nerf_oracle.py::march_cell_index.
+__device__ __forceinline__ bool cell_occupied(float x, float y, float z, float dt, const MarchParams &P,
+                                              const uint8_t *__restrict__ bitfield) {
+    int level = 0;
+    float mip_bound = fminf(1.0f, P.bound);
+    if (P.cascade > 1) {
+        const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+        int e0, e1;
+        (void)frexpf(mx, &e0);
+        (void)frexpf(dt * (0.5f * (float)P.G), &e1);
+        e0 = min(P.cascade - 1, max(0, e0));
+        e1 = min(P.cascade - 1, max(0, e1));
+        level = max(e0, e1);
+        mip_bound = fminf(ldexpf(1.0f, level), P.bound);
+    }
+    const float rb = 1.0f / mip_bound;
+    const float halfG = 0.5f * (float)P.G;
+    const float gm1 = (float)(P.G - 1);
+    float ux = x * rb, uy = y * rb, uz = z * rb;
+    ux = ux + 1.0f; uy = uy + 1.0f; uz = uz + 1.0f;
+    ux = ux * halfG; uy = uy * halfG; uz = uz * halfG;
+    const uint32_t nx = (uint32_t)(int)clampf(ux, 0.0f, gm1);
+    const uint32_t ny = (uint32_t)(int)clampf(uy, 0.0f, gm1);
+    const uint32_t nz = (uint32_t)(int)clampf(uz, 0.0f, gm1);
+    const uint32_t idx = (uint32_t)level * (uint32_t)(P.G * P.G * P.G) + morton3d(nx, ny, nz);
+    return (bitfield[idx >> 3] >> (idx & 7u)) & 1u;
+}
+
+// One wavefront per ray.  Each iteration tests 64 consecutive lattice points of the ray;
+// ballot + popcount gives the count (pass 1) or, with mbcnt, each sample's slot (pass 2).
+template <bool WRITE, bool UNIFORM_DT>
+__global__ void __launch_bounds__(256)
+k_march_train(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ nears,
+              const float *__restrict__ fars, int64_t N, const uint8_t *__restrict__ bitfield, MarchParams P,
+              const float *__restrict__ noises, float *__restrict__ xyzs, float *__restrict__ dirs,
+              float *__restrict__ deltas, int32_t *__restrict__ rays) {
+    const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform
+    if (n >= N) return;
+    const int lane = lane_id();
+    const float near = nears[n], far = fars[n];
+    int count = 0;
+    int64_t offset = 0;
+    int budget = P.max_steps;
+    if (WRITE) {
+        offset = rays[n * 3 + 1];
+        budget = rays[n * 3 + 2];  // 0 if the ray was dropped for capacity
+    }
+    if (near < far && budget > 0) {
+        const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+        const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+        const float dt0 = clampf(near * P.dt_gamma, P.dt_min, P.dt_max);
+        const float noise = noises ? noises[n] : 0.0f;
+        const float t0 = near + dt0 * noise;
+        float t = t0;
+        if (!UNIFORM_DT) {  // lane l starts at lattice point l
+            for (int i = 0; i < lane; ++i) t = t + clampf(t * P.dt_gamma, P.dt_min, P.dt_max);
+        }
+        for (int base = 0; base < (1 << 22); base += 64) {  // bound: a non-finite `far` must not spin
+            float dt;
+            if (UNIFORM_DT) {
+                dt = P.dt_min;
+                t = (float)(base + lane) * dt;
+                t = t + t0;
+            } else {
+                dt = clampf(t * P.dt_gamma, P.dt_min, P.dt_max);
+            }
+            const bool valid = t < far;
+            if (__ballot(valid) == 0ull) break;  // lattice is monotone: nothing further is valid
+            float x = dx * t, y = dy * t, z = dz * t;
+            x = x + ox; y = y + oy; z = z + oz;
+            x = clampf(x, -P.bound, P.bound);
+            y = clampf(y, -P.bound, P.bound);
+            z = clampf(z, -P.bound, P.bound);
+            const bool occ = valid && cell_occupied(x, y, z, dt, P, bitfield);
+            const unsigned long long mask = __ballot(occ);
+            const int rank = count + mbcnt(mask);
+            if (WRITE && occ && rank < budget) {
+                const int64_t s = offset + rank;
+                xyzs[s * 3] = x; xyzs[s * 3 + 1] = y; xyzs[s * 3 + 2] = z;
+                dirs[s * 3] = dx; dirs[s * 3 + 1] = dy; dirs[s * 3 + 2] = dz;
+                deltas[s * 2] = dt; deltas[s * 2 + 1] = t;
+            }
+            count += __popcll(mask);
+            if (count >= budget) { count = budget; break; }
+            if (!UNIFORM_DT) {
+                for (int i = 0; i < 64; ++i) t = t + clampf(t * P.dt_gamma, P.dt_min, P.dt_max);
+            }
+        }
+    }
+    if (!WRITE && lane == 0) {
+        rays[n * 3] = (int32_t)n;
+        rays[n * 3 + 1] = 0;
+        rays[n * 3 + 2] = count;
+    }
+}
+
+// Single-workgroup exclusive scan of the per-ray counts (N is a few thousand per view).
+// Also counts live rays and drops rays that would overflow `capacity`.
+__global__ void __launch_bounds__(1024) k_march_scan(int32_t *__restrict__ rays, int64_t N, int64_t capacity,
+                                                     int32_t *__restrict__ counter) {
+    __shared__ int wave_tot[16];
+    __shared__ int wave_live[16];
+    __shared__ long long carry_s;
+    __shared__ int live_s, drop_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) { carry_s = 0; live_s = 0; drop_s = 0; }
+    __syncthreads();
+    for (int64_t base = 0; base < N; base += 1024) {
+        const int64_t n = base + tid;
+        const int c = (n < N) ? rays[n * 3 + 2] : 0;
+        const int inc = wave_inclusive_sum_i(c);
+        if (lane == 63) wave_tot[wid] = inc;
+        __syncthreads();
+        int wave_off = 0;
+        for (int w = 0; w < wid; ++w) wave_off += wave_tot[w];
+        const long long carry = carry_s;
+        const long long off = carry + wave_off + inc - c;
+        int cc = c;
+        const bool dropped = (c > 0) && (off + c > capacity);
+        if (dropped) cc = 0;
+        if (n < N) {
+            rays[n * 3 + 1] = (int32_t)(dropped ? 0 : off);
+            rays[n * 3 + 2] = cc;
+        }
+        const unsigned long long lm = __ballot(cc > 0);
+        const unsigned long long dm = __ballot(dropped);
+        if (lane == 0) {
+            wave_live[wid] = __popcll(lm);
+            atomicAdd(&drop_s, __popcll(dm));
+        }
+        __syncthreads();
+        if (tid == 0) {
+            long long tot = 0;
+            int lv = 0;
+            for (int w = 0; w < 16; ++w) { tot += wave_tot[w]; lv += wave_live[w]; }
+            carry_s = carry + tot;
+            live_s += lv;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const long long total = carry_s;
+        counter[0] = (int32_t)(total > capacity ? capacity : total);
+        counter[1] = live_s;
+        counter[2] = drop_s;
+        counter[3] = 0;
+    }
+}
+
+// M = offset of the first dropped ray when rays were dropped (samples after it are never written)
+__global__ void k_march_fix_total(const int32_t *__restrict__ rays, int64_t N, int32_t *__restrict__ counter) {
+    // only needed when counter[2] > 0: recompute M as max(offset+count) over kept rays
+    if (counter[2] == 0) return;
+    __shared__ int best;
+    if (threadIdx.x == 0) best = 0;
+    __syncthreads();
+    int loc = 0;
+    for (int64_t n = threadIdx.x; n < N; n += blockDim.x) loc = max(loc, rays[n * 3 + 1] + rays[n * 3 + 2]);
+    atomicMax(&best, loc);
+    __syncthreads();
+    if (threadIdx.x == 0) counter[0] = best;
+}
+
+// ------------------------------------------------------------------ H4 inference
+// One thread per alive ray: emit up to n_step occupied lattice samples starting at rays_t.
+__global__ void __launch_bounds__(256)
+k_march_rays(int64_t n_alive, int n_step, const int32_t *__restrict__ rays_alive, const float *__restrict__ rays_t,
+             const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ fars,
+             const uint8_t *__restrict__ bitfield, MarchParams P, float *__restrict__ xyzs, float *__restrict__ dirs,
+             float *__restrict__ deltas) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_alive) return;
+    const int32_t n = rays_alive[i];
+    float *px = xyzs + i * n_step * 3, *pd = dirs + i * n_step * 3, *pt = deltas + i * n_step * 2;
+    int step = 0;
+    if (n >= 0) {
+        const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+        const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+        const float far = fars[n];
+        float t = rays_t[n];
+        int guard = 0;
+        while (t < far && step < n_step && guard < (1 << 22)) {
+            const float dt = clampf(t * P.dt_gamma, P.dt_min, P.dt_max);
+            float x = dx * t, y = dy * t, z = dz * t;
+            x = x + ox; y = y + oy; z = z + oz;
+            x = clampf(x, -P.bound, P.bound);
+            y = clampf(y, -P.bound, P.bound);
+            z = clampf(z, -P.bound, P.bound);
+            if (cell_occupied(x, y, z, dt, P, bitfield)) {
+                px[step * 3] = x; px[step * 3 + 1] = y; px[step * 3 + 2] = z;
+                pd[step * 3] = dx; pd[step * 3 + 1] = dy; pd[step * 3 + 2] = dz;
+                pt[step * 2] = dt; pt[step * 2 + 1] = t;
+                ++step;
+            }
+            t = t + dt;
+            ++guard;
+        }
+    }
+    for (; step < n_step; ++step) {  // padding: dt = 0 contributes nothing; t < 0 marks "ray exhausted"
+        px[step * 3] = 0.f; px[step * 3 + 1] = 0.f; px[step * 3 + 2] = 0.f;
+        pd[step * 3] = 0.f; pd[step * 3 + 1] = 0.f; pd[step * 3 + 2] = 1.f;
+        pt[step * 2] = 0.f; pt[step * 2 + 1] = -1.f;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_composite_rays(int64_t n_alive, int n_step, int32_t *__restrict__ rays_alive, float *__restrict__ rays_t,
+                 const float *__restrict__ sigmas, const float *__restrict__ rgbs, const float *__restrict__ deltas,
+                 int C, float T_thresh, float *__restrict__ weights_sum, float *__restrict__ depth,
+                 float *__restrict__ image, float *__restrict__ transmittance) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_alive) return;
+    const int32_t n = rays_alive[i];
+    if (n < 0) return;
+    const float *sg = sigmas + i * n_step, *rg = rgbs + i * n_step * C, *dl = deltas + i * n_step * 2;
+    float T = transmittance[n], ws = weights_sum[n], d = depth[n];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < C; ++c) acc[c] = image[n * C + c];
+    float t_last = rays_t[n];
+    bool alive = true;
+    int step = 0;
+    for (; step < n_step; ++step) {
+        const float dt = dl[step * 2], t = dl[step * 2 + 1];
+        if (t < 0.f) { alive = false; break; }  // march ran past `far`
+        const float alpha = 1.0f - __expf(-sg[step] * dt);
+        const float w = alpha * T;
+        ws += w;
+        d = fmaf(w, t, d);
+        for (int c = 0; c < C; ++c) acc[c] = fmaf(w, rg[step * C + c], acc[c]);
+        T *= 1.0f - alpha;
+        t_last = t + dt;
+        if (T < T_thresh) { alive = false; break; }
+    }
+    transmittance[n] = T;
+    weights_sum[n] = ws;
+    depth[n] = d;
+    for (int c = 0; c < C; ++c) image[n * C + c] = acc[c];
+    rays_t[n] = t_last;
+    if (!alive) rays_alive[i] = -1;
+}
+
+// Live-ray compaction: keep entries >= 0, preserve order.  Single workgroup, wave ballot +
+// mbcnt prefix, LDS carry across waves.
+__global__ void __launch_bounds__(1024) k_compact_rays(const int32_t *__restrict__ in, int64_t n,
+                                                       int32_t *__restrict__ out, int32_t *__restrict__ n_out) {
+    __shared__ int wave_cnt[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int64_t i = base + tid;
+        const int32_t v = (i < n) ? in[i] : -1;
+        const bool keep = v >= 0;
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) wave_cnt[wid] = __popcll(m);
+        __syncthreads();
+        int off = carry_s;
+        for (int w = 0; w < wid; ++w) off += wave_cnt[w];
+        if (keep) out[off + mbcnt(m)] = v;
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; ++w) tot += wave_cnt[w];
+            carry_s += tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *n_out = carry_s;
+}
+
+// ------------------------------------------------------------------ H10 helpers
+__global__ void __launch_bounds__(256)
+k_occ_cell_points(const uint32_t *__restrict__ indices, int64_t n, float mip_bound, int G,
+                  const float *__restrict__ noise, float *__restrict__ xyzs) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t idx = indices ? indices[i] : (uint32_t)i;
+        const float cx = (float)compact_bits(idx), cy = (float)compact_bits(idx >> 1), cz = (float)compact_bits(idx >> 2);
+        const float nx = noise ? noise[i * 3] : 0.5f, ny = noise ? noise[i * 3 + 1] : 0.5f,
+                    nz = noise ? noise[i * 3 + 2] : 0.5f;
+        const float s = 2.0f / (float)G;
+        float ux = cx + nx, uy = cy + ny, uz = cz + nz;
+        ux = ux * s; uy = uy * s; uz = uz * s;
+        ux = ux - 1.0f; uy = uy - 1.0f; uz = uz - 1.0f;
+        xyzs[i * 3] = ux * mip_bound;
+        xyzs[i * 3 + 1] = uy * mip_bound;
+        xyzs[i * 3 + 2] = uz * mip_bound;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_occ_update(float *__restrict__ grid, const uint32_t *__restrict__ indices,
+                                                    int64_t n, const float *__restrict__ sig, float decay) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t idx = indices ? indices[i] : (uint32_t)i;
+        const float old = grid[idx], s = sig[i];
+        if (old >= 0.f && s >= 0.f) grid[idx] = fmaxf(old * decay, s);
+    }
+}
+
+// mean of max(grid, 0) over all cells; scratch = {sum, unused}
+__global__ void __launch_bounds__(256) k_occ_mean_partial(const float *__restrict__ grid, int64_t n,
+                                                          float *__restrict__ scratch) {
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        s += fmaxf(grid[i], 0.f);
+    s = wave_sum(s);
+    if (lane_id() == 0) atomicAdd(&scratch[0], s);
+}
+__global__ void k_occ_mean_final(const float *__restrict__ scratch, float n, float *__restrict__ mean) {
+    *mean = scratch[0] / n;
+}
+
+static MarchParams make_params(float bound, int cascade, int G, int max_steps, float dt_gamma) {
+    MarchParams P;
+    P.bound = bound;
+    P.cascade = cascade;
+    P.G = G;
+    P.max_steps = max_steps;
+    P.dt_gamma = dt_gamma;
+    P.dt_min = (float)(2.0 * 1.7320508075688772 / (double)max_steps);
+    P.dt_max = (float)(2.0 * 1.7320508075688772 * (double)(1 << (cascade - 1)) / (double)G);
+    return P;
+}
+
+static int grid_for(int64_t n, int block = 256, int cap = 4096) {
+    int64_t g = div_up(n, block);
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+}  // namespace lnerf
+
+using namespace lnerf;
+
+extern "C" {
+
+int lnerf_get_rays(const float *c2w, int B, int H, int W, float fx, float fy, float cx, float cy, float *rays_o,
+                   float *rays_d, lnerf_stream_t stream) {
+    LNERF_REQUIRE(c2w && rays_o && rays_d, "get_rays: null pointer");
+    LNERF_REQUIRE(B > 0 && H > 0 && W > 0, "get_rays: B,H,W must be positive (got %d,%d,%d)", B, H, W);
+    LNERF_REQUIRE(fx != 0.f && fy != 0.f, "get_rays: zero focal length");
+    const int64_t total = (int64_t)B * H * W;
+    hipLaunchKernelGGL(k_get_rays, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), c2w, B, H, W, fx, fy, cx, cy,
+                       rays_o, rays_d);
+    LNERF_CHECK_LAUNCH("get_rays");
+    return LNERF_OK;
+}
+
+int lnerf_near_far_from_aabb(const float *rays_o, const float *rays_d, int64_t N, float xmin, float ymin, float zmin,
+                             float xmax, float ymax, float zmax, float min_near, float *nears, float *fars,
+                             lnerf_stream_t stream) {
+    LNERF_REQUIRE(N >= 0, "near_far_from_aabb: negative N");
+    if (N == 0) return LNERF_OK;
+    LNERF_REQUIRE(rays_o && rays_d && nears && fars, "near_far_from_aabb: null pointer");
+    LNERF_REQUIRE(xmin <= xmax && ymin <= ymax && zmin <= zmax, "near_far_from_aabb: inverted aabb");
+    hipLaunchKernelGGL(k_near_far, dim3(grid_for(N)), dim3(256), 0, as_stream(stream), rays_o, rays_d, N, xmin, ymin,
+                       zmin, xmax, ymax, zmax, min_near, nears, fars);
+    LNERF_CHECK_LAUNCH("near_far_from_aabb");
+    return LNERF_OK;
+}
+
+int lnerf_morton3d(const int32_t *coords, int64_t n, uint32_t *indices, lnerf_stream_t stream) {
+    LNERF_REQUIRE(n >= 0, "morton3d: negative n");
+    if (n == 0) return LNERF_OK;
+    LNERF_REQUIRE(coords && indices, "morton3d: null pointer");
+    hipLaunchKernelGGL(k_morton3d, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), coords, n, indices);
+    LNERF_CHECK_LAUNCH("morton3d");
+    return LNERF_OK;
+}
+
+int lnerf_morton3d_invert(const uint32_t *indices, int64_t n, int32_t *coords, lnerf_stream_t stream) {
+    LNERF_REQUIRE(n >= 0, "morton3d_invert: negative n");
+    if (n == 0) return LNERF_OK;
+    LNERF_REQUIRE(coords && indices, "morton3d_invert: null pointer");
+    hipLaunchKernelGGL(k_morton3d_invert, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), indices, n, coords);
+    LNERF_CHECK_LAUNCH("morton3d_invert");
+    return LNERF_OK;
+}
+
+int lnerf_packbits(const float *grid, int64_t n_cells, float thresh, const float *mean_dev, uint8_t *bitfield,
+                   lnerf_stream_t stream) {
+    LNERF_REQUIRE(n_cells >= 0 && n_cells % 8 == 0, "packbits: n_cells (%lld) must be a multiple of 8",
+                  (long long)n_cells);
+    if (n_cells == 0) return LNERF_OK;
+    LNERF_REQUIRE(grid && bitfield, "packbits: null pointer");
+    LNERF_REQUIRE(((uintptr_t)grid & 15) == 0, "packbits: grid must be 16-byte aligned");
+    hipLaunchKernelGGL(k_packbits, dim3(grid_for(n_cells / 8)), dim3(256), 0, as_stream(stream), grid, n_cells / 8,
+                       thresh, mean_dev, bitfield);
+    LNERF_CHECK_LAUNCH("packbits");
+    return LNERF_OK;
+}
+
+static int check_march_common(const char *who, float bound, int cascade, int grid_size, int max_steps, float dt_gamma) {
+    LNERF_REQUIRE(bound > 0.f, "%s: bound must be > 0", who);
+    LNERF_REQUIRE(cascade >= 1 && cascade <= 8, "%s: cascade must be in [1,8] (got %d)", who, cascade);
+    LNERF_REQUIRE(grid_size >= 8 && grid_size <= 1024 && (grid_size & (grid_size - 1)) == 0,
+                  "%s: grid_size must be a power of two in [8,1024] (got %d)", who, grid_size);
+    LNERF_REQUIRE((int64_t)cascade * grid_size * grid_size * grid_size <= (int64_t)1 << 31,
+                  "%s: occupancy grid too large", who);
+    LNERF_REQUIRE(max_steps >= 1 && max_steps <= 65536, "%s: max_steps out of range (%d)", who, max_steps);
+    LNERF_REQUIRE(dt_gamma >= 0.f, "%s: dt_gamma must be >= 0", who);
+    return LNERF_OK;
+}
+
+int lnerf_march_rays_train(const float *rays_o, const float *rays_d, const float *nears, const float *fars, int64_t N,
+                           const uint8_t *bitfield, float bound, int cascade, int grid_size, int max_steps,
+                           float dt_gamma, const float *noises, int64_t capacity, float *xyzs, float *dirs,
+                           float *deltas, int32_t *rays, int32_t *counter, lnerf_stream_t stream) {
+    int rc = check_march_common("march_rays_train", bound, cascade, grid_size, max_steps, dt_gamma);
+    if (rc) return rc;
+    LNERF_REQUIRE(N >= 0 && N <= ((int64_t)1 << 24), "march_rays_train: N out of range (%lld)", (long long)N);
+    LNERF_REQUIRE(capacity >= 0 && capacity <= 0x7FFFFFFFll, "march_rays_train: capacity out of range");
+    LNERF_REQUIRE(counter, "march_rays_train: null counter");
+    if (N == 0) {
+        (void)hipMemsetAsync(counter, 0, 4 * sizeof(int32_t), as_stream(stream));
+        return LNERF_OK;
+    }
+    LNERF_REQUIRE(rays_o && rays_d && nears && fars && bitfield && rays, "march_rays_train: null pointer");
+    LNERF_REQUIRE(capacity == 0 || (xyzs && dirs && deltas), "march_rays_train: null sample buffers");
+    const MarchParams P = make_params(bound, cascade, grid_size, max_steps, dt_gamma);
+    const dim3 block(256), grid((unsigned)div_up(N, 4));  // 4 wavefronts (rays) per workgroup
+    hipStream_t s = as_stream(stream);
+    if (dt_gamma == 0.f)
+        hipLaunchKernelGGL((k_march_train<false, true>), grid, block, 0, s, rays_o, rays_d, nears, fars, N, bitfield, P,
+                           noises, xyzs, dirs, deltas, rays);
+    else
+        hipLaunchKernelGGL((k_march_train<false, false>), grid, block, 0, s, rays_o, rays_d, nears, fars, N, bitfield,
+                           P, noises, xyzs, dirs, deltas, rays);
+    LNERF_CHECK_LAUNCH("march_rays_train(count)");
+    hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, s, rays, N, capacity, counter);
+    LNERF_CHECK_LAUNCH("march_rays_train(scan)");
+    hipLaunchKernelGGL(k_march_fix_total, dim3(1), dim3(1024), 0, s, rays, N, counter);
+    LNERF_CHECK_LAUNCH("march_rays_train(fix)");
+    if (dt_gamma == 0.f)
+        hipLaunchKernelGGL((k_march_train<true, true>), grid, block, 0, s, rays_o, rays_d, nears, fars, N, bitfield, P,
+                           noises, xyzs, dirs, deltas, rays);
+    else
+        hipLaunchKernelGGL((k_march_train<true, false>), grid, block, 0, s, rays_o, rays_d, nears, fars, N, bitfield, P,
+                           noises, xyzs, dirs, deltas, rays);
+    LNERF_CHECK_LAUNCH("march_rays_train(write)");
+    return LNERF_OK;
+}
+
+int lnerf_march_rays(int64_t n_alive, int n_step, const int32_t *rays_alive, const float *rays_t, const float *rays_o,
+                     const float *rays_d, const float *fars, const uint8_t *bitfield, float bound, int cascade,
+                     int grid_size, int max_steps, float dt_gamma, float *xyzs, float *dirs, float *deltas,
+                     lnerf_stream_t stream) {
+    int rc = check_march_common("march_rays", bound, cascade, grid_size, max_steps, dt_gamma);
+    if (rc) return rc;
+    LNERF_REQUIRE(n_alive >= 0 && n_step >= 1, "march_rays: bad n_alive/n_step");
+    if (n_alive == 0) return LNERF_OK;
+    LNERF_REQUIRE(rays_alive && rays_t && rays_o && rays_d && fars && bitfield && xyzs && dirs && deltas,
+                  "march_rays: null pointer");
+    const MarchParams P = make_params(bound, cascade, grid_size, max_steps, dt_gamma);
+    hipLaunchKernelGGL(k_march_rays, dim3((unsigned)div_up(n_alive, 256)), dim3(256), 0, as_stream(stream), n_alive,
+                       n_step, rays_alive, rays_t, rays_o, rays_d, fars, bitfield, P, xyzs, dirs, deltas);
+    LNERF_CHECK_LAUNCH("march_rays");
+    return LNERF_OK;
+}
+
+int lnerf_composite_rays(int64_t n_alive, int n_step, int32_t *rays_alive, float *rays_t, const float *sigmas,
+                         const float *rgbs, const float *deltas, int C, float T_thresh, float *weights_sum,
+                         float *depth, float *image, float *transmittance, lnerf_stream_t stream) {
+    LNERF_REQUIRE(n_alive >= 0 && n_step >= 1, "composite_rays: bad n_alive/n_step");
+    LNERF_REQUIRE(C >= 1 && C <= 4, "composite_rays: C must be in [1,4] (got %d)", C);
+    if (n_alive == 0) return LNERF_OK;
+    LNERF_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image && transmittance,
+                  "composite_rays: null pointer");
+    hipLaunchKernelGGL(k_composite_rays, dim3((unsigned)div_up(n_alive, 256)), dim3(256), 0, as_stream(stream), n_alive,
+                       n_step, rays_alive, rays_t, sigmas, rgbs, deltas, C, T_thresh, weights_sum, depth, image,
+                       transmittance);
+    LNERF_CHECK_LAUNCH("composite_rays");
+    return LNERF_OK;
+}
+
+int lnerf_compact_rays(const int32_t *alive_in, int64_t n, int32_t *alive_out, int32_t *n_alive_dev,
+                       lnerf_stream_t stream) {
+    LNERF_REQUIRE(n >= 0, "compact_rays: negative n");
+    LNERF_REQUIRE(n_alive_dev, "compact_rays: null n_alive_dev");
+    LNERF_REQUIRE(n == 0 || (alive_in && alive_out), "compact_rays: null pointer");
+    LNERF_REQUIRE(alive_in != alive_out || n == 0, "compact_rays: in-place compaction is not supported");
+    hipLaunchKernelGGL(k_compact_rays, dim3(1), dim3(1024), 0, as_stream(stream), alive_in, n, alive_out, n_alive_dev);
+    LNERF_CHECK_LAUNCH("compact_rays");
+    return LNERF_OK;
+}
+
+int lnerf_occ_cell_points(const uint32_t *indices, int64_t n, int cascade_level, int grid_size, float bound,
+                          const float *noise, float *xyzs, lnerf_stream_t stream) {
+    LNERF_REQUIRE(n >= 0 && cascade_level >= 0 && cascade_level < 8 && grid_size > 0 && bound > 0.f,
+                  "occ_cell_points: bad arguments");
+    if (n == 0) return LNERF_OK;
+    LNERF_REQUIRE(xyzs, "occ_cell_points: null xyzs");
+    const float mip_bound = fminf((float)(1 << cascade_level), bound);
+    hipLaunchKernelGGL(k_occ_cell_points, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), indices, n, mip_bound,
+                       grid_size, noise, xyzs);
+    LNERF_CHECK_LAUNCH("occ_cell_points");
+    return LNERF_OK;
+}
+
+int lnerf_occ_update(float *grid_level, const uint32_t *indices, int64_t n, const float *new_sigmas, float decay,
+                     lnerf_stream_t stream) {
+    LNERF_REQUIRE(n >= 0, "occ_update: negative n");
+    if (n == 0) return LNERF_OK;
+    LNERF_REQUIRE(grid_level && new_sigmas, "occ_update: null pointer");
+    hipLaunchKernelGGL(k_occ_update, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), grid_level, indices, n,
+                       new_sigmas, decay);
+    LNERF_CHECK_LAUNCH("occ_update");
+    return LNERF_OK;
+}
+
+int lnerf_occ_mean(const float *grid, int64_t n, float *mean_dev, float *scratch2, lnerf_stream_t stream) {
+    LNERF_REQUIRE(n > 0 && grid && mean_dev && scratch2, "occ_mean: bad arguments");
+    (void)hipMemsetAsync(scratch2, 0, 2 * sizeof(float), as_stream(stream));
+    hipLaunchKernelGGL(k_occ_mean_partial, dim3(grid_for(n, 256, 512)), dim3(256), 0, as_stream(stream), grid, n,
+                       scratch2);
+    LNERF_CHECK_LAUNCH("occ_mean(partial)");
+    hipLaunchKernelGGL(k_occ_mean_final, dim3(1), dim3(1), 0, as_stream(stream), scratch2, (float)n, mean_dev);
+    LNERF_CHECK_LAUNCH("occ_mean(final)");
+    return LNERF_OK;
+}
+
+}  // extern "C"

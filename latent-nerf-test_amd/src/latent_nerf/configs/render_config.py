@@ -1,0 +1,55 @@
+"""Render configuration of the latent-NeRF path.  Field names/defaults follow what the reference
+still advertises for the absent package (`--render.nerf_type latent`,
+cuda_ray, max_steps 1024, update_extra_interval 16, max_ray_batch 4096, density_thresh 10,
+train 64x64, bound 1, dt_gamma 0, min_near 0.1, radius_range (1.0,1.5), fovy_range (40,70)),
+plus the MI355X-specific knobs at the bottom."""
+from dataclasses import dataclass
+from typing import Tuple
+
+from ..models.nerf_utils import NeRFType
+
+
+@dataclass
+class RenderConfig:
+    # Whether to use the occupancy-grid (HIP) ray marcher
+    cuda_ray: bool = True
+    # Maximal number of samples per ray
+    max_steps: int = 1024
+    # Samples per ray of the uniform sampler (non-cuda_ray path)
+    num_steps: int = 128
+    upsample_steps: int = 0
+    # Refresh the occupancy grid every N training steps
+    update_extra_interval: int = 16
+    # Rays per launch at inference
+    max_ray_batch: int = 4096
+    # Occupancy threshold
+    density_thresh: float = 10.0
+    train_w: int = 64
+    train_h: int = 64
+    eval_w: int = 128
+    eval_h: int = 128
+    jitter_pose: bool = False
+    # Scene is assumed inside [-bound, bound]^3
+    bound: float = 1.0
+    dt_gamma: float = 0.0
+    min_near: float = 0.1
+    radius_range: Tuple[float, float] = (1.0, 1.5)
+    fovy_range: Tuple[float, float] = (40.0, 70.0)
+    dir_text: bool = True
+    angle_overhead: float = 30.0
+    angle_front: float = 60.0
+    backbone: str = "grid"
+    nerf_type: NeRFType = NeRFType.latent
+    # > 0 enables the learned background net (bg colour otherwise comes from the caller)
+    bg_radius: float = 0.0
+    # occupancy grid resolution
+    grid_size: int = 128
+    # ---- MI355X knobs
+    # "f32": exact-f32 MFMA MLP (parity path), "bf16": bf16 MFMA, f32 accumulate
+    mlp_precision: str = "f32"
+    # "f32": gather reads the master table, "bf16": gather reads a bf16 shadow (half the bytes)
+    table_dtype: str = "f32"
+    # workgroup -> (level, tile) mapping of the gather/scatter: 0 = level on grid.y, 1 = XCD-aware
+    gather_variant: int = 1
+    # sample buffer capacity per view (0 = rays * min(max_steps, 256))
+    max_samples: int = 0

@@ -1,0 +1,150 @@
+"""Multiresolution hash-grid encoder (Instant-NGP), HIP-backed.  Counterpart of the `gridencoder`
+extension of the absent src/latent_nerf/models/encoders; the level
+table follows the align_corners=False convention recorded there."""
+import ctypes
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..raymarching import backend as _b
+from ..raymarching.raymarching import _chk, _p, _stream
+
+
+class GridLevels:
+    """Host-side level table shared with the kernels (offsets in rows, per-level scale, resolution)."""
+
+    def __init__(self, num_levels=16, level_dim=2, base_resolution=16, desired_resolution=2048,
+                 log2_hashmap_size=19):
+        if level_dim != 2:
+            raise ValueError("only level_dim == 2 is built")
+        if not (1 <= num_levels <= 32):
+            raise ValueError("num_levels must be in [1, 32]")
+        self.num_levels, self.level_dim = num_levels, level_dim
+        self.base_resolution, self.desired_resolution = base_resolution, desired_resolution
+        self.log2_hashmap_size = log2_hashmap_size
+        max_params = 2 ** log2_hashmap_size
+        pls = 2.0 ** (math.log2(desired_resolution / base_resolution) / (num_levels - 1)) if num_levels > 1 else 1.0
+        S = math.log2(pls)
+        offsets, scales, ress = [0], [], []
+        for l in range(num_levels):
+            res_host = int(math.ceil(base_resolution * pls ** l))
+            n = min(max_params, (res_host + 1) ** 3)
+            n = int(math.ceil(n / 8) * 8)
+            offsets.append(offsets[-1] + n)
+            scale = float(np.float32(2.0 ** (l * S) * base_resolution - 1.0))
+            scales.append(scale)
+            ress.append(int(math.ceil(scale)) + 1)
+        self.offsets, self.scales, self.resolutions = offsets, scales, ress
+        self.n_rows = offsets[-1]
+        self.out_dim = num_levels * level_dim
+        # ctypes views handed to the C ABI on every call
+        self.c_offsets = (ctypes.c_int32 * (num_levels + 1))(*offsets)
+        self.c_scales = (ctypes.c_float * num_levels)(*scales)
+        self.c_res = (ctypes.c_int32 * num_levels)(*ress)
+
+
+def grid_encode_forward(xyzs, bound, table, levels: GridLevels, m_host, m_dev, level_stride, out=None,
+                        out_dtype=torch.float32, variant=1):
+    """xyzs [>=m_host,3] world positions -> level-major features [L, level_stride, 2]."""
+    tdt = _b.F32 if table.dtype == torch.float32 else _b.BF16
+    if table.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("table must be float32 or bfloat16")
+    if out is None:
+        out = torch.empty(levels.num_levels, level_stride, 2, device=xyzs.device, dtype=out_dtype)
+    odt = _b.F32 if out.dtype == torch.float32 else _b.BF16
+    _b.call("lnerf_grid_encode_forward", _chk(xyzs, "xyzs"), float(bound), _chk(table, "table", table.dtype), tdt,
+            levels.num_levels, levels.level_dim, levels.c_offsets, levels.c_scales, levels.c_res, int(m_host),
+            _chk(m_dev, "m_dev", torch.int32, allow_none=True), int(level_stride), _chk(out, "feat", out.dtype), odt,
+            int(variant), _stream())
+    return out
+
+
+def grid_encode_backward(xyzs, bound, dfeat, levels: GridLevels, m_host, m_dev, level_stride, dtable, variant=1):
+    """dtable (f32 [rows,2]) += scatter of dfeat (level-major, f32)."""
+    _b.call("lnerf_grid_encode_backward", _chk(xyzs, "xyzs"), float(bound), _chk(dfeat, "dfeat"), _b.F32,
+            levels.num_levels, levels.level_dim, levels.c_offsets, levels.c_scales, levels.c_res, int(m_host),
+            _chk(m_dev, "m_dev", torch.int32, allow_none=True), int(level_stride), _chk(dtable, "dtable"),
+            int(variant), _stream())
+    return dtable
+
+
+class _GridEncode(torch.autograd.Function):
+    """feat = encode(xyzs; table).  `table` is the f32 master parameter (gradient target);
+    `shadow` an optional bf16 copy that the gather actually reads."""
+
+    @staticmethod
+    def forward(ctx, xyzs, table, shadow, levels, bound, m_host, m_dev, level_stride, feat_dtype, variant):
+        src = table if shadow is None else shadow
+        feat = grid_encode_forward(xyzs, bound, src.detach(), levels, m_host, m_dev, level_stride, None, feat_dtype,
+                                   variant)
+        ctx.save_for_backward(xyzs, m_dev if m_dev is not None else torch.empty(0))
+        ctx.has_mdev = m_dev is not None
+        ctx.meta = (levels, bound, m_host, level_stride, variant, table.shape, table.device)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        xyzs, m_dev = ctx.saved_tensors
+        levels, bound, m_host, level_stride, variant, shape, dev = ctx.meta
+        dtable = torch.zeros(shape, device=dev, dtype=torch.float32)
+        dfeat = dfeat.contiguous()
+        if dfeat.dtype != torch.float32:
+            dfeat = dfeat.float()
+        grid_encode_backward(xyzs, bound, dfeat, levels, m_host, m_dev if ctx.has_mdev else None, level_stride,
+                             dtable, variant)
+        return None, dtable, None, None, None, None, None, None, None, None
+
+
+class GridEncoder(nn.Module):
+    """embeddings: f32 [n_rows, 2] master table (U(-1e-4, 1e-4) init).  With
+    `table_dtype=torch.bfloat16` the gather reads a bf16 shadow that is refreshed lazily whenever
+    the master changed (or explicitly by the fused Adam step)."""
+
+    def __init__(self, num_levels=16, level_dim=2, base_resolution=16, desired_resolution=2048,
+                 log2_hashmap_size=19, table_dtype=torch.float32, variant=1):
+        super().__init__()
+        self.levels = GridLevels(num_levels, level_dim, base_resolution, desired_resolution, log2_hashmap_size)
+        self.out_dim = self.levels.out_dim
+        self.variant = variant
+        self.table_dtype = table_dtype
+        self.embeddings = nn.Parameter(torch.empty(self.levels.n_rows, level_dim))
+        self.reset_parameters()
+        self._shadow = None
+        self._shadow_version = -1
+
+    def reset_parameters(self):
+        self.embeddings.data.uniform_(-1e-4, 1e-4)
+
+    def shadow(self):
+        if self.table_dtype == torch.float32:
+            return None
+        ver = self.embeddings._version
+        if self._shadow is None or self._shadow.device != self.embeddings.device:
+            self._shadow = torch.empty(self.levels.n_rows, 2, device=self.embeddings.device, dtype=torch.bfloat16)
+            self._shadow_version = -1
+        if self._shadow_version != ver:
+            _b.call("lnerf_cast_f32_to_bf16", _p(self.embeddings.data), _p(self._shadow),
+                    self.embeddings.numel(), _stream())
+            self._shadow_version = ver
+        return self._shadow
+
+    def mark_shadow_fresh(self):
+        """Called by the fused optimiser step, which rewrites the shadow in the same pass."""
+        self._shadow_version = self.embeddings._version
+
+    def encode(self, xyzs, bound, m_host, m_dev=None, level_stride=None, feat_dtype=torch.float32):
+        """Level-major features [L, level_stride, 2] (differentiable w.r.t. embeddings)."""
+        if level_stride is None:
+            level_stride = xyzs.shape[0]
+        return _GridEncode.apply(xyzs, self.embeddings, self.shadow(), self.levels, bound, m_host, m_dev, level_stride,
+                                 feat_dtype, self.variant)
+
+    def forward(self, inputs, bound=1.0):
+        """inputs [..., 3] in [-bound, bound] -> [..., L*2] (sample-major view, as the upstream encoder)."""
+        prefix = inputs.shape[:-1]
+        x = inputs.reshape(-1, 3).contiguous().float()
+        M = x.shape[0]
+        feat = self.encode(x, bound, M)
+        return feat.permute(1, 0, 2).reshape(*prefix, self.out_dim)

@@ -1,0 +1,127 @@
+"""NeRFNetwork: hash-grid encoder + fused sigma/latent MLP (+ background net), HIP-backed.
+Counterpart of src/latent_nerf/models/network_grid.py of the absent package (SURVEY.md
+Appendix A: sigma_net = MLP(32, 1+C, hidden 64, 3 layers, bias), density blob, bg_net)."""
+import math
+
+import torch
+import torch.nn as nn
+
+from ..raymarching import backend as _b
+from ..raymarching.raymarching import _chk, _p, _stream
+from .encoding import GridEncoder
+from .nerf_utils import NeRFType
+from .renderer import NeRFRenderer
+
+_PREC = {"f32": _b.F32, "bf16": _b.BF16}
+
+
+class _SigmaLatentMLP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, xyzs, w1, b1, w2, b2, w3, b3, m_host, m_dev, level_stride, blob_scale, blob_std,
+                precision, workspace):
+        out_dim = w3.shape[0]
+        dev = xyzs.device
+        sigmas = torch.empty(level_stride, device=dev, dtype=torch.float32)
+        rgbs = torch.empty(level_stride, out_dim - 1, device=dev, dtype=torch.float32)
+        fdt = _b.F32 if feat.dtype == torch.float32 else _b.BF16
+        _b.call("lnerf_mlp_forward", _chk(feat, "feat", feat.dtype), fdt, int(level_stride), _chk(xyzs, "xyzs"),
+                _chk(w1, "w1"), _chk(b1, "b1"), _chk(w2, "w2"), _chk(b2, "b2"), _chk(w3, "w3"), _chk(b3, "b3"),
+                out_dim, float(blob_scale), float(blob_std), int(m_host),
+                _chk(m_dev, "m_dev", torch.int32, allow_none=True), _p(sigmas), _p(rgbs), precision, _stream())
+        ctx.save_for_backward(feat, xyzs, w1, b1, w2, b2, w3, b3, sigmas,
+                              m_dev if m_dev is not None else torch.empty(0))
+        ctx.meta = (m_host, m_dev is not None, level_stride, blob_scale, blob_std, precision, workspace)
+        return sigmas, rgbs
+
+    @staticmethod
+    def backward(ctx, dsigmas, drgbs):
+        feat, xyzs, w1, b1, w2, b2, w3, b3, sigmas, m_dev = ctx.saved_tensors
+        m_host, has_mdev, level_stride, blob_scale, blob_std, precision, workspace = ctx.meta
+        out_dim = w3.shape[0]
+        dev = xyzs.device
+        dsigmas = torch.zeros_like(sigmas) if dsigmas is None else dsigmas.contiguous()
+        drgbs = torch.zeros(level_stride, out_dim - 1, device=dev) if drgbs is None else drgbs.contiguous()
+        dfeat = torch.empty(feat.shape, device=dev, dtype=torch.float32)
+        grads = [torch.zeros_like(t) for t in (w1, b1, w2, b2, w3, b3)]
+        need = _b.get_lib().lnerf_mlp_backward_workspace_bytes(out_dim)
+        if workspace is None or workspace.numel() < need:
+            workspace = torch.empty(need, device=dev, dtype=torch.uint8)
+        fdt = _b.F32 if feat.dtype == torch.float32 else _b.BF16
+        _b.call("lnerf_mlp_backward", _p(feat), fdt, int(level_stride), _p(xyzs), _p(w1), _p(b1), _p(w2), _p(b2),
+                _p(w3), _p(b3), out_dim, float(blob_scale), float(blob_std), int(m_host),
+                _p(m_dev) if has_mdev else None, _p(sigmas), _chk(dsigmas, "dsigmas"), _chk(drgbs, "drgbs"),
+                _p(dfeat), *[_p(g) for g in grads], _p(workspace), workspace.numel(), precision, _stream())
+        return (dfeat, None, *grads, None, None, None, None, None, None, None)
+
+
+class NeRFNetwork(NeRFRenderer):
+    def __init__(self, cfg, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19,
+                 hidden_dim=64, blob_scale=5.0, blob_std=0.2):
+        super().__init__(cfg, latent_mode=cfg.nerf_type == NeRFType.latent)
+        if hidden_dim != 64 or num_levels * level_dim != 32:
+            raise ValueError("the fused HIP MLP is built for 32 -> 64 -> 64 -> 1+C")
+        self.img_dims = 3 + 1 if self.latent_mode else 3
+        self.blob_scale, self.blob_std = blob_scale, blob_std
+        self.precision = cfg.mlp_precision
+        table_dtype = torch.bfloat16 if cfg.table_dtype == "bf16" else torch.float32
+        self.encoder = GridEncoder(num_levels, level_dim, base_resolution, 2048 * self.bound, log2_hashmap_size,
+                                   table_dtype=table_dtype, variant=cfg.gather_variant)
+        in_dim, out_dim = self.encoder.out_dim, 1 + self.img_dims
+        # nn.Linear default init, kept as bare parameters: the fused kernel takes all six at once
+        self.w1 = nn.Parameter(torch.empty(hidden_dim, in_dim))
+        self.b1 = nn.Parameter(torch.empty(hidden_dim))
+        self.w2 = nn.Parameter(torch.empty(hidden_dim, hidden_dim))
+        self.b2 = nn.Parameter(torch.empty(hidden_dim))
+        self.w3 = nn.Parameter(torch.empty(out_dim, hidden_dim))
+        self.b3 = nn.Parameter(torch.empty(out_dim))
+        for w, b in ((self.w1, self.b1), (self.w2, self.b2), (self.w3, self.b3)):
+            bound = 1.0 / math.sqrt(w.shape[1])
+            nn.init.uniform_(w, -bound, bound)
+            nn.init.uniform_(b, -bound, bound)
+        self.bg_radius = cfg.bg_radius
+        if self.bg_radius > 0:
+            self.bg_w1 = nn.Parameter(torch.empty(64, 39))
+            self.bg_b1 = nn.Parameter(torch.empty(64))
+            self.bg_w2 = nn.Parameter(torch.empty(self.img_dims, 64))
+            self.bg_b2 = nn.Parameter(torch.empty(self.img_dims))
+            for w, b in ((self.bg_w1, self.bg_b1), (self.bg_w2, self.bg_b2)):
+                bound = 1.0 / math.sqrt(w.shape[1])
+                nn.init.uniform_(w, -bound, bound)
+                nn.init.uniform_(b, -bound, bound)
+        self._mlp_ws = None
+
+    # ---- per-sample field -------------------------------------------------------------
+    def field(self, xyzs, m_host, m_dev=None, level_stride=None):
+        """xyzs [cap,3] -> sigmas [cap], latents [cap,C] for the first min(m_host, *m_dev) rows."""
+        if level_stride is None:
+            level_stride = xyzs.shape[0]
+        feat_dtype = torch.bfloat16 if self.precision == "bf16" else torch.float32
+        feat = self.encoder.encode(xyzs, self.bound, m_host, m_dev, level_stride, feat_dtype)
+        if self._mlp_ws is None or self._mlp_ws.device != xyzs.device:
+            need = _b.get_lib().lnerf_mlp_backward_workspace_bytes(self.w3.shape[0])
+            self._mlp_ws = torch.empty(need, device=xyzs.device, dtype=torch.uint8)
+        sigmas, rgbs = _SigmaLatentMLP.apply(feat, xyzs, self.w1, self.b1, self.w2, self.b2, self.w3, self.b3, m_host,
+                                             m_dev, level_stride, self.blob_scale, self.blob_std,
+                                             _PREC[self.precision], self._mlp_ws)
+        if not self.latent_mode:
+            rgbs = torch.sigmoid(rgbs)
+        return sigmas, rgbs
+
+    def forward(self, x, d=None):
+        x = x.reshape(-1, 3).contiguous().float()
+        return self.field(x, x.shape[0])
+
+    def density(self, x):
+        sigmas, rgbs = self.forward(x)
+        return {"sigma": sigmas, "albedo": rgbs}
+
+    def background(self, d):
+        from .bg import background_net
+        return background_net(d, self.bg_w1, self.bg_b1, self.bg_w2, self.bg_b2)
+
+    def get_params(self, lr):
+        params = [{"params": [self.encoder.embeddings], "lr": lr * 10},
+                  {"params": [self.w1, self.b1, self.w2, self.b2, self.w3, self.b3], "lr": lr}]
+        if self.bg_radius > 0:
+            params.append({"params": [self.bg_w1, self.bg_b1, self.bg_w2, self.bg_b2], "lr": lr})
+        return params

@@ -1,0 +1,24 @@
+"""Lane-level emulation of the gfx950 MFMA shapes used by csrc/mlp.hip.
+
+Used only by CPU tests: it replays the kernels' index algebra (which lane holds which matrix
+element, what goes where in LDS) with numpy so that layout mistakes are caught without a GPU.
+Lane maps (cdna_hip_programming.md §3):
+  v_mfma_f32_16x16x4_f32 :  A[i = l&15][k = l>>4]   B[k = l>>4][j = l&15]
+  C/D (all 16x16 shapes) :  D[i = (l>>4)*4 + reg][j = l&15]
+"""
+import numpy as np
+
+
+def mfma_16x16x4_f32(a, b, c):
+    """a, b: [64] per-lane scalars; c: [64,4] per-lane accumulators -> new c."""
+    A = np.zeros((16, 4), dtype=np.float64)
+    B = np.zeros((4, 16), dtype=np.float64)
+    for l in range(64):
+        A[l & 15, l >> 4] = a[l]
+        B[l >> 4, l & 15] = b[l]
+    D = A @ B
+    out = c.astype(np.float64).copy()
+    for l in range(64):
+        for r in range(4):
+            out[l, r] += D[(l >> 4) * 4 + r, l & 15]
+    return out

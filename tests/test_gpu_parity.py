@@ -1,0 +1,390 @@
+"""GPU parity tests: every HIP kernel (through the C ABI via the host package) against the CPU
+oracle on the same seeded inputs.  Run with `pytest -m gpu` on an MI355X.
+
+Tolerances (fp32 path, stated per SURVEY.md §7):
+  * discrete outputs (Morton, bitfield, ray spans, which lattice points are samples): bit-exact
+  * forward floats: rtol 1e-4, atol 1e-5    * gradients: rtol 1e-3, atol 1e-5 (float atomics
+    reorder sums); weight gradients that sum 1e5 terms: relative-to-max 1e-4.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev(built_lib):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X (torch.cuda.is_available() is False)")
+    from src.latent_nerf.raymarching import backend as B
+    B.get_lib()  # fail loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def _scene(G=32, HW=16, theta=60.0, phi=20.0, radius=1.25, seed=0, bound=1.0, cascade=1, sphere=0.5):
+    torch.manual_seed(seed)
+    grid = O.density_grid_from_function(lambda x: (x.norm(dim=-1) < sphere).float() * 10.0, G, cascade, bound)
+    bits = O.packbits(grid.reshape(-1), 0.01)
+    f = HW / (2 * math.tan(math.radians(55) / 2))
+    c2w = O.pose_from_angles(math.radians(theta), math.radians(phi), radius)
+    ro, rd = O.get_rays(c2w, f, f, HW / 2, HW / 2, HW, HW)
+    return grid, bits, c2w, (f, f, HW / 2, HW / 2), ro[0].contiguous(), rd[0].contiguous()
+
+
+def _close(a, b, rtol=1e-4, atol=1e-5, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = err > tol
+    assert not bool(bad.any()), "%s: %d/%d outside tol, max abs err %.3e (ref max %.3e)" % (
+        what, int(bad.sum()), bad.numel(), float(err.max()), float(b.abs().max()))
+
+
+def _close_rel_max(a, b, rel=1e-4, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    scale = float(b.abs().max()) + 1e-30
+    err = float((a - b).abs().max())
+    assert err <= rel * scale, "%s: max abs err %.3e vs scale %.3e" % (what, err, scale)
+
+
+# ------------------------------------------------------------------------------ H1 / H2 / H3
+def test_get_rays_and_near_far(dev):
+    from src.latent_nerf.raymarching import raymarching as rm
+    _, _, c2w, intr, ro, rd = _scene(HW=24)
+    poses = torch.stack([c2w, O.pose_from_angles(0.3, 4.0, 1.1), O.pose_from_angles(2.5, 1.0, 1.5)]).to(dev)
+    go, gd = rm.get_rays(poses, intr, 24, 24)
+    ro_all, rd_all = O.get_rays(poses.cpu(), *intr, 24, 24)
+    _close(go, ro_all, 0, 1e-7, "rays_o")
+    _close(gd, rd_all, 1e-6, 1e-7, "rays_d")
+    _close(gd.norm(dim=-1), torch.ones(3, 576), 1e-6, 1e-6, "unit dirs")
+    # near/far incl. rays that miss the box and axis-parallel rays
+    o = torch.cat([ro_all.reshape(-1, 3), torch.tensor([[0.0, 0.0, -3.0], [5.0, 5.0, 5.0], [0.2, 0.1, 3.0]])])
+    d = torch.cat([rd_all.reshape(-1, 3), torch.tensor([[0.0, 0.0, 1.0], [1.0, 0.0, 0.0], [0.0, 0.0, -1.0]])])
+    for aabb, mn in (([-1, -1, -1, 1, 1, 1], 0.1), ([-0.5, -0.25, -0.5, 0.5, 0.75, 0.5], 0.05)):
+        n_ref, f_ref = O.near_far_from_aabb(o, d, aabb, mn)
+        n, f = rm.near_far_from_aabb(o.to(dev), d.to(dev), aabb, mn)
+        _close(n, n_ref, 1e-6, 1e-6, "nears")
+        _close(f, f_ref, 1e-6, 1e-6, "fars")
+        assert bool((n_ref[-2] == O.FLT_MAX).item()) and float(n[-2]) == float(n_ref[-2])
+
+
+def test_morton_and_packbits_bit_exact(dev, bits_oracle):
+    from src.latent_nerf.raymarching import raymarching as rm
+    rng = np.random.RandomState(0)
+    coords = torch.from_numpy(rng.randint(0, 1024, size=(100003, 3)).astype(np.int32))
+    idx = rm.morton3D(coords.to(dev))
+    assert torch.equal(idx.cpu().long(), O.morton3d(coords.long()))
+    assert torch.equal(rm.morton3D_invert(idx).cpu(), coords)
+    grid = torch.rand(2, 64 ** 3) * 2
+    for thresh, mean in ((1.0, None), (1.5, 0.7)):
+        md = None if mean is None else torch.tensor([mean], device=dev)
+        bits = rm.packbits(grid.to(dev), thresh, None, md)
+        ref = O.packbits(grid.reshape(-1), thresh if mean is None else min(thresh, mean))
+        assert torch.equal(bits.cpu(), ref)
+    assert rm.morton3D(coords[:0].to(dev)).numel() == 0  # empty input
+
+
+# ------------------------------------------------------------------------------ H4
+def _march_both(dev, ro, rd, bits, bound, cascade, G, max_steps, dt_gamma, noises, capacity=None):
+    from src.latent_nerf.raymarching import raymarching as rm
+    aabb = [-bound] * 3 + [bound] * 3
+    nears, fars = O.near_far_from_aabb(ro, rd, aabb, 0.1)
+    ref = O.march_rays_train(ro, rd, nears, fars, bits, bound, cascade, G, max_steps, dt_gamma, noises)
+    res = rm.march_rays_train(ro.to(dev), rd.to(dev), bound, bits.to(dev), cascade, G, nears.to(dev), fars.to(dev),
+                              dt_gamma=dt_gamma, max_steps=max_steps, capacity=capacity,
+                              noises=None if noises is None else noises.to(dev))
+    return ref, res
+
+
+@pytest.mark.parametrize("dt_gamma,perturb", [(0.0, False), (0.0, True), (1.0 / 128, True)])
+def test_march_rays_train_bit_exact(dev, dt_gamma, perturb):
+    G = 64
+    _, bits, _, _, ro, rd = _scene(G=G, HW=32)
+    noises = torch.rand(ro.shape[0]) if perturb else None
+    (xyzs, dirs, deltas, rays, M), res = _march_both(dev, ro, rd, bits, 1.0, 1, G, 512, dt_gamma, noises)
+    cnt = res.counter.cpu()
+    assert int(cnt[0]) == M and M > 1000
+    assert int(cnt[1]) == int((rays[:, 2] > 0).sum()) and int(cnt[2]) == 0
+    assert torch.equal(res.rays.cpu(), rays)
+    assert torch.equal(res.xyzs[:M].cpu(), xyzs)
+    assert torch.equal(res.deltas[:M].cpu(), deltas)
+    assert torch.equal(res.dirs[:M].cpu(), dirs)
+
+
+def test_march_cascades_cap_and_capacity(dev):
+    G = 32
+    # two cascades, fully occupied: per-ray cap binds (oracle test_march_max_steps_cap)
+    full = torch.ones(2, G ** 3)
+    bits = O.packbits(full.reshape(-1), 0.5)
+    _, _, _, _, ro, rd = _scene(G=G, HW=12)
+    (xyzs, dirs, deltas, rays, M), res = _march_both(dev, ro, rd, bits, 2.0, 2, G, 64, 0.0, None)
+    assert int(rays[:, 2].max()) == 64
+    assert torch.equal(res.rays.cpu(), rays) and int(res.counter[0]) == M
+    assert torch.equal(res.xyzs[:M].cpu(), xyzs) and torch.equal(res.deltas[:M].cpu(), deltas)
+    # sphere in a 2-cascade grid (mip level selection)
+    _, bits2, _, _, ro, rd = _scene(G=G, HW=16, bound=2.0, cascade=2, sphere=0.8, radius=1.6)
+    (xyzs, dirs, deltas, rays, M), res = _march_both(dev, ro, rd, bits2, 2.0, 2, G, 256, 0.0, torch.rand(ro.shape[0]))
+    assert M > 0 and torch.equal(res.rays.cpu(), rays) and torch.equal(res.xyzs[:M].cpu(), xyzs)
+    # capacity overflow: later rays are dropped, earlier spans stay intact, nothing is written past capacity
+    cap = M // 2
+    _, res = _march_both(dev, ro, rd, bits2, 2.0, 2, G, 256, 0.0, None, capacity=cap)
+    r = res.rays.cpu()
+    c = res.counter.cpu()
+    assert int(c[2]) > 0 and int(c[0]) <= cap
+    kept = r[:, 2] > 0
+    assert int((r[kept, 1] + r[kept, 2]).max()) == int(c[0])
+    # no occupied cells / all rays missing: zero samples
+    empty = torch.zeros(G ** 3 // 8, dtype=torch.uint8)
+    (_, _, _, rays0, M0), res0 = _march_both(dev, ro, rd, empty, 1.0, 1, G, 256, 0.0, None)
+    assert M0 == 0 and int(res0.counter[0]) == 0 and int(res0.rays[:, 2].sum()) == 0
+
+
+# ------------------------------------------------------------------------------ H5 / H6
+def _rand_points(M, bound=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.rand(M, 3, generator=g) * 2 - 1) * bound
+    x[0] = torch.tensor([-bound, -bound, -bound])
+    x[1] = torch.tensor([bound, bound, bound])  # the far corner: pos_grid + 1 == resolution
+    x[2] = torch.tensor([0.0, 0.0, 0.0])
+    return x
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("cfg", ["small", "full"])
+def test_grid_encode_forward_backward(dev, variant, cfg):
+    from src.latent_nerf.models import encoding as E
+    if cfg == "small":
+        kw = dict(num_levels=16, base_resolution=4, desired_resolution=128, log2_hashmap_size=12)
+        M = 3001
+    else:
+        kw = dict(num_levels=16, base_resolution=16, desired_resolution=2048, log2_hashmap_size=19)
+        M = 20000
+    lv = O.make_grid_levels(**kw)
+    levels = E.GridLevels(kw["num_levels"], 2, kw["base_resolution"], kw["desired_resolution"],
+                          kw["log2_hashmap_size"])
+    assert levels.offsets == lv.offsets and levels.resolutions == lv.resolutions
+    assert np.allclose(levels.scales, lv.scales, rtol=0, atol=0)
+    torch.manual_seed(1)
+    table = torch.randn(lv.n_rows, 2) * 0.1
+    x = _rand_points(M)
+    tref = table.clone().requires_grad_()
+    ref = O.grid_encode((x + 1.0) / 2.0, tref, lv)                      # [M, 32]
+    stride = M + 37                                                      # level_stride > M on purpose
+    m_dev = torch.tensor([M], dtype=torch.int32, device=dev)
+    feat = E.grid_encode_forward(x.to(dev), 1.0, table.to(dev), levels, stride, m_dev, stride, variant=variant)
+    got = feat[:, :M, :].permute(1, 0, 2).reshape(M, 32)
+    _close(got, ref, 1e-4, 1e-6, "features")
+    # backward (scatter-add) vs autograd of the oracle
+    g = torch.randn(M, 32)
+    ref.backward(g)
+    dfeat = torch.zeros(kw["num_levels"], stride, 2)
+    dfeat[:, :M, :] = g.reshape(M, kw["num_levels"], 2).permute(1, 0, 2)
+    dtable = torch.zeros(lv.n_rows, 2, device=dev)
+    E.grid_encode_backward(x.to(dev), 1.0, dfeat.to(dev), levels, stride, m_dev, stride, dtable, variant=variant)
+    _close(dtable, tref.grad, 1e-3, 1e-5, "dtable")
+    # accumulate semantics (+=)
+    E.grid_encode_backward(x.to(dev), 1.0, dfeat.to(dev), levels, stride, m_dev, stride, dtable, variant=variant)
+    _close(dtable, 2 * tref.grad, 1e-3, 2e-5, "dtable accumulates")
+
+
+def test_grid_encode_bf16_and_properties_full_size(dev):
+    from src.latent_nerf.models import encoding as E
+    levels = E.GridLevels()
+    lv = O.make_grid_levels()
+    M = 1 << 19
+    x = _rand_points(M, seed=5).to(dev)
+    # partition of unity at BASELINE size: a constant table gives constant features on every level
+    const = torch.full((levels.n_rows, 2), 0.625, device=dev)
+    f = E.grid_encode_forward(x, 1.0, const, levels, M, None, M)
+    assert float((f - 0.625).abs().max()) < 1e-6
+    # bf16 shadow table / bf16 features vs the oracle evaluated on the bf16-rounded table
+    torch.manual_seed(2)
+    table = torch.randn(levels.n_rows, 2) * 0.1
+    tb = table.to(torch.bfloat16)
+    sub = 4096
+    ref = O.grid_encode((x[:sub].cpu() + 1) / 2, tb.float(), lv)
+    f32o = E.grid_encode_forward(x[:sub].contiguous(), 1.0, tb.to(dev), levels, sub, None, sub)
+    _close(f32o.permute(1, 0, 2).reshape(sub, 32), ref, 1e-4, 1e-6, "bf16 table -> f32 feat")
+    fb = E.grid_encode_forward(x[:sub].contiguous(), 1.0, tb.to(dev), levels, sub, None, sub,
+                               out_dtype=torch.bfloat16)
+    _close(fb.float().permute(1, 0, 2).reshape(sub, 32), ref.to(torch.bfloat16).float(), 1e-2, 1e-4, "bf16 feat")
+    # linearity of the scatter: backward(a*g1 + g2) == a*backward(g1) + backward(g2) (up to atomics order)
+    g1 = torch.randn(16, sub, 2, device=dev)
+    g2 = torch.randn(16, sub, 2, device=dev)
+    outs = []
+    for g in (g1, g2, 3.0 * g1 + g2):
+        d = torch.zeros(levels.n_rows, 2, device=dev)
+        E.grid_encode_backward(x[:sub].contiguous(), 1.0, g.contiguous(), levels, sub, None, sub, d)
+        outs.append(d)
+    _close(outs[2], 3.0 * outs[0] + outs[1], 1e-3, 1e-4, "scatter linearity")
+    # total gradient mass is conserved level by level: sum(dtable[level]) == sum(dfeat[level])
+    for l in (0, 7, 15):
+        s = outs[0][levels.offsets[l]:levels.offsets[l + 1]].sum(0)
+        _close(s, g1[l].sum(0), 1e-3, 1e-2, "mass level %d" % l)
+
+
+# ------------------------------------------------------------------------------ H7
+def _mlp_inputs(M, seed=0):
+    torch.manual_seed(seed)
+    feat = torch.randn(M, 32) * 0.5
+    xyz = (torch.rand(M, 3) * 2 - 1) * 0.8
+    p = O.init_mlp_params(seed=seed)
+    return feat, xyz, p
+
+
+@pytest.mark.parametrize("M", [1, 63, 64, 1000, 70001])
+def test_mlp_forward_backward_f32(dev, M):
+    from src.latent_nerf.models.network_grid import _SigmaLatentMLP
+    from src.latent_nerf.raymarching import backend as B
+    feat, xyz, p = _mlp_inputs(M, seed=M)
+    pr = {k: v.clone().requires_grad_() for k, v in p.items()}
+    fr = feat.clone().requires_grad_()
+    s_ref, c_ref = O.sigma_latent_mlp(fr, xyz, pr)
+    gs, gc = torch.randn(M) * 0.1, torch.randn(M, 4)
+    ((s_ref * gs).sum() + (c_ref * gc).sum()).backward()
+    stride = M + 5
+    lm = torch.zeros(16, stride, 2)
+    lm[:, :M, :] = feat.reshape(M, 16, 2).permute(1, 0, 2)
+    lm = lm.to(dev).requires_grad_()
+    pg = {k: v.to(dev).requires_grad_() for k, v in p.items()}
+    xg = torch.zeros(stride, 3)
+    xg[:M] = xyz
+    m_dev = torch.tensor([M], dtype=torch.int32, device=dev)
+    sig, rgb = _SigmaLatentMLP.apply(lm, xg.to(dev), pg["w1"], pg["b1"], pg["w2"], pg["b2"], pg["w3"], pg["b3"],
+                                     stride, m_dev, stride, 5.0, 0.2, B.F32, None)
+    _close(sig[:M], s_ref, 1e-4, 1e-5, "sigma")
+    _close(rgb[:M], c_ref, 1e-4, 1e-5, "latent")
+    gsp, gcp = torch.zeros(stride), torch.zeros(stride, 4)
+    gsp[:M], gcp[:M] = gs, gc
+    torch.autograd.backward([sig, rgb], [gsp.to(dev), gcp.to(dev)])
+    dfe = lm.grad[:, :M, :].permute(1, 0, 2).reshape(M, 32)
+    _close(dfe, fr.grad, 1e-3, 1e-5, "dfeat")
+    for k in ("w1", "b1", "w2", "b2", "w3", "b3"):
+        _close_rel_max(pg[k].grad, pr[k].grad, 1e-4, "d" + k)
+
+
+def test_mlp_trunc_exp_clamp_and_rgb_mode_shapes(dev):
+    from src.latent_nerf.models.network_grid import _SigmaLatentMLP
+    from src.latent_nerf.raymarching import backend as B
+    # huge pre-activation: forward = exp(x), backward uses exp(min(x, 15))
+    M = 64
+    feat = torch.zeros(16, M, 2, device=dev)
+    p = O.init_mlp_params(out_dim=4)  # C = 3 (rgb mode)
+    p["b3"] = torch.tensor([18.0, 0.1, 0.2, 0.3])
+    pg = {k: v.to(dev).requires_grad_() for k, v in p.items()}
+    xyz = torch.full((M, 3), 5.0, device=dev)  # blob ~ 0
+    sig, rgb = _SigmaLatentMLP.apply(feat, xyz, pg["w1"], pg["b1"], pg["w2"], pg["b2"], pg["w3"], pg["b3"], M, None, M,
+                                     5.0, 0.2, B.F32, None)
+    pr = {k: v.clone().requires_grad_() for k, v in p.items()}
+    s_ref, c_ref = O.sigma_latent_mlp(torch.zeros(M, 32), xyz.cpu(), pr)
+    assert rgb.shape == (M, 3)
+    _close(sig, s_ref, 1e-4, 1e-3, "sigma big")
+    sig.sum().backward()
+    s_ref.sum().backward()
+    _close_rel_max(pg["b3"].grad, pr["b3"].grad, 1e-4, "db3 clamp")
+    assert abs(float(pg["b3"].grad[0]) / (M * math.exp(15.0)) - 1.0) < 1e-3
+
+
+# ------------------------------------------------------------------------------ H8 / H9
+@pytest.mark.parametrize("C", [3, 4])
+def test_composite_forward_backward(dev, C):
+    from src.latent_nerf.raymarching import raymarching as rm
+    torch.manual_seed(C)
+    cnts = torch.tensor([0, 5, 1, 64, 65, 3, 0, 300, 128, 2])
+    N = len(cnts)
+    offs = torch.cumsum(cnts, 0) - cnts
+    M = int(cnts.sum())
+    rays = torch.stack([torch.randperm(N), offs, cnts], -1).int()
+    sig = torch.rand(M) * 20
+    sig[offs[7]:offs[7] + 300] = torch.rand(300) * 400      # forces the early stop inside a long ray
+    rgb = torch.randn(M, C)
+    dl = torch.stack([torch.full((M,), 3.4e-3), torch.rand(M) + 0.3], -1)
+    bg = torch.rand(N, C)
+    sr, rr, br = sig.clone().requires_grad_(), rgb.clone().requires_grad_(), bg.clone().requires_grad_()
+    ws_ref, dp_ref, img_ref = O.composite_rays_train(sr, rr, dl, rays, 1e-4, br)
+    g_ws, g_dp, g_img = torch.randn(N), torch.randn(N), torch.randn(N, C)
+    ((ws_ref * g_ws).sum() + (dp_ref * g_dp).sum() + (img_ref * g_img).sum()).backward()
+    sg, rg, bgg = sig.to(dev).requires_grad_(), rgb.to(dev).requires_grad_(), bg.to(dev).requires_grad_()
+    ws, dp, img = rm.composite_rays_train(sg, rg, dl.to(dev), rays.to(dev), 1e-4, bgg)
+    _close(ws, ws_ref, 1e-4, 1e-6, "weights_sum")
+    _close(dp, dp_ref, 1e-4, 1e-6, "depth")
+    _close(img, img_ref, 1e-4, 1e-6, "image")
+    torch.autograd.backward([ws, dp, img], [g_ws.to(dev), g_dp.to(dev), g_img.to(dev)])
+    _close(sg.grad, sr.grad, 1e-3, 1e-5, "dsigma")
+    _close(rg.grad, rr.grad, 1e-3, 1e-6, "drgb")
+    _close(bgg.grad, br.grad, 1e-4, 1e-6, "dbg")
+    # without background / without weights_sum & depth gradients
+    ws2, dp2, img2 = rm.composite_rays_train(sig.to(dev), rgb.to(dev), dl.to(dev), rays.to(dev), 1e-4, None)
+    ws3, dp3, img3 = O.composite_rays_train(sig, rgb, dl, rays, 1e-4, None)
+    _close(img2, img3, 1e-4, 1e-6, "image no bg")
+    assert float(ws2.max()) <= 1.0 + 1e-5
+
+
+# ------------------------------------------------------------------------------ H11, Adam, occupancy
+def test_background_net(dev):
+    from src.latent_nerf.models.bg import background_net
+    torch.manual_seed(0)
+    N = 1000
+    d = torch.nn.functional.normalize(torch.randn(N, 3), dim=-1)
+    p = O.init_bg_params()
+    pr = {k: v.clone().requires_grad_() for k, v in p.items()}
+    ref = O.bg_mlp(d, pr)
+    g = torch.randn(N, 4)
+    ref.backward(g)
+    pg = {k: v.to(dev).requires_grad_() for k, v in p.items()}
+    out = background_net(d.to(dev), pg["w1"], pg["b1"], pg["w2"], pg["b2"])
+    _close(out, ref, 1e-4, 1e-5, "bg out")
+    out.backward(g.to(dev))
+    for k in p:
+        _close_rel_max(pg[k].grad, pr[k].grad, 1e-4, "bg d" + k)
+
+
+def test_adam_step_matches_torch(dev):
+    from src.latent_nerf.raymarching import backend as B
+    from src.latent_nerf.raymarching.raymarching import _p, _stream
+    torch.manual_seed(0)
+    n = 100003
+    p0 = torch.randn(n)
+    ref = p0.clone().requires_grad_()
+    opt = torch.optim.Adam([ref], lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    p, m, v = p0.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    shadow = torch.empty(n, device=dev, dtype=torch.bfloat16)
+    for step in range(1, 4):
+        g = torch.randn(n)
+        ref.grad = g.clone() * 0.5
+        opt.step()
+        gd = g.to(dev)
+        B.call("lnerf_adam_step", _p(p), _p(gd), _p(m), _p(v), _p(shadow), n, 1e-2, 0.9, 0.99, 1e-15, step, 0.5, 1,
+               _stream())
+        assert float(gd.abs().max()) == 0.0  # gradient cleared in the same pass
+    _close(p, ref, 1e-5, 1e-6, "adam params")
+    assert torch.equal(shadow.cpu(), p.cpu().to(torch.bfloat16))
+
+
+def test_occupancy_helpers(dev):
+    from src.latent_nerf.raymarching import backend as B
+    from src.latent_nerf.raymarching.raymarching import _p, _stream
+    G = 16
+    idx = torch.randperm(G ** 3)[:1000].int()
+    noise = torch.rand(1000, 3)
+    ref = O.occupancy_cell_points(idx.long(), 1, G, 2.0, noise)
+    xyz = torch.empty(1000, 3, device=dev)
+    B.call("lnerf_occ_cell_points", _p(idx.to(dev)), 1000, 1, G, 2.0, _p(noise.to(dev)), _p(xyz), _stream())
+    _close(xyz, ref, 1e-6, 1e-6, "cell points")
+    grid = torch.rand(1, G ** 3) * 3
+    grid[0, :100] = -1.0
+    sig = torch.rand(1000) * 5
+    ref_g = O.update_density_grid(grid, idx.long(), 0, sig, 0.95)
+    gg = grid.to(dev)
+    B.call("lnerf_occ_update", _p(gg[0]), _p(idx.to(dev)), 1000, _p(sig.to(dev)), 0.95, _stream())
+    _close(gg, ref_g, 1e-6, 1e-6, "occ update")
+    mean = torch.zeros(1, device=dev)
+    scratch = torch.zeros(2, device=dev)
+    B.call("lnerf_occ_mean", _p(gg), gg.numel(), _p(mean), _p(scratch), _stream())
+    assert abs(float(mean) - float(ref_g.clamp(min=0).mean())) < 1e-4

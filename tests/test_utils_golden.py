@@ -1,0 +1,46 @@
+"""Known-answer vectors captured from the reference's own src/utils.py
+(tests/golden/make_utils_golden.py) against (a) the oracle restatement and (b) the product's
+host-side mirror latent-nerf-test_amd/src/utils.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+from src import utils as U
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "utils_golden.json")))
+
+
+@pytest.mark.parametrize("impl", [O.get_view_direction, U.get_view_direction], ids=["oracle", "product"])
+def test_view_direction_matches_reference(impl):
+    n = 0
+    for case in GOLD["view_direction"]:
+        th = torch.tensor(case["thetas"], dtype=torch.float32)
+        ph = torch.tensor(case["phis"], dtype=torch.float32)
+        if case["kind"] == "defaults":
+            out = impl(th, ph)
+        else:
+            out = impl(th, ph, np.deg2rad(case["overhead_deg"]), np.deg2rad(case["front_deg"]))
+        assert out.tolist() == case["expect"], case["kind"]
+        n += len(case["expect"])
+    assert n > 900
+
+
+def test_survey_known_answers():
+    # theta = 90 deg sweep and phi = 0 sweep
+    ph = torch.tensor(np.deg2rad([0, 30, 44, 47, 90, 134, 137, 180, 224, 227, 270, 314, 317, 359]), dtype=torch.float32)
+    th = torch.full_like(ph, np.deg2rad(90.0))
+    out = U.get_view_direction(th, ph, np.deg2rad(30.0), np.deg2rad(70.0))
+    assert out.tolist() == [0, 0, 0, 3, 3, 3, 2, 2, 2, 1, 1, 1, 0, 0]
+    th = torch.tensor(np.deg2rad([0.2, 0.5, 1, 30, 60, 179, 179.5, 179.9]), dtype=torch.float32)
+    out = U.get_view_direction(th, torch.zeros_like(th), np.deg2rad(30.0), np.deg2rad(70.0))
+    assert out.tolist() == [4, 4, 0, 0, 0, 0, 5, 5]
+
+
+@pytest.mark.parametrize("impl", [O.tensor2numpy, U.tensor2numpy], ids=["oracle", "product"])
+def test_tensor2numpy_matches_reference(impl):
+    for case in GOLD["tensor2numpy"]:
+        assert impl(torch.tensor(case["input"])).tolist() == case["expect"]
