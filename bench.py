@@ -150,11 +150,38 @@ class KernelTimer:
         return sum(a.elapsed_time(b) for a, b in p) / max(len(p), 1)
 
 
+def usable_cores():
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, min(n, 64))
+
+
+def log(msg):
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
 def cpu_baseline(frames):
     """The oracle's pure-PyTorch fp32 step (render fwd+bwd + Adam) on the host cores."""
     from oracle import nerf_oracle as O
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
+    log("cpu baseline on %d threads" % cores)
     torch.manual_seed(0)
     lv = O.make_grid_levels()
     table = (torch.randn(lv.n_rows, 2) * 0.1).requires_grad_()
@@ -178,8 +205,13 @@ def cpu_baseline(frames):
         opt.step()
         dt = time.perf_counter() - t0
         M = out["M"]
+        log("cpu frame %d: %.2f s" % (i, dt))
         if i > 0:
             times.append(dt)
+        if i == 0 and dt > 15.0:  # keep the default run bounded (~30 s of CPU work)
+            frames = min(frames, 1)
+        if i >= frames:
+            break
     med = sorted(times)[len(times) // 2]
     return {"value": 1.0 / med, "unit": "latent-frames/sec", "cores": cores, "kind": "port",
             "sample": "%d timed frames (+1 warm-up) of the same 64x64x4 / 128^3 step, M=%d samples/frame, "
@@ -213,8 +245,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log("model built on %s (rank %d/%d)" % (dev, rank, world))
     for _ in range(args.warmup):
         step()
+    torch.cuda.synchronize()
+    log("warm-up done")
     timer = KernelTimer(["lnerf_grid_encode_forward", "lnerf_grid_encode_backward"])
     B.set_profile_hook(timer.hook)
     barrier()
@@ -229,6 +264,8 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    if rank == 0:
+        log("timed region: %.3f s for %d steps" % (elapsed, args.steps))
 
     breakdown = None
     if args.breakdown and rank == 0:

@@ -255,7 +255,10 @@ __global__ void k_march_fix_total(const int32_t *__restrict__ rays, int64_t N, i
     if (threadIdx.x == 0) best = 0;
     __syncthreads();
     int loc = 0;
-    for (int64_t n = threadIdx.x; n < N; n += blockDim.x) loc = max(loc, rays[n * 3 + 1] + rays[n * 3 + 2]);
+    for (int64_t n = threadIdx.x; n < N; n += blockDim.x) {
+        const int c = rays[n * 3 + 2];
+        if (c > 0) loc = max(loc, rays[n * 3 + 1] + c);  // empty rays carry a meaningless offset
+    }
     atomicMax(&best, loc);
     __syncthreads();
     if (threadIdx.x == 0) counter[0] = best;

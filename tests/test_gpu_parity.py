@@ -374,15 +374,16 @@ def test_occupancy_helpers(dev):
     idx = torch.randperm(G ** 3)[:1000].int()
     noise = torch.rand(1000, 3)
     ref = O.occupancy_cell_points(idx.long(), 1, G, 2.0, noise)
+    idx_d, noise_d = idx.to(dev), noise.to(dev)  # keep the device tensors alive across the raw-pointer call
     xyz = torch.empty(1000, 3, device=dev)
-    B.call("lnerf_occ_cell_points", _p(idx.to(dev)), 1000, 1, G, 2.0, _p(noise.to(dev)), _p(xyz), _stream())
+    B.call("lnerf_occ_cell_points", _p(idx_d), 1000, 1, G, 2.0, _p(noise_d), _p(xyz), _stream())
     _close(xyz, ref, 1e-6, 1e-6, "cell points")
     grid = torch.rand(1, G ** 3) * 3
     grid[0, :100] = -1.0
     sig = torch.rand(1000) * 5
     ref_g = O.update_density_grid(grid, idx.long(), 0, sig, 0.95)
-    gg = grid.to(dev)
-    B.call("lnerf_occ_update", _p(gg[0]), _p(idx.to(dev)), 1000, _p(sig.to(dev)), 0.95, _stream())
+    gg, sig_d = grid.to(dev), sig.to(dev)
+    B.call("lnerf_occ_update", _p(gg[0]), _p(idx_d), 1000, _p(sig_d), 0.95, _stream())
     _close(gg, ref_g, 1e-6, 1e-6, "occ update")
     mean = torch.zeros(1, device=dev)
     scratch = torch.zeros(2, device=dev)
