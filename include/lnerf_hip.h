@@ -113,11 +113,17 @@ int lnerf_grid_encode_forward(const float *xyzs, float bound, const void *table,
                               int level_dim, const int32_t *offsets_host, const float *scales_host,
                               const int32_t *res_host, int64_t m_host, const int32_t *m_dev, int64_t level_stride,
                               void *feat, int feat_dtype, int variant, lnerf_stream_t stream);
-/* dtable (f32, [rows, F]) is ACCUMULATED into (+=).  variant 0 = global float atomics. */
+/* dtable (f32, [rows, F]) is ACCUMULATED into (+=).
+ * variant 0/1: per-lane global float atomics (blockIdx.y level map / XCD-aware map); no workspace.
+ * variant 2  : two-pass bucketed scatter -- records binned per 64 KiB table chunk with plain
+ *              stores, then reduced in LDS and added with coalesced stores; needs `workspace`
+ *              of lnerf_grid_encode_backward_workspace_bytes() bytes (16-byte aligned). */
+size_t lnerf_grid_encode_backward_workspace_bytes(int num_levels, const int32_t *offsets_host, int64_t m_host);
 int lnerf_grid_encode_backward(const float *xyzs, float bound, const void *dfeat, int dfeat_dtype, int num_levels,
                                int level_dim, const int32_t *offsets_host, const float *scales_host,
                                const int32_t *res_host, int64_t m_host, const int32_t *m_dev, int64_t level_stride,
-                               float *dtable, int variant, lnerf_stream_t stream);
+                               float *dtable, int variant, void *workspace, size_t workspace_bytes,
+                               lnerf_stream_t stream);
 
 /* ---- H7: fused sigma/latent MLP  32 -> 64 -> 64 -> out_dim (= 1 + C), ReLU hidden.
  * Weights are PyTorch nn.Linear layout: w1 [64,32], b1 [64], w2 [64,64], b2 [64], w3 [out_dim,64],

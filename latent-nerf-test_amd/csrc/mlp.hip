@@ -133,13 +133,14 @@ constexpr int BWD_MAX_BLOCKS = 512;
 __global__ void __launch_bounds__(256, 2)
 k_mlp_backward_f32(MlpArgs a, const float *__restrict__ sigmas, const float *__restrict__ dsigmas,
                    const float *__restrict__ drgbs, float *__restrict__ dfeat, float *__restrict__ slabs) {
-    __shared__ float sW1[HID * LDX];
-    __shared__ float sW2[HID * LDH];
-    __shared__ float sW3[OUTP * LDH];
-    __shared__ float sB1[HID], sB2[HID];
-    __shared__ float sX[4][16 * LDX];
-    __shared__ float sP[4][16 * LDH];  // A1, later dZ1
-    __shared__ float sQ[4][16 * LDH];  // A2, later dZ2
+    // one LDS block, carved by hand so that the per-wave activation tiles can be reused for the
+    // end-of-kernel reduction of the four waves' weight-gradient accumulators
+    constexpr int O_W1 = 0, O_W2 = O_W1 + HID * LDX, O_W3 = O_W2 + HID * LDH, O_B1 = O_W3 + OUTP * LDH,
+                  O_B2 = O_B1 + HID, O_X = O_B2 + HID, O_P = O_X + 4 * 16 * LDX, O_Q = O_P + 4 * 16 * LDH,
+                  O_END = O_Q + 4 * 16 * LDH;
+    static_assert(O_END - O_X >= SLAB, "activation tiles must hold one slab");
+    __shared__ float smem[O_END];
+    float *sW1 = smem + O_W1, *sW2 = smem + O_W2, *sW3 = smem + O_W3, *sB1 = smem + O_B1, *sB2 = smem + O_B2;
     int64_t M = a.m_host;
     if (a.m_dev) { const int64_t md = *a.m_dev; M = md < M ? md : M; }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -151,7 +152,7 @@ k_mlp_backward_f32(MlpArgs a, const float *__restrict__ sigmas, const float *__r
         sW3[(i / HID) * LDH + (i % HID)] = (i / HID) < a.out_dim ? a.w3[i] : 0.f;
     if (tid < HID) { sB1[tid] = a.b1[tid]; sB2[tid] = a.b2[tid]; }
     __syncthreads();
-    float *X = sX[w], *P = sP[w], *Q = sQ[w];
+    float *X = smem + O_X + w * 16 * LDX, *P = smem + O_P + w * 16 * LDH, *Q = smem + O_Q + w * 16 * LDH;
     const float e15 = 3269017.3724721107f;  // exp(15)
 
     f32x4 gW2[4][4], gW1[4][2], gW3[4];
@@ -324,49 +325,70 @@ k_mlp_backward_f32(MlpArgs a, const float *__restrict__ sigmas, const float *__r
         }
     }
 
-    // ---- one slab per wavefront (deterministic; summed by k_mlp_reduce_slabs)
-    float *slab = slabs + ((int64_t)blockIdx.x * 4 + w) * SLAB;
+    // ---- the four waves add their accumulators into one LDS slab in wave order (deterministic),
+    //      then the workgroup writes ONE slab; k_mlp_reduce_slabs sums the slabs of all workgroups.
+    float *slab = smem + O_X;
+    __syncthreads();
+    for (int i = tid; i < SLAB; i += 256) slab[i] = 0.f;
+    __syncthreads();
+    for (int turn = 0; turn < 4; ++turn) {
+        if (w == turn) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int o = mt * 16 + q * 4 + r;
+                for (int r = 0; r < 4; ++r) {
+                    const int o = mt * 16 + q * 4 + r;
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) slab[SL_W2 + o * HID + nt * 16 + j] = gW2[mt][nt][r];
-            slab[SL_W1 + o * IN + j] = gW1[mt][0][r];
-            slab[SL_W1 + o * IN + 16 + j] = gW1[mt][1][r];
+                    for (int nt = 0; nt < 4; ++nt) slab[SL_W2 + o * HID + nt * 16 + j] += gW2[mt][nt][r];
+                    slab[SL_W1 + o * IN + j] += gW1[mt][0][r];
+                    slab[SL_W1 + o * IN + 16 + j] += gW1[mt][1][r];
+                }
+            // dW3: C rows = n3 (q*4 + r), cols = h (nt*16 + j)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[SL_W3 + (q * 4 + r) * HID + nt * 16 + j] += gW3[nt][r];
+            // biases: gb1/gb2 hold per-lane sums over this lane's 4 rows; add the 4 lane groups (q)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                float v1 = gb1[nt], v2 = gb2[nt];
+                v1 += __shfl_xor(v1, 16, 64); v1 += __shfl_xor(v1, 32, 64);
+                v2 += __shfl_xor(v2, 16, 64); v2 += __shfl_xor(v2, 32, 64);
+                if (q == 0) { slab[SL_B1 + nt * 16 + j] += v1; slab[SL_B2 + nt * 16 + j] += v2; }
+            }
+            // gb3[kk]: lane (s = j, k = 4kk + q) -> sum over the 16 lanes j
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                float v = gb3[kk];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+                v += __shfl_xor(v, 8, 64);
+                if (j == 0) slab[SL_B3 + 4 * kk + q] += v;
+            }
         }
-    // dW3: C rows = n3 (q*4 + r), cols = h (nt*16 + j)
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) slab[SL_W3 + (q * 4 + r) * HID + nt * 16 + j] = gW3[nt][r];
-    // biases: gb1/gb2 hold per-lane sums over this lane's 4 rows; add the 4 lane groups (q)
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        float v1 = gb1[nt], v2 = gb2[nt];
-        v1 += __shfl_xor(v1, 16, 64); v1 += __shfl_xor(v1, 32, 64);
-        v2 += __shfl_xor(v2, 16, 64); v2 += __shfl_xor(v2, 32, 64);
-        if (q == 0) { slab[SL_B1 + nt * 16 + j] = v1; slab[SL_B2 + nt * 16 + j] = v2; }
+        __syncthreads();
     }
-    // gb3[kk]: lane (s = j, k = 4kk + q) -> sum over the 16 lanes j
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        float v = gb3[kk];
-        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-        if (j == 0) slab[SL_B3 + 4 * kk + q] = v;
-    }
-    if (lane < 8) slab[SL_B3 + 8 + lane] = 0.f;
+    float *gslab = slabs + (int64_t)blockIdx.x * SLAB;
+    for (int i = tid; i < SLAB; i += 256) gslab[i] = slab[i];
 }
 
+// 64 parameters per workgroup; 4 lane groups each sum every 4th slab (coalesced 256-B reads), then
+// the partials are added in a fixed order: deterministic.
 __global__ void __launch_bounds__(256)
 k_mlp_reduce_slabs(const float *__restrict__ slabs, int n_slabs, int out_dim, float *__restrict__ dw1,
                    float *__restrict__ db1, float *__restrict__ dw2, float *__restrict__ db2, float *__restrict__ dw3,
                    float *__restrict__ db3) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= SLAB) return;
+    __shared__ float part[4][64];
+    const int pi = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + pi;
     float s = 0.f;
-    for (int b = 0; b < n_slabs; ++b) s += slabs[(int64_t)b * SLAB + p];
+    if (p < SLAB) {
+#pragma unroll 8
+        for (int b = sg; b < n_slabs; b += 4) s += slabs[(int64_t)b * SLAB + p];
+    }
+    part[sg][pi] = s;
+    __syncthreads();
+    if (sg != 0 || p >= SLAB) return;
+    s = ((part[0][pi] + part[1][pi]) + part[2][pi]) + part[3][pi];
     if (p < SL_B1) dw1[p - SL_W1] += s;
     else if (p < SL_W2) db1[p - SL_B1] += s;
     else if (p < SL_B2) dw2[p - SL_W2] += s;
@@ -414,7 +436,7 @@ int lnerf_mlp_forward(const void *feat, int feat_dtype, int64_t level_stride, co
 
 size_t lnerf_mlp_backward_workspace_bytes(int out_dim) {
     (void)out_dim;
-    return (size_t)BWD_MAX_BLOCKS * 4 * SLAB * sizeof(float);
+    return (size_t)BWD_MAX_BLOCKS * SLAB * sizeof(float);
 }
 
 int lnerf_mlp_backward(const void *feat, int feat_dtype, int64_t level_stride, const float *xyzs, const float *w1,
@@ -441,8 +463,8 @@ int lnerf_mlp_backward(const void *feat, int feat_dtype, int64_t level_stride, c
     hipLaunchKernelGGL(k_mlp_backward_f32, dim3((unsigned)blocks), dim3(256), 0, s, a, sigmas, dsigmas, drgbs, dfeat,
                        (float *)workspace);
     LNERF_CHECK_LAUNCH("mlp_backward");
-    hipLaunchKernelGGL(k_mlp_reduce_slabs, dim3((unsigned)div_up(SLAB, 256)), dim3(256), 0, s,
-                       (const float *)workspace, (int)blocks * 4, out_dim, dw1, db1, dw2, db2, dw3, db3);
+    hipLaunchKernelGGL(k_mlp_reduce_slabs, dim3((unsigned)div_up(SLAB, 64)), dim3(256), 0, s,
+                       (const float *)workspace, (int)blocks, out_dim, dw1, db1, dw2, db2, dw3, db3);
     LNERF_CHECK_LAUNCH("mlp_backward(reduce)");
     return LNERF_OK;
 }

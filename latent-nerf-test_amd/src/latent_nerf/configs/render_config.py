@@ -51,5 +51,7 @@ class RenderConfig:
     table_dtype: str = "f32"
     # workgroup -> (level, tile) mapping of the gather/scatter: 0 = level on grid.y, 1 = XCD-aware
     gather_variant: int = 1
+    # hash-grid backward: 0/1 = global float atomics, 2 = two-pass bucketed scatter (LDS reduction)
+    scatter_variant: int = 2
     # sample buffer capacity per view (0 = rays * min(max_steps, 256))
     max_samples: int = 0

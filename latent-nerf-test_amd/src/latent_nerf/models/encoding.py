@@ -61,12 +61,34 @@ def grid_encode_forward(xyzs, bound, table, levels: GridLevels, m_host, m_dev, l
     return out
 
 
-def grid_encode_backward(xyzs, bound, dfeat, levels: GridLevels, m_host, m_dev, level_stride, dtable, variant=1):
-    """dtable (f32 [rows,2]) += scatter of dfeat (level-major, f32)."""
+_scatter_ws = {}
+
+
+def scatter_workspace(levels: GridLevels, m_host, device):
+    """Device scratch of the bucketed scatter (variant 2), cached per (device, size)."""
+    need = _b.get_lib().lnerf_grid_encode_backward_workspace_bytes(levels.num_levels, levels.c_offsets, int(m_host))
+    if need == 0:
+        raise _b.LnerfError("bucketed scatter cannot handle this level table; use scatter variant 0/1")
+    key = (str(device), need)
+    ws = _scatter_ws.get(key)
+    if ws is None:
+        _scatter_ws.clear()  # one live workspace: it can be gigabytes
+        ws = torch.empty(need, device=device, dtype=torch.uint8)
+        _scatter_ws[key] = ws
+    return ws
+
+
+def grid_encode_backward(xyzs, bound, dfeat, levels: GridLevels, m_host, m_dev, level_stride, dtable, variant=2):
+    """dtable (f32 [rows,2]) += scatter of dfeat (level-major, f32).
+    variant 0/1: global float atomics; 2: two-pass bucketed scatter (LDS reduction)."""
+    ws, ws_bytes = None, 0
+    if variant == 2:
+        wst = scatter_workspace(levels, m_host, xyzs.device)
+        ws, ws_bytes = _p(wst), wst.numel()
     _b.call("lnerf_grid_encode_backward", _chk(xyzs, "xyzs"), float(bound), _chk(dfeat, "dfeat"), _b.F32,
             levels.num_levels, levels.level_dim, levels.c_offsets, levels.c_scales, levels.c_res, int(m_host),
             _chk(m_dev, "m_dev", torch.int32, allow_none=True), int(level_stride), _chk(dtable, "dtable"),
-            int(variant), _stream())
+            int(variant), ws, ws_bytes, _stream())
     return dtable
 
 
@@ -75,13 +97,14 @@ class _GridEncode(torch.autograd.Function):
     `shadow` an optional bf16 copy that the gather actually reads."""
 
     @staticmethod
-    def forward(ctx, xyzs, table, shadow, levels, bound, m_host, m_dev, level_stride, feat_dtype, variant):
+    def forward(ctx, xyzs, table, shadow, levels, bound, m_host, m_dev, level_stride, feat_dtype, variant,
+                scatter_variant):
         src = table if shadow is None else shadow
         feat = grid_encode_forward(xyzs, bound, src.detach(), levels, m_host, m_dev, level_stride, None, feat_dtype,
                                    variant)
         ctx.save_for_backward(xyzs, m_dev if m_dev is not None else torch.empty(0))
         ctx.has_mdev = m_dev is not None
-        ctx.meta = (levels, bound, m_host, level_stride, variant, table.shape, table.device)
+        ctx.meta = (levels, bound, m_host, level_stride, scatter_variant, table.shape, table.device)
         return feat
 
     @staticmethod
@@ -94,7 +117,7 @@ class _GridEncode(torch.autograd.Function):
             dfeat = dfeat.float()
         grid_encode_backward(xyzs, bound, dfeat, levels, m_host, m_dev if ctx.has_mdev else None, level_stride,
                              dtable, variant)
-        return None, dtable, None, None, None, None, None, None, None, None
+        return None, dtable, None, None, None, None, None, None, None, None, None
 
 
 class GridEncoder(nn.Module):
@@ -103,11 +126,12 @@ class GridEncoder(nn.Module):
     the master changed (or explicitly by the fused Adam step)."""
 
     def __init__(self, num_levels=16, level_dim=2, base_resolution=16, desired_resolution=2048,
-                 log2_hashmap_size=19, table_dtype=torch.float32, variant=1):
+                 log2_hashmap_size=19, table_dtype=torch.float32, variant=1, scatter_variant=2):
         super().__init__()
         self.levels = GridLevels(num_levels, level_dim, base_resolution, desired_resolution, log2_hashmap_size)
         self.out_dim = self.levels.out_dim
         self.variant = variant
+        self.scatter_variant = scatter_variant
         self.table_dtype = table_dtype
         self.embeddings = nn.Parameter(torch.empty(self.levels.n_rows, level_dim))
         self.reset_parameters()
@@ -139,7 +163,7 @@ class GridEncoder(nn.Module):
         if level_stride is None:
             level_stride = xyzs.shape[0]
         return _GridEncode.apply(xyzs, self.embeddings, self.shadow(), self.levels, bound, m_host, m_dev, level_stride,
-                                 feat_dtype, self.variant)
+                                 feat_dtype, self.variant, self.scatter_variant)
 
     def forward(self, inputs, bound=1.0):
         """inputs [..., 3] in [-bound, bound] -> [..., L*2] (sample-major view, as the upstream encoder)."""

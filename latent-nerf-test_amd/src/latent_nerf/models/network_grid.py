@@ -65,7 +65,8 @@ class NeRFNetwork(NeRFRenderer):
         self.precision = cfg.mlp_precision
         table_dtype = torch.bfloat16 if cfg.table_dtype == "bf16" else torch.float32
         self.encoder = GridEncoder(num_levels, level_dim, base_resolution, 2048 * self.bound, log2_hashmap_size,
-                                   table_dtype=table_dtype, variant=cfg.gather_variant)
+                                   table_dtype=table_dtype, variant=cfg.gather_variant,
+                                   scatter_variant=cfg.scatter_variant)
         in_dim, out_dim = self.encoder.out_dim, 1 + self.img_dims
         # nn.Linear default init, kept as bare parameters: the fused kernel takes all six at once
         self.w1 = nn.Parameter(torch.empty(hidden_dim, in_dim))

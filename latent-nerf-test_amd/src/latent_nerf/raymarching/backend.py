@@ -46,7 +46,8 @@ _SIGNATURES = {
     "lnerf_composite_rays": [_L, _I, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _P],
     "lnerf_compact_rays": [_P, _L, _P, _P, _P],
     "lnerf_grid_encode_forward": [_P, _F, _P, _I, _I, _I, _P, _P, _P, _L, _P, _L, _P, _I, _I, _P],
-    "lnerf_grid_encode_backward": [_P, _F, _P, _I, _I, _I, _P, _P, _P, _L, _P, _L, _P, _I, _P],
+    "lnerf_grid_encode_backward_workspace_bytes": [_I, _P, _L],
+    "lnerf_grid_encode_backward": [_P, _F, _P, _I, _I, _I, _P, _P, _P, _L, _P, _L, _P, _I, _P, _Z, _P],
     "lnerf_mlp_forward": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _L, _P, _P, _P, _I, _P],
     "lnerf_mlp_backward_workspace_bytes": [_I],
     "lnerf_mlp_backward": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _L, _P, _P, _P, _P, _P, _P, _P, _P,
@@ -65,6 +66,7 @@ _RESTYPES = {
     "lnerf_last_error": _c.c_char_p,
     "lnerf_build_info": _c.c_char_p,
     "lnerf_mlp_backward_workspace_bytes": _Z,
+    "lnerf_grid_encode_backward_workspace_bytes": _Z,
 }
 
 _lib = None
