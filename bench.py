@@ -49,7 +49,7 @@ def parse():
                     help="f32: f32 table + exact-f32 MFMA MLP; bf16: bf16 shadow table + bf16 MFMA MLP")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
-    ap.add_argument("--gather-variant", type=int, default=1)
+    ap.add_argument("--gather-variant", type=int, default=0)
     ap.add_argument("--breakdown", action="store_true", help="extra untimed pass: per-kernel event timings")
     return ap.parse_args()
 

@@ -56,6 +56,13 @@ const char *lnerf_last_error(void);
 /* "gfx950;<git or build tag>" -- lets the host side assert what it loaded */
 const char *lnerf_build_info(void);
 
+/* Performance knobs (never change results beyond float summation order).  Keys:
+ *   "scatter_compact_max_res": levels with resolution <= value merge per-wavefront runs of equal
+ *                              rows before binning (default 512).
+ *   "scatter_bin_map":         workgroup->(level,tile) map of the binning pass, 0 = level on
+ *                              blockIdx.y (default), 1 = XCD-aware. */
+int lnerf_set_tuning(const char *key, int value);
+
 /* ---- H1: ray generation (absent upstream: `get_rays` of nerf_utils; camera convention
  * src/latent_paint/models/render.py:19-31).  c2w [B,4,4] row-major, columns (right,down,forward,eye).
  * rays_o, rays_d [B, H*W, 3]. */

@@ -12,6 +12,8 @@
 //            tables of its own levels instead of all 16.
 #include "common.h"
 
+#include <string.h>
+
 namespace lnerf {
 
 __device__ __forceinline__ uint32_t grid_index(uint32_t x, uint32_t y, uint32_t z, uint32_t res, uint32_t hsize) {
@@ -182,25 +184,57 @@ k_grid_backward_atomic(const float *__restrict__ xyzs, float bound, const TG *__
 //                             64 KiB tile to the gradient table with coalesced stores.
 // A bucket that overflows its region falls back to global atomics for the excess records, so the
 // result is always complete.
-constexpr int BK_SHIFT = 13, BK_ROWS = 1 << BK_SHIFT;  // 8192 rows * 8 B = 64 KiB
+constexpr int BK_SHIFT = 12, BK_ROWS = 1 << BK_SHIFT;  // 4096 rows * 8 B = 32 KiB of accumulators
+constexpr int BIN_T = 512;                              // threads (= samples) per binning tile
 constexpr int BK_MAX_PER_LEVEL = 256;                   // LDS counters per workgroup tile
+
+// one scatter record: 12 bytes
+struct Rec {
+    uint32_t row;  // row inside the level (bucket = row >> BK_SHIFT)
+    float v0, v1;  // w * dfeat
+};
 
 struct BucketMeta {
     int nb[LNERF_MAX_LEVELS];            // buckets per level
     int bstart[LNERF_MAX_LEVELS + 1];    // first global bucket id of the level
     int cap[LNERF_MAX_LEVELS];           // record capacity of each bucket of the level
     int slices[LNERF_MAX_LEVELS];        // pass-2 workgroups per bucket
+    int compact[LNERF_MAX_LEVELS];       // 1: merge runs of equal rows inside a wavefront before binning
     int wgstart[LNERF_MAX_LEVELS + 1];   // first pass-2 workgroup of the level
     long long rstart[LNERF_MAX_LEVELS];  // first record slot of the level's region
 };
 
+// Sum runs of equal keys across the wavefront (lanes = consecutive samples of a ray: on coarse levels
+// they sit in the same cell, so the same vertex appears in long runs).  After the call, the LAST lane
+// of every run holds the run's sums and returns true; the other lanes return false.
+__device__ __forceinline__ bool wave_run_reduce(uint32_t key, bool valid, float &a0, float &a1) {
+    const int lane = lane_id();
+    const uint32_t prev = __shfl_up(key, 1, 64);
+    const int pvalid = __shfl_up((int)valid, 1, 64);
+    int f = (lane == 0) || (prev != key) || !valid || !pvalid;  // run head
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float t0 = __shfl_up(a0, d, 64), t1 = __shfl_up(a1, d, 64);
+        const int tf = __shfl_up(f, d, 64);
+        if (lane >= d && !f) { a0 += t0; a1 += t1; f = tf; }
+    }
+    const uint32_t next = __shfl_down(key, 1, 64);
+    const int nvalid = __shfl_down((int)valid, 1, 64);
+    const bool tail = (lane == 63) || (next != key) || !nvalid;
+    return valid && tail;
+}
+
 template <typename TG>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(BIN_T, 6)
 k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict__ dfeat, GridMeta meta, BucketMeta bm,
               int64_t m_host, const int32_t *__restrict__ m_dev, int64_t level_stride, int32_t *__restrict__ cursor,
-              uint4 *__restrict__ recs, float *__restrict__ dtable, int variant) {
-    __shared__ int s_cnt[BK_MAX_PER_LEVEL];
-    __shared__ int s_base[BK_MAX_PER_LEVEL];
+              unsigned int *__restrict__ gmax, Rec *__restrict__ recs, float *__restrict__ dtable, int variant) {
+    __shared__ int s_cnt[BK_MAX_PER_LEVEL];   // records of this tile per bucket
+    __shared__ int s_base[BK_MAX_PER_LEVEL];  // first slot reserved in the bucket's global region
+    __shared__ int s_off[BK_MAX_PER_LEVEL];   // first slot of the bucket in the LDS stage
+    __shared__ unsigned int s_max[BK_MAX_PER_LEVEL];  // bit pattern of the largest |value| per bucket
+    __shared__ Rec s_stage[BIN_T * 8];        // the tile's records, grouped by bucket (48 KiB)
+    __shared__ int s_total;
     int64_t M = m_host;
     if (m_dev) { const int64_t md = *m_dev; M = md < M ? md : M; }
     const TileMap tm = tile_map(variant, meta.num_levels);
@@ -211,21 +245,28 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
     const uint32_t off = (uint32_t)meta.offsets[l];
     const uint32_t hsize = (uint32_t)(meta.offsets[l + 1] - meta.offsets[l]);
     const int nb = bm.nb[l], cap = bm.cap[l], b0 = bm.bstart[l];
-    uint4 *lrec = recs + bm.rstart[l];
+    const bool compact = bm.compact[l] != 0;  // wave-uniform: coarse level, merge runs first
+    const bool few_buckets = nb <= 32;        // wave-uniform: rank with ballots instead of per-lane LDS atomics
+    Rec *lrec = recs + bm.rstart[l];
     float *lt = dtable + (int64_t)off * 2;
-    const int tid = threadIdx.x;
-    for (int64_t tile = tm.tile0; tile * 256 < M; tile += tm.tstep) {
-        for (int i = tid; i < nb; i += 256) s_cnt[i] = 0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int64_t tile = tm.tile0; tile * BIN_T < M; tile += tm.tstep) {
+        for (int i = tid; i < nb; i += BIN_T) { s_cnt[i] = 0; s_max[i] = 0u; }
         __syncthreads();
-        const int64_t m = tile * 256 + tid;
+        const int64_t m = tile * BIN_T + tid;
         const bool valid = m < M;
         uint32_t row[8];
-        float wv[8];
+        float v0[8], v1[8];
         int rank[8];
-        float2 gg = make_float2(0.f, 0.f);
-        if (valid) {
-            const LevelPos p = level_pos(xyzs, m, bound, scale);
-            gg = Feat2<TG>::load(dfeat + ((int64_t)l * level_stride + m) * 2, 0);
+        uint32_t emit = 0;  // bit c: this lane appends a record for corner c
+        {
+            LevelPos p;
+            p.gx = p.gy = p.gz = 0; p.fx = p.fy = p.fz = 0.f;
+            float2 gg = make_float2(0.f, 0.f);
+            if (valid) {
+                p = level_pos(xyzs, m, bound, scale);
+                gg = Feat2<TG>::load(dfeat + ((int64_t)l * level_stride + m) * 2, 0);
+            }
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const uint32_t bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
@@ -233,40 +274,118 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
                 const float wx = bx ? p.fx : 1.0f - p.fx;
                 const float wy = by ? p.fy : 1.0f - p.fy;
                 const float wz = bz ? p.fz : 1.0f - p.fz;
-                wv[c] = (wx * wy) * wz;
-                rank[c] = atomicAdd(&s_cnt[row[c] >> BK_SHIFT], 1);
+                const float w = (wx * wy) * wz;
+                v0[c] = w * gg.x;
+                v1[c] = w * gg.y;
+                bool e = valid;
+                if (compact) e = wave_run_reduce(row[c], valid, v0[c], v1[c]);
+                emit |= (e ? 1u : 0u) << c;
             }
         }
-        __syncthreads();
-        for (int i = tid; i < nb; i += 256) {
-            const int c = s_cnt[i];
-            s_base[i] = c ? atomicAdd(&cursor[b0 + i], c) : 0;
+        // ---- rank every record inside its bucket (tile-local)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const bool e = (emit >> c) & 1u;
+            const int b = (int)(row[c] >> BK_SHIFT);
+            rank[c] = 0;
+            if (few_buckets) {  // all lanes of a wave mostly target one or two buckets
+                unsigned long long todo = __ballot(e);
+                while (todo) {
+                    const int leader = __ffsll((long long)todo) - 1;
+                    const int bl = __shfl(b, leader, 64);
+                    const unsigned long long mm = __ballot(e && b == bl);
+                    int base = 0;
+                    if (lane == leader) base = atomicAdd(&s_cnt[bl], __popcll(mm));
+                    base = __shfl(base, leader, 64);
+                    if (e && b == bl) rank[c] = base + mbcnt(mm);
+                    todo &= ~mm;
+                }
+            } else if (e) {
+                rank[c] = atomicAdd(&s_cnt[b], 1);
+            }
+            if (e) atomicMax(&s_max[b], __float_as_uint(fmaxf(fabsf(v0[c]), fabsf(v1[c]))));  // +floats order as uints
         }
         __syncthreads();
-        if (valid) {
+        // ---- exclusive scan of the tile's bucket counts (wave 0); the global reservations (one
+        //      returning atomic per touched bucket) are issued now and consumed after the staging
+        int my_base[(BK_MAX_PER_LEVEL + BIN_T - 1) / BIN_T];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int b = (int)(row[c] >> BK_SHIFT);
-                const int slot = s_base[b] + rank[c];
-                const float v0 = wv[c] * gg.x, v1 = wv[c] * gg.y;
-                if (slot < cap) {
-                    lrec[(int64_t)b * cap + slot] =
-                        make_uint4(row[c] & (BK_ROWS - 1), __float_as_uint(v0), __float_as_uint(v1), 0u);
-                } else {  // bucket region full: finish this record with global atomics
-                    atomicAdd(lt + (int64_t)row[c] * 2, v0);
-                    atomicAdd(lt + (int64_t)row[c] * 2 + 1, v1);
+        for (int k = 0; k < (BK_MAX_PER_LEVEL + BIN_T - 1) / BIN_T; ++k) {
+            const int i = tid + k * BIN_T;
+            my_base[k] = 0;
+            if (i < nb) {
+                const int c = s_cnt[i];
+                if (c) {
+                    my_base[k] = atomicAdd(&cursor[b0 + i], c);
+                    atomicMax(&gmax[b0 + i], s_max[i]);
                 }
             }
         }
-        // s_cnt is re-zeroed behind the next iteration's first barrier; s_base readers are done
-        // before anyone can pass that barrier and the one after it.
+        if (tid < 64) {  // nb <= 256 -> 4 buckets per lane
+            int c4[4], sum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = tid * 4 + k;
+                c4[k] = i < nb ? s_cnt[i] : 0;
+                sum += c4[k];
+            }
+            const int inc = wave_inclusive_sum_i(sum);
+            int run = inc - sum;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = tid * 4 + k;
+                if (i < nb) s_off[i] = run;
+                run += c4[k];
+            }
+            if (tid == 63) s_total = inc;
+        }
+        __syncthreads();
+        // ---- group the records by bucket in LDS
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if ((emit >> c) & 1u) {
+                const int b = (int)(row[c] >> BK_SHIFT);
+                Rec r;
+                r.row = row[c]; r.v0 = v0[c]; r.v1 = v1[c];
+                s_stage[s_off[b] + rank[c]] = r;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < (BK_MAX_PER_LEVEL + BIN_T - 1) / BIN_T; ++k) {
+            const int i = tid + k * BIN_T;
+            if (i < nb) s_base[i] = my_base[k];
+        }
+        __syncthreads();
+        // ---- copy out: consecutive lanes -> consecutive slots of (mostly) the same bucket: coalesced
+        const int total = s_total;
+        for (int i = tid; i < total; i += BIN_T) {
+            const Rec r = s_stage[i];
+            const int b = (int)(r.row >> BK_SHIFT);
+            const int slot = s_base[b] + (i - s_off[b]);
+            if (slot < cap) {
+                lrec[(int64_t)b * cap + slot] = r;
+            } else {  // bucket region full: finish this record with global atomics
+                atomicAdd(lt + (int64_t)r.row * 2, r.v0);
+                atomicAdd(lt + (int64_t)r.row * 2 + 1, r.v1);
+            }
+        }
+        // the next iteration's first barrier orders these LDS reads before s_stage/s_off are rewritten
+        // (s_cnt is only re-zeroed, and nobody reads it after the barrier above)
     }
 }
 
+// Pass 2.  LDS float atomics run at ~0.5 lane/clk on gfx950 while integer LDS atomics run at the
+// plain-store rate (measured: profiles/README.md, "reduce_dbg"), so the tile accumulates in 64-bit
+// FIXED POINT: every value is scaled by a power of two chosen from the bucket's largest |value|
+// (found by pass 1) so that |q| < 2^44, which leaves 2^17 additions of head-room in an int64.  The
+// scaling is exact, the integer sum is exact and order-independent, and the only rounding is the
+// quantisation of each addend to 2^-45 of the bucket maximum plus one final conversion to f32:
+// the result is bitwise reproducible and at least as accurate as an f32 running sum.
 __global__ void __launch_bounds__(512)
-k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ cursor, const uint4 *__restrict__ recs,
-                 float *__restrict__ dtable) {
-    __shared__ float acc[BK_ROWS * 2];
+k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ cursor,
+                 const unsigned int *__restrict__ gmax, const Rec *__restrict__ recs, float *__restrict__ dtable,
+                 int dbg) {
+    __shared__ long long acc[BK_ROWS * 2];
     // locate (level, bucket, slice) of this workgroup
     int l = 0;
     while (l + 1 < meta.num_levels && (int)blockIdx.x >= bm.wgstart[l + 1]) ++l;
@@ -278,37 +397,67 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
     n = n < cap ? n : cap;
     const int lo = (int)(((long long)n * s) / S), hi = (int)(((long long)n * (s + 1)) / S);
     if (hi <= lo) return;  // uniform per workgroup
+    // largest |value| < 2^(e-126)  ->  scale 2^(170-e) puts it below 2^44
+    int e = (int)(gmax[bm.bstart[l] + b] >> 23);
+    e = e < 1 ? 1 : (e > 254 ? 254 : e);
+    int k = 170 - e;               // power of two to scale by; split so that both factors are normal floats
+    k = k > 200 ? 200 : k;
+    const float sc_a = ldexpf(1.0f, k / 2), sc_b = ldexpf(1.0f, k - k / 2);
+    const float un_a = ldexpf(1.0f, -(k / 2)), un_b = ldexpf(1.0f, -(k - k / 2));
     const int tid = threadIdx.x;
-    for (int i = tid; i < BK_ROWS * 2; i += 512) acc[i] = 0.f;
+    for (int i = tid; i < BK_ROWS * 2; i += 512) acc[i] = 0ll;
     __syncthreads();
-    const uint4 *rp = recs + bm.rstart[l] + (long long)b * cap;
-    for (int i = lo + tid; i < hi; i += 512) {
-        const uint4 r = rp[i];
-        atomicAdd(&acc[r.x * 2], __uint_as_float(r.y));
-        atomicAdd(&acc[r.x * 2 + 1], __uint_as_float(r.z));
+    const Rec *rp = recs + bm.rstart[l] + (long long)b * cap;
+    unsigned long long *ua = reinterpret_cast<unsigned long long *>(acc);
+    const uint32_t rmask = BK_ROWS - 1;
+    int i = lo + tid;
+    for (; i + 512 < hi; i += 2 * 512) {  // two 12-byte loads in flight per lane
+        const Rec r0 = rp[i], r1 = rp[i + 512];
+        const long long q00 = __float2ll_rn((r0.v0 * sc_a) * sc_b);
+        const long long q01 = __float2ll_rn((r0.v1 * sc_a) * sc_b);
+        const long long q10 = __float2ll_rn((r1.v0 * sc_a) * sc_b);
+        const long long q11 = __float2ll_rn((r1.v1 * sc_a) * sc_b);
+        atomicAdd(&ua[(r0.row & rmask) * 2], (unsigned long long)q00);
+        atomicAdd(&ua[(r0.row & rmask) * 2 + 1], (unsigned long long)q01);
+        atomicAdd(&ua[(r1.row & rmask) * 2], (unsigned long long)q10);
+        atomicAdd(&ua[(r1.row & rmask) * 2 + 1], (unsigned long long)q11);
     }
+    for (; i < hi; i += 512) {
+        const Rec r = rp[i];
+        atomicAdd(&ua[(r.row & rmask) * 2], (unsigned long long)__float2ll_rn((r.v0 * sc_a) * sc_b));
+        atomicAdd(&ua[(r.row & rmask) * 2 + 1], (unsigned long long)__float2ll_rn((r.v1 * sc_a) * sc_b));
+    }
+    (void)dbg;
     __syncthreads();
     const int hsize = meta.offsets[l + 1] - meta.offsets[l];
     const int row0 = b << BK_SHIFT;
     int rows = hsize - row0;
     rows = rows < BK_ROWS ? rows : BK_ROWS;
     float *dst = dtable + ((int64_t)meta.offsets[l] + row0) * 2;
-    if (S == 1) {  // sole owner of these rows in this launch: plain read-modify-write, 16 B per lane
-        const int n4 = (rows * 2) >> 2;
-        for (int i = tid; i < n4; i += 512) {
-            float4 d = reinterpret_cast<float4 *>(dst)[i];
-            const float4 a = reinterpret_cast<const float4 *>(acc)[i];
-            d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w;
-            reinterpret_cast<float4 *>(dst)[i] = d;
+    if (S == 1) {  // sole owner of these rows in this launch: plain read-modify-write, 8 B per lane
+        for (int r = tid; r < rows; r += 512) {
+            float2 d = reinterpret_cast<float2 *>(dst)[r];
+            d.x += ((float)acc[2 * r] * un_a) * un_b;
+            d.y += ((float)acc[2 * r + 1] * un_a) * un_b;
+            reinterpret_cast<float2 *>(dst)[r] = d;
         }
-        for (int i = (n4 << 2) + tid; i < rows * 2; i += 512) dst[i] += acc[i];
     } else {       // several slices share the rows: contiguous float atomics (256 B per wave instruction)
-        for (int i = tid; i < rows * 2; i += 512) {
-            const float a = acc[i];
-            if (a != 0.f) atomicAdd(&dst[i], a);
+        for (int kk = tid; kk < rows * 2; kk += 512) {
+            const long long a = acc[kk];
+            if (a != 0ll) atomicAdd(&dst[kk], ((float)a * un_a) * un_b);
         }
     }
 }
+
+// levels up to this resolution merge per-wave runs before binning (tunable: lnerf_set_tuning)
+static int g_compact_max_res = 512;
+// workgroup -> (level, tile) map of the binning pass: 0 = level on blockIdx.y, 1 = XCD-aware
+static int g_bin_map = 0;
+// TIMING-ONLY experiment switch of the reduce pass (non-zero values give wrong sums)
+static int g_reduce_dbg = 0;
+
+// device header of the workspace: bucket cursors (int32) followed by bucket maxima (uint32)
+static size_t cursor_bytes(int n_buckets) { return ((size_t)n_buckets * 2 * sizeof(int32_t) + 4095) / 4096 * 4096; }
 
 static int fill_bucket_meta(const GridMeta &meta, int64_t m_host, BucketMeta &bm, int64_t &total_recs,
                             int &total_buckets, int &total_wgs) {
@@ -324,13 +473,14 @@ static int fill_bucket_meta(const GridMeta &meta, int64_t m_host, BucketMeta &bm
         if (cap > 8 * m_host) cap = 8 * m_host;
         if (cap < 64) cap = 64;
         if (cap > 0x7FFFFFFF) return -1;
-        int slices = (int)((per_bucket + 65535) / 65536);    // ~64 Ki records per pass-2 workgroup
+        int slices = (int)((per_bucket + 65535) / 65536);    // <= ~64 Ki records per pass-2 workgroup
         if (slices < 1) slices = 1;
         if (slices > 64) slices = 64;
         bm.nb[l] = nb;
         bm.bstart[l] = total_buckets;
         bm.cap[l] = (int)cap;
         bm.slices[l] = slices;
+        bm.compact[l] = meta.res[l] <= g_compact_max_res ? 1 : 0;
         bm.wgstart[l] = total_wgs;
         bm.rstart[l] = total_recs;
         total_buckets += nb;
@@ -409,16 +559,37 @@ int lnerf_grid_encode_forward(const float *xyzs, float bound, const void *table,
     return LNERF_OK;
 }
 
+int lnerf_set_tuning(const char *key, int value) {
+    LNERF_REQUIRE(key, "set_tuning: null key");
+    if (strcmp(key, "scatter_compact_max_res") == 0) {
+        LNERF_REQUIRE(value >= 0, "set_tuning: scatter_compact_max_res must be >= 0");
+        g_compact_max_res = value;
+        return LNERF_OK;
+    }
+    if (strcmp(key, "scatter_bin_map") == 0) {
+        LNERF_REQUIRE(value == 0 || value == 1, "set_tuning: scatter_bin_map must be 0 or 1");
+        g_bin_map = value;
+        return LNERF_OK;
+    }
+    if (strcmp(key, "scatter_reduce_debug") == 0) {
+        g_reduce_dbg = value;
+        return LNERF_OK;
+    }
+    set_error("set_tuning: unknown key '%s'", key);
+    return LNERF_ERR_INVALID_ARG;
+}
+
 size_t lnerf_grid_encode_backward_workspace_bytes(int num_levels, const int32_t *offsets_host, int64_t m_host) {
     if (num_levels < 1 || num_levels > LNERF_MAX_LEVELS || !offsets_host || m_host < 0) return 0;
     GridMeta meta;
     meta.num_levels = num_levels;
     for (int l = 0; l <= num_levels; ++l) meta.offsets[l] = offsets_host[l];
+    for (int l = 0; l < num_levels; ++l) meta.res[l] = 0;
     BucketMeta bm;
     int64_t recs;
     int nbk, nwg;
     if (fill_bucket_meta(meta, m_host, bm, recs, nbk, nwg) != 0) return 0;
-    return (size_t)4096 + (size_t)recs * sizeof(uint4);  // [0,4096): bucket cursors, then the records
+    return cursor_bytes(nbk) + (size_t)recs * sizeof(Rec);  // bucket cursors, then the records
 }
 
 int lnerf_grid_encode_backward(const float *xyzs, float bound, const void *dfeat, int dfeat_dtype, int num_levels,
@@ -449,23 +620,25 @@ int lnerf_grid_encode_backward(const float *xyzs, float bound, const void *dfeat
     int nbk, nwg;
     LNERF_REQUIRE(fill_bucket_meta(meta, m_host, bm, recs, nbk, nwg) == 0,
                   "grid_encode_backward: level too large for the bucketed scatter (use variant 0/1)");
-    LNERF_REQUIRE(nbk * (int)sizeof(int32_t) <= 4096, "grid_encode_backward: too many buckets (%d)", nbk);
-    const size_t need = (size_t)4096 + (size_t)recs * sizeof(uint4);
+    const size_t cbytes = cursor_bytes(nbk);
+    const size_t need = cbytes + (size_t)recs * sizeof(Rec);
     LNERF_REQUIRE(workspace && workspace_bytes >= need, "grid_encode_backward: workspace too small (%zu < %zu)",
                   workspace_bytes, need);
     LNERF_REQUIRE(((uintptr_t)workspace & 15) == 0 && ((uintptr_t)dtable & 15) == 0,
                   "grid_encode_backward: workspace/dtable must be 16-byte aligned");
     int32_t *cursor = (int32_t *)workspace;
-    uint4 *rec = (uint4 *)((char *)workspace + 4096);
-    if (hipMemsetAsync(cursor, 0, 4096, s) != hipSuccess) {
+    unsigned int *gmax = (unsigned int *)workspace + nbk;
+    Rec *rec = (Rec *)((char *)workspace + cbytes);
+    if (hipMemsetAsync(cursor, 0, cbytes, s) != hipSuccess) {
         set_error("grid_encode_backward: hipMemsetAsync failed");
         return LNERF_ERR_HIP;
     }
-    launch_dims(1, num_levels, m_host, grid);
-    hipLaunchKernelGGL((k_scatter_bin<float>), grid, dim3(256), 0, s, xyzs, bound, (const float *)dfeat, meta, bm,
-                       m_host, m_dev, level_stride, cursor, rec, dtable, 1);
+    launch_dims(g_bin_map, num_levels, div_up(m_host, BIN_T / 256), grid);  // tiles of BIN_T samples
+    hipLaunchKernelGGL((k_scatter_bin<float>), grid, dim3(BIN_T), 0, s, xyzs, bound, (const float *)dfeat, meta, bm,
+                       m_host, m_dev, level_stride, cursor, gmax, rec, dtable, g_bin_map);
     LNERF_CHECK_LAUNCH("grid_encode_backward(bin)");
-    hipLaunchKernelGGL(k_scatter_reduce, dim3((unsigned)nwg), dim3(512), 0, s, meta, bm, cursor, rec, dtable);
+    hipLaunchKernelGGL(k_scatter_reduce, dim3((unsigned)nwg), dim3(512), 0, s, meta, bm, cursor, gmax, rec, dtable,
+                       g_reduce_dbg);
     LNERF_CHECK_LAUNCH("grid_encode_backward(reduce)");
     return LNERF_OK;
 }

@@ -46,7 +46,7 @@ class GridLevels:
 
 
 def grid_encode_forward(xyzs, bound, table, levels: GridLevels, m_host, m_dev, level_stride, out=None,
-                        out_dtype=torch.float32, variant=1):
+                        out_dtype=torch.float32, variant=0):
     """xyzs [>=m_host,3] world positions -> level-major features [L, level_stride, 2]."""
     tdt = _b.F32 if table.dtype == torch.float32 else _b.BF16
     if table.dtype not in (torch.float32, torch.bfloat16):
@@ -126,7 +126,7 @@ class GridEncoder(nn.Module):
     the master changed (or explicitly by the fused Adam step)."""
 
     def __init__(self, num_levels=16, level_dim=2, base_resolution=16, desired_resolution=2048,
-                 log2_hashmap_size=19, table_dtype=torch.float32, variant=1, scatter_variant=2):
+                 log2_hashmap_size=19, table_dtype=torch.float32, variant=0, scatter_variant=2):
         super().__init__()
         self.levels = GridLevels(num_levels, level_dim, base_resolution, desired_resolution, log2_hashmap_size)
         self.out_dim = self.levels.out_dim

@@ -36,6 +36,7 @@ _SIGNATURES = {
     "lnerf_abi_version": [],
     "lnerf_last_error": [],
     "lnerf_build_info": [],
+    "lnerf_set_tuning": [_c.c_char_p, _I],
     "lnerf_get_rays": [_P, _I, _I, _I, _F, _F, _F, _F, _P, _P, _P],
     "lnerf_near_far_from_aabb": [_P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P],
     "lnerf_morton3d": [_P, _L, _P, _P],

@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Kernel-level A/B timings on the bench scene (64x64 rays, 128^3 sphere occupancy, M ~ 4.3e5 samples).
+
+Variants of one op are timed in interleaved rounds inside one process (guide §5.4 rule 24) with HIP
+events on the launch stream; prints one JSON object.  Usage (GPU box):
+    python tools/microbench.py [gather] [scatter] [mlp]
+"""
+import json
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (ROOT, os.path.join(ROOT, "latent-nerf-test_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+
+def timed(fns, rounds=20, warm=3):
+    """fns: dict name -> callable.  Returns name -> (median_ms, min_ms)."""
+    for _ in range(warm):
+        for f in fns.values():
+            f()
+    torch.cuda.synchronize()
+    samples = {k: [] for k in fns}
+    for _ in range(rounds):
+        for k, f in fns.items():
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            f()
+            b.record()
+            samples[k].append((a, b))
+    torch.cuda.synchronize()
+    out = {}
+    for k, evs in samples.items():
+        ts = sorted(a.elapsed_time(b) for a, b in evs)
+        out[k] = (round(ts[len(ts) // 2], 4), round(ts[0], 4))
+    return out
+
+
+def main():
+    which = set(sys.argv[1:]) or {"gather", "scatter", "mlp"}
+    import bench
+    from src.latent_nerf.models import encoding as E
+    from src.latent_nerf.raymarching import backend as B
+    from src.latent_nerf.raymarching import raymarching as rm
+    dev = torch.device("cuda:0")
+    net, pose, intr, bg, grad = bench.build(dev, "f32", 1, 0)
+    rays_o, rays_d = rm.get_rays(pose, intr, bench.H, bench.W)
+    out = net.render(rays_o, rays_d, bg_color=bg, perturb=False)
+    M = int(out["counter"][0])
+    cap = net._march.capacity
+    xyzs = net._march.xyzs
+    m_dev = net._march.counter[0:1]
+    levels = net.encoder.levels
+    table = net.encoder.embeddings.data
+    table_bf = table.to(torch.bfloat16)
+    res = {"M": M, "capacity": cap}
+
+    if "gather" in which:
+        f32o = torch.empty(16, cap, 2, device=dev)
+        bf16o = torch.empty(16, cap, 2, device=dev, dtype=torch.bfloat16)
+        fns = {}
+        for var in (0, 1):
+            fns["f32tab_f32out_v%d" % var] = (lambda v=var: E.grid_encode_forward(xyzs, 1.0, table, levels, cap, m_dev, cap, f32o, variant=v))
+            fns["bf16tab_f32out_v%d" % var] = (lambda v=var: E.grid_encode_forward(xyzs, 1.0, table_bf, levels, cap, m_dev, cap, f32o, variant=v))
+            fns["bf16tab_bf16out_v%d" % var] = (lambda v=var: E.grid_encode_forward(xyzs, 1.0, table_bf, levels, cap, m_dev, cap, bf16o, variant=v))
+        t = timed(fns)
+        res["gather_ms(median,min)"] = t
+        res["gather_GBps_algorithmic"] = {k: round(M * (1164 if k.startswith("f32tab") else (652 if "f32out" in k else 588)) / (v[0] * 1e-3) / 1e9, 1)
+                                          for k, v in t.items()}
+
+    if "scatter" in which:
+        dfeat = torch.randn(16, cap, 2, device=dev)
+        dtable = torch.zeros_like(table)
+        fns = {}
+        for cmr in (0, 32, 128, 512):
+            def f(c=cmr):
+                B.call("lnerf_set_tuning", b"scatter_compact_max_res", c)
+                E.grid_encode_backward(xyzs, 1.0, dfeat, levels, cap, m_dev, cap, dtable, variant=2)
+            fns["bucketed_compact%d" % cmr] = f
+        t = timed(fns, rounds=10)
+        B.call("lnerf_set_tuning", b"scatter_compact_max_res", 512)
+        res["scatter_ms(median,min)"] = t
+
+    if "scatter_levels" in which:
+        # one launch pair per level (num_levels = 1 slices of the level table): per-level cost under rocprofv3
+        import ctypes
+        from src.latent_nerf.raymarching.raymarching import _p, _stream
+        dfeat = torch.randn(16, cap, 2, device=dev)
+        dtable = torch.zeros_like(table)
+        ws = E.scatter_workspace(levels, cap, dev)
+        per = {}
+        for l in range(16):
+            offs = (ctypes.c_int32 * 2)(levels.offsets[l], levels.offsets[l + 1])
+            sc = (ctypes.c_float * 1)(levels.scales[l])
+            rs = (ctypes.c_int32 * 1)(levels.resolutions[l])
+            dptr = ctypes.c_void_p(dfeat.data_ptr() + l * cap * 2 * 4)
+
+            def f(offs=offs, sc=sc, rs=rs, dptr=dptr):
+                B.call("lnerf_grid_encode_backward", _p(xyzs), 1.0, dptr, B.F32, 1, 2, offs, sc, rs, cap, _p(m_dev), cap,
+                       _p(dtable), 2, _p(ws), ws.numel(), _stream())
+            per["level%02d" % l] = f
+        res["scatter_level_ms(median,min)"] = timed(per, rounds=6, warm=1)
+
+    if "mlp" in which:
+        from src.latent_nerf.models.network_grid import _SigmaLatentMLP
+        feat = torch.randn(16, cap, 2, device=dev) * 0.3
+        with torch.no_grad():
+            t = timed({"mlp_fwd_f32": lambda: _SigmaLatentMLP.apply(feat, xyzs, net.w1, net.b1, net.w2, net.b2, net.w3, net.b3,
+                                                                   cap, m_dev, cap, 5.0, 0.2, B.F32, net._mlp_ws)})
+        res["mlp_ms(median,min)"] = t
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
