@@ -45,8 +45,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--precision", default=os.environ.get("LNERF_BENCH_PRECISION", "f32"), choices=["f32", "bf16"],
-                    help="f32: f32 table + exact-f32 MFMA MLP; bf16: bf16 shadow table + bf16 MFMA MLP")
+    ap.add_argument("--precision", default=os.environ.get("LNERF_BENCH_PRECISION", "bf16"), choices=["f32", "bf16"],
+                    help="bf16 (BASELINE configs[1]): bf16 shadow table + bf16 features + bf16 MFMA MLP, f32 "
+                         "master weights/accumulation/compositing; f32: f32 table + exact-f32 MFMA MLP")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--gather-variant", type=int, default=0)

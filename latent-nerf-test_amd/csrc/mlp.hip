@@ -8,38 +8,19 @@
 // MFMA 16x16x4 f32 lane maps (guide §3):  A[i = l&15][k = l>>4],  B[k = l>>4][j = l&15],
 // C/D[i = (l>>4)*4 + reg][j = l&15].
 #include "common.h"
+#include "mlp_shared.h"
 
 namespace lnerf {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-constexpr int IN = 32, HID = 64, OUTP = 16;  // OUTP: padded output width (one 16-wide tile)
+constexpr int IN = MLP_IN, HID = MLP_HID, OUTP = MLP_OUTP;
 constexpr int LDX = IN + 1, LDH = HID + 1;   // padded LDS leading dimensions
-
-struct MlpArgs {
-    const void *feat;
-    int feat_bf16;
-    int64_t level_stride;
-    const float *xyzs;
-    const float *w1, *b1, *w2, *b2, *w3, *b3;
-    int out_dim;
-    float blob_scale, blob_denom;  // blob = scale * exp(-|x|^2 / denom), denom = 2 std^2
-    int64_t m_host;
-    const int32_t *m_dev;
-};
 
 __device__ __forceinline__ float load_feat(const MlpArgs &a, int level, int f, int64_t m) {
     const int64_t i = ((int64_t)level * a.level_stride + m) * 2 + f;
     if (a.feat_bf16) return bf16_to_f32(reinterpret_cast<const uint16_t *>(a.feat)[i]);
     return reinterpret_cast<const float *>(a.feat)[i];
-}
-
-__device__ __forceinline__ float blob_of(const MlpArgs &a, int64_t m) {
-    const float x = a.xyzs[m * 3], y = a.xyzs[m * 3 + 1], z = a.xyzs[m * 3 + 2];
-    const float d2 = (x * x + y * y) + z * z;
-    return a.blob_scale * expf(-d2 / a.blob_denom);
 }
 
 // ------------------------------------------------------------------ forward
@@ -125,10 +106,9 @@ k_mlp_forward_f32(MlpArgs a, float *__restrict__ sigmas, float *__restrict__ rgb
 }
 
 // ------------------------------------------------------------------ backward
-// slab layout (floats): dW1 [64*32] | db1 [64] | dW2 [64*64] | db2 [64] | dW3 [16*64] | db3 [16]
-constexpr int SL_W1 = 0, SL_B1 = SL_W1 + HID * IN, SL_W2 = SL_B1 + HID, SL_B2 = SL_W2 + HID * HID,
-              SL_W3 = SL_B2 + HID, SL_B3 = SL_W3 + OUTP * HID, SLAB = SL_B3 + OUTP;
-constexpr int BWD_MAX_BLOCKS = 512;
+constexpr int SL_W1 = MLP_SL_W1, SL_B1 = MLP_SL_B1, SL_W2 = MLP_SL_W2, SL_B2 = MLP_SL_B2, SL_W3 = MLP_SL_W3,
+              SL_B3 = MLP_SL_B3, SLAB = MLP_SLAB;
+constexpr int BWD_MAX_BLOCKS = MLP_BWD_MAX_BLOCKS;
 
 __global__ void __launch_bounds__(256, 2)
 k_mlp_backward_f32(MlpArgs a, const float *__restrict__ sigmas, const float *__restrict__ dsigmas,
@@ -424,9 +404,13 @@ int lnerf_mlp_forward(const void *feat, int feat_dtype, int64_t level_stride, co
     if (rc) return rc;
     if (m_host == 0) return LNERF_OK;
     LNERF_REQUIRE(sigmas && rgbs, "mlp_forward: null output");
-    LNERF_REQUIRE(precision == LNERF_F32, "mlp_forward: bf16 precision is not built yet");
     MlpArgs a{feat, feat_dtype == LNERF_BF16, level_stride, xyzs, w1, b1, w2, b2, w3, b3, out_dim, blob_scale,
               2.0f * blob_std * blob_std, m_host, m_dev};
+    if (precision == LNERF_BF16) {
+        int64_t blocks = div_up(m_host, 128);
+        if (blocks > 2048) blocks = 2048;
+        return launch_mlp_forward_bf16(a, sigmas, rgbs, (int)blocks, as_stream(stream));
+    }
     int64_t blocks = div_up(m_host, 64);
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(k_mlp_forward_f32, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a, sigmas, rgbs);
@@ -451,18 +435,22 @@ int lnerf_mlp_backward(const void *feat, int feat_dtype, int64_t level_stride, c
     if (m_host == 0) return LNERF_OK;
     LNERF_REQUIRE(sigmas && dsigmas && drgbs && dfeat && dw1 && db1 && dw2 && db2 && dw3 && db3,
                   "mlp_backward: null pointer");
-    LNERF_REQUIRE(precision == LNERF_F32, "mlp_backward: bf16 precision is not built yet");
     LNERF_REQUIRE(workspace && workspace_bytes >= lnerf_mlp_backward_workspace_bytes(out_dim),
                   "mlp_backward: workspace too small (%zu < %zu)", workspace_bytes,
                   lnerf_mlp_backward_workspace_bytes(out_dim));
     MlpArgs a{feat, feat_dtype == LNERF_BF16, level_stride, xyzs, w1, b1, w2, b2, w3, b3, out_dim, blob_scale,
               2.0f * blob_std * blob_std, m_host, m_dev};
-    int64_t blocks = div_up(m_host, 64);
+    int64_t blocks = div_up(m_host, precision == LNERF_BF16 ? 128 : 64);
     if (blocks > BWD_MAX_BLOCKS) blocks = BWD_MAX_BLOCKS;
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(k_mlp_backward_f32, dim3((unsigned)blocks), dim3(256), 0, s, a, sigmas, dsigmas, drgbs, dfeat,
-                       (float *)workspace);
-    LNERF_CHECK_LAUNCH("mlp_backward");
+    if (precision == LNERF_BF16) {
+        int rc2 = launch_mlp_backward_bf16(a, sigmas, dsigmas, drgbs, dfeat, (float *)workspace, (int)blocks, s);
+        if (rc2) return rc2;
+    } else {
+        hipLaunchKernelGGL(k_mlp_backward_f32, dim3((unsigned)blocks), dim3(256), 0, s, a, sigmas, dsigmas, drgbs,
+                           dfeat, (float *)workspace);
+        LNERF_CHECK_LAUNCH("mlp_backward");
+    }
     hipLaunchKernelGGL(k_mlp_reduce_slabs, dim3((unsigned)div_up(SLAB, 64)), dim3(256), 0, s,
                        (const float *)workspace, (int)blocks, out_dim, dw1, db1, dw2, db2, dw3, db3);
     LNERF_CHECK_LAUNCH("mlp_backward(reduce)");

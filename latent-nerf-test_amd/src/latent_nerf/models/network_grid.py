@@ -54,6 +54,63 @@ class _SigmaLatentMLP(torch.autograd.Function):
         return (dfeat, None, *grads, None, None, None, None, None, None, None)
 
 
+class _HashMLPField(torch.autograd.Function):
+    """sigma, latent = MLP(hash_encode(xyzs)) as ONE autograd node: the level-major feature tensor (f32 or
+    bf16) and its f32 gradient stay internal, so autograd never re-casts or copies them.
+    forward : gather (lnerf_grid_encode_forward) -> MLP (lnerf_mlp_forward)
+    backward: MLP backward (-> dfeat f32, weight grads) -> scatter (lnerf_grid_encode_backward)."""
+
+    @staticmethod
+    def forward(ctx, xyzs, table, shadow, w1, b1, w2, b2, w3, b3, encoder, bound, m_host, m_dev, level_stride,
+                blob_scale, blob_std, precision, workspace):
+        from . import encoding as E
+        levels = encoder.levels
+        src = table if shadow is None else shadow
+        feat_dtype = torch.bfloat16 if precision == _b.BF16 else torch.float32
+        feat = E.grid_encode_forward(xyzs, bound, src.detach(), levels, m_host, m_dev, level_stride, None, feat_dtype,
+                                     encoder.variant)
+        out_dim = w3.shape[0]
+        dev = xyzs.device
+        sigmas = torch.empty(level_stride, device=dev, dtype=torch.float32)
+        rgbs = torch.empty(level_stride, out_dim - 1, device=dev, dtype=torch.float32)
+        fdt = _b.F32 if feat.dtype == torch.float32 else _b.BF16
+        _b.call("lnerf_mlp_forward", _p(feat), fdt, int(level_stride), _chk(xyzs, "xyzs"), _chk(w1, "w1"),
+                _chk(b1, "b1"), _chk(w2, "w2"), _chk(b2, "b2"), _chk(w3, "w3"), _chk(b3, "b3"), out_dim,
+                float(blob_scale), float(blob_std), int(m_host), _chk(m_dev, "m_dev", torch.int32, allow_none=True),
+                _p(sigmas), _p(rgbs), precision, _stream())
+        ctx.save_for_backward(xyzs, feat, w1, b1, w2, b2, w3, b3, sigmas,
+                              m_dev if m_dev is not None else torch.empty(0))
+        ctx.meta = (encoder, bound, m_host, m_dev is not None, level_stride, blob_scale, blob_std, precision, workspace,
+                    table.shape)
+        return sigmas, rgbs
+
+    @staticmethod
+    def backward(ctx, dsigmas, drgbs):
+        from . import encoding as E
+        xyzs, feat, w1, b1, w2, b2, w3, b3, sigmas, m_dev = ctx.saved_tensors
+        (encoder, bound, m_host, has_mdev, level_stride, blob_scale, blob_std, precision, workspace,
+         tshape) = ctx.meta
+        m_dev = m_dev if has_mdev else None
+        out_dim = w3.shape[0]
+        dev = xyzs.device
+        dsigmas = torch.zeros_like(sigmas) if dsigmas is None else dsigmas.contiguous()
+        drgbs = torch.zeros(level_stride, out_dim - 1, device=dev) if drgbs is None else drgbs.contiguous()
+        dfeat = torch.empty(feat.shape, device=dev, dtype=torch.float32)
+        grads = [torch.zeros_like(t) for t in (w1, b1, w2, b2, w3, b3)]
+        need = _b.get_lib().lnerf_mlp_backward_workspace_bytes(out_dim)
+        if workspace is None or workspace.numel() < need:
+            workspace = torch.empty(need, device=dev, dtype=torch.uint8)
+        fdt = _b.F32 if feat.dtype == torch.float32 else _b.BF16
+        _b.call("lnerf_mlp_backward", _p(feat), fdt, int(level_stride), _p(xyzs), _p(w1), _p(b1), _p(w2), _p(b2),
+                _p(w3), _p(b3), out_dim, float(blob_scale), float(blob_std), int(m_host), _p(m_dev), _p(sigmas),
+                _chk(dsigmas, "dsigmas"), _chk(drgbs, "drgbs"), _p(dfeat), *[_p(g) for g in grads], _p(workspace),
+                workspace.numel(), precision, _stream())
+        dtable = torch.zeros(tshape, device=dev, dtype=torch.float32)
+        E.grid_encode_backward(xyzs, bound, dfeat, encoder.levels, m_host, m_dev, level_stride, dtable,
+                               encoder.scatter_variant)
+        return (None, dtable, None, *grads, None, None, None, None, None, None, None, None, None)
+
+
 class NeRFNetwork(NeRFRenderer):
     def __init__(self, cfg, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19,
                  hidden_dim=64, blob_scale=5.0, blob_std=0.2):
@@ -96,14 +153,13 @@ class NeRFNetwork(NeRFRenderer):
         """xyzs [cap,3] -> sigmas [cap], latents [cap,C] for the first min(m_host, *m_dev) rows."""
         if level_stride is None:
             level_stride = xyzs.shape[0]
-        feat_dtype = torch.bfloat16 if self.precision == "bf16" else torch.float32
-        feat = self.encoder.encode(xyzs, self.bound, m_host, m_dev, level_stride, feat_dtype)
         if self._mlp_ws is None or self._mlp_ws.device != xyzs.device:
             need = _b.get_lib().lnerf_mlp_backward_workspace_bytes(self.w3.shape[0])
             self._mlp_ws = torch.empty(need, device=xyzs.device, dtype=torch.uint8)
-        sigmas, rgbs = _SigmaLatentMLP.apply(feat, xyzs, self.w1, self.b1, self.w2, self.b2, self.w3, self.b3, m_host,
-                                             m_dev, level_stride, self.blob_scale, self.blob_std,
-                                             _PREC[self.precision], self._mlp_ws)
+        enc = self.encoder
+        sigmas, rgbs = _HashMLPField.apply(xyzs, enc.embeddings, enc.shadow(), self.w1, self.b1, self.w2, self.b2,
+                                           self.w3, self.b3, enc, self.bound, m_host, m_dev, level_stride,
+                                           self.blob_scale, self.blob_std, _PREC[self.precision], self._mlp_ws)
         if not self.latent_mode:
             rgbs = torch.sigmoid(rgbs)
         return sigmas, rgbs

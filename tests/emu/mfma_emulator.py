@@ -22,3 +22,20 @@ def mfma_16x16x4_f32(a, b, c):
         for r in range(4):
             out[l, r] += D[(l >> 4) * 4 + r, l & 15]
     return out
+
+
+def mfma_16x16x32(a, b, c):
+    """v_mfma_f32_16x16x32_{bf16,f16} lane maps: a, b: [64, 8] per-lane fragments
+    (A[i = l&15][k = 8*(l>>4) + jj], B[k = 8*(l>>4) + jj][j = l&15]); c: [64, 4]."""
+    A = np.zeros((16, 32), dtype=np.float64)
+    B = np.zeros((32, 16), dtype=np.float64)
+    for l in range(64):
+        for jj in range(8):
+            A[l & 15, 8 * (l >> 4) + jj] = a[l, jj]
+            B[8 * (l >> 4) + jj, l & 15] = b[l, jj]
+    D = A @ B
+    out = c.astype(np.float64).copy()
+    for l in range(64):
+        for r in range(4):
+            out[l, r] += D[(l >> 4) * 4 + r, l & 15]
+    return out

@@ -290,6 +290,48 @@ def test_mlp_forward_backward_f32(dev, M):
         _close_rel_max(pg[k].grad, pr[k].grad, 1e-4, "d" + k)
 
 
+@pytest.mark.parametrize("M,feat_bf16", [(1, True), (31, True), (129, False), (5000, True), (70001, True)])
+def test_mlp_forward_backward_bf16(dev, M, feat_bf16):
+    """bf16 MFMA path vs the oracle with bf16-rounded operands (features, weights, hidden activations)
+    and f32 accumulation.  Tolerances: forward rtol 2e-2 / atol 2e-3 (an accumulation-order difference
+    can flip the bf16 rounding of a hidden unit); gradients 3e-2 of the largest reference entry
+    (the kernel additionally rounds dZ to bf16 before each product)."""
+    from src.latent_nerf.models.network_grid import _SigmaLatentMLP
+    from src.latent_nerf.raymarching import backend as B
+    feat, xyz, p = _mlp_inputs(M, seed=M + 1)
+    feat = feat.to(torch.bfloat16).float()  # what the bf16 gather would hand over
+    pr = {k: v.clone().requires_grad_() for k, v in p.items()}
+    fr = feat.clone().requires_grad_()
+    s_ref, c_ref = O.sigma_latent_mlp(fr, xyz, pr, bf16=True)
+    gs, gc = torch.randn(M) * 0.1, torch.randn(M, 4)
+    ((s_ref * gs).sum() + (c_ref * gc).sum()).backward()
+    stride = M + 7
+    lm = torch.zeros(16, stride, 2)
+    lm[:, :M, :] = feat.reshape(M, 16, 2).permute(1, 0, 2)
+    lm = lm.to(dev)
+    if feat_bf16:
+        lm = lm.to(torch.bfloat16)
+    lm.requires_grad_()
+    pg = {k: v.to(dev).requires_grad_() for k, v in p.items()}
+    xg = torch.zeros(stride, 3)
+    xg[:M] = xyz
+    m_dev = torch.tensor([M], dtype=torch.int32, device=dev)
+    sig, rgb = _SigmaLatentMLP.apply(lm, xg.to(dev), pg["w1"], pg["b1"], pg["w2"], pg["b2"], pg["w3"], pg["b3"],
+                                     stride, m_dev, stride, 5.0, 0.2, B.BF16, None)
+    _close(sig[:M], s_ref, 2e-2, 2e-3, "sigma bf16")
+    _close(rgb[:M], c_ref, 2e-2, 2e-3, "latent bf16")
+    gsp, gcp = torch.zeros(stride), torch.zeros(stride, 4)
+    gsp[:M], gcp[:M] = gs, gc
+    torch.autograd.backward([sig, rgb], [gsp.to(dev), gcp.to(dev)])
+    dfe = lm.grad.float()[:, :M, :].permute(1, 0, 2).reshape(M, 32)
+    _close_rel_max(dfe, fr.grad, 3e-2, "dfeat bf16")
+    for k in ("w1", "b1", "w2", "b2", "w3", "b3"):
+        _close_rel_max(pg[k].grad, pr[k].grad, 3e-2, "bf16 d" + k)
+    # and the bf16 path stays close to the exact f32 network (sanity on the rounding model)
+    s32, c32 = O.sigma_latent_mlp(feat, xyz, p)
+    _close(rgb[:M], c32, 5e-2, 2e-2, "latent bf16 vs f32")
+
+
 def test_mlp_trunc_exp_clamp_and_rgb_mode_shapes(dev):
     from src.latent_nerf.models.network_grid import _SigmaLatentMLP
     from src.latent_nerf.raymarching import backend as B

@@ -101,6 +101,34 @@ def test_render_train_matches_oracle(dev, size):
         assert e <= 2e-3 * s + 1e-7, ("d" + k, e, s)
 
 
+def test_render_train_bf16_matches_bf16_oracle(dev):
+    """BASELINE config 2 precision (bf16 shadow table, bf16 features, bf16 MFMA MLP, f32 compositing)
+    against the oracle with the same roundings.  Discrete outputs stay bit-exact; images within 2e-2."""
+    G, HW, log2_T, base = 64, 32, 14, 16
+    net, cfg, lv, table, params, grid = _make(dev, G, HW, log2_T, base, seed=2, mlp_precision="bf16", table_dtype="bf16")
+    net.train()
+    ro, rd = _rays(HW, 70.0, 30.0, 1.3)
+    N = HW * HW
+    torch.manual_seed(3)
+    bg = torch.rand(N, 4)
+    g = torch.randn(1, N, 4) * 0.35
+    out = net.render(ro.to(dev), rd.to(dev), bg_color=bg.to(dev), perturb=False)
+    out["image"].backward(g.to(dev))
+    ref = O.render_frame(ro[0], rd[0], table, params, lv, O.packbits(grid.reshape(-1), 0.01), G=G, bg_color=bg,
+                         bf16_mlp=True, bf16_table=True)
+    ref["image"].backward(g[0])
+    assert int(out["counter"][0]) == ref["M"] and torch.equal(out["rays"].cpu(), ref["rays"])
+    e, s = _err(out["image"][0], ref["image"])
+    assert e <= 2e-2 * max(s, 1.0), ("image", e, s)
+    e, s = _err(out["weights_sum"][0], ref["weights_sum"])
+    assert e <= 2e-2, ("weights_sum", e)
+    e, s = _err(net.encoder.embeddings.grad, table.grad)
+    assert e <= 5e-2 * s, ("dtable", e, s)
+    for k in ("w1", "b1", "w2", "b2", "w3", "b3"):
+        e, s = _err(getattr(net, k).grad, params[k].grad)
+        assert e <= 5e-2 * s + 1e-7, ("d" + k, e, s)
+
+
 def test_render_contract_and_properties(dev):
     """The renderer->trainer contract of src/latent_paint/models/textured_mesh.py:181-220 /
     src/stable_diffusion.py:259: 'image' reshapes to [B,4,H,W] latents, and
