@@ -52,6 +52,10 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--gather-variant", type=int, default=0)
     ap.add_argument("--breakdown", action="store_true", help="extra untimed pass: per-kernel event timings")
+    ap.add_argument("--graph", type=int, default=1,
+                    help="1: replay the captured hipGraph of the whole step (every --probe-every-th timed step still runs "
+                         "eagerly so that the gather can be bracketed by HIP events); 0: eager launches only")
+    ap.add_argument("--probe-every", type=int, default=8)
     return ap.parse_args()
 
 
@@ -78,52 +82,29 @@ def build(dev, precision, variant, rank):
     return net, pose, intr, bg, grad
 
 
-class AdamState:
-    """Fused HIP Adam over every parameter tensor (betas/eps of the reference's trainer.py:93-95)."""
-
-    def __init__(self, net, lr):
-        self.items = []
-        for group in net.get_params(lr):
-            for p in group["params"]:
-                self.items.append((p, torch.zeros_like(p), torch.zeros_like(p), group["lr"]))
-        self.step_no = 0
-        self.net = net
-
-    def step(self, grad_scale):
-        from src.latent_nerf.raymarching import backend as B
-        from src.latent_nerf.raymarching.raymarching import _p, _stream
-        self.step_no += 1
-        enc = self.net.encoder
-        for p, m, v, lr in self.items:
-            # the kernel rewrites the bf16 shadow in the same pass (the ctypes write does not bump the
-            # tensor version, so GridEncoder keeps treating the shadow as current -- which it is)
-            shadow = enc.shadow() if p is enc.embeddings else None
-            B.call("lnerf_adam_step", _p(p.data), _p(p.grad), _p(m), _p(v), _p(shadow), p.numel(), lr, 0.9, 0.99, 1e-15,
-                   self.step_no, grad_scale, 0, _stream())
-            p.grad = None
-
-
 def make_step(net, pose, intr, bg, grad, opt, world):
+    """Returns (eager_step, fwd_bwd, opt_step, sync)."""
     from src.latent_nerf.raymarching import raymarching as rm
-    import torch.distributed as dist
+    from src.latent_nerf.training.distributed import GradSync
     small = [p for p in net.parameters() if p is not net.encoder.embeddings]
+    sync = GradSync([net.encoder.embeddings], small)
 
-    def step():
+    def fwd_bwd():
         rays_o, rays_d = rm.get_rays(pose, intr, H, W)
         out = net.render(rays_o, rays_d, bg_color=bg, perturb=True)
         out["image"].backward(gradient=grad)
-        if world > 1:
-            dist.all_reduce(net.encoder.embeddings.grad)
-            flat = torch.cat([p.grad.reshape(-1) for p in small])
-            dist.all_reduce(flat)
-            o = 0
-            for p in small:
-                p.grad.copy_(flat[o:o + p.numel()].view_as(p))
-                o += p.numel()
-        opt.step(1.0 / world)
         return out
 
-    return step
+    def opt_step():
+        opt.step(grad_scale=1.0 / world)
+
+    def step():
+        out = fwd_bwd()
+        sync.allreduce()                 # no-op at world size 1
+        opt_step()
+        return out
+
+    return step, fwd_bwd, opt_step, sync.allreduce
 
 
 class KernelTimer:
@@ -238,8 +219,9 @@ def main():
     from src.latent_nerf.raymarching import backend as B
     B.get_lib()  # no fallback: raise here if the HIP library is missing
     net, pose, intr, bg, grad = build(dev, args.precision, args.gather_variant, rank)
-    opt = AdamState(net, LR)
-    step = make_step(net, pose, intr, bg, grad, opt, world)
+    from src.latent_nerf.training.optimizer import FusedAdam
+    opt = FusedAdam(net.get_params(LR), betas=(0.9, 0.99), eps=1e-15, encoder=net.encoder, capturable=True)
+    step, fwd_bwd, opt_step, sync = make_step(net, pose, intr, bg, grad, opt, world)
 
     def barrier():
         if world > 1:
@@ -247,19 +229,36 @@ def main():
         torch.cuda.synchronize()
 
     log("model built on %s (rank %d/%d)" % (dev, rank, world))
-    for _ in range(args.warmup):
-        step()
+    launch = "eager"
+    gstep = None
+    if args.graph:
+        from src.latent_nerf.training.graph_step import GraphedTrainStep
+        try:
+            gstep = GraphedTrainStep(fwd_bwd, opt_step, list(net.parameters()), sync=sync, world=world, warmup=3)
+            launch = "hipgraph"
+        except Exception as e:  # launch mechanism only: the kernels and the maths are identical either way
+            log("hipGraph capture failed (%s: %s); running eager launches" % (type(e).__name__, e))
+            torch.cuda.synchronize()
+            gstep = None
+    for i in range(args.warmup):
+        (gstep if (gstep is not None and i % 2) else step)()
     torch.cuda.synchronize()
-    log("warm-up done")
+    log("warm-up done (%s)" % launch)
     timer = KernelTimer(["lnerf_grid_encode_forward", "lnerf_grid_encode_backward"])
-    B.set_profile_hook(timer.hook)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    n_probe = 0
+    for i in range(args.steps):
+        if gstep is None or (i % args.probe_every) == args.probe_every - 1:
+            B.set_profile_hook(timer.hook)   # eager step: the gather is bracketed by HIP events on its stream
+            out = step()
+            B.set_profile_hook(None)
+            n_probe += 1
+        else:
+            out = gstep()
+    host_enqueue = time.perf_counter() - t0   # host time to enqueue the steps (GPU runs behind)
     barrier()
     elapsed = time.perf_counter() - t0
-    B.set_profile_hook(None)
     M = int(out["counter"][0].item())
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
@@ -272,7 +271,7 @@ def main():
     if args.breakdown and rank == 0:
         names = ["lnerf_get_rays", "lnerf_near_far_from_aabb", "lnerf_march_rays_train", "lnerf_grid_encode_forward",
                  "lnerf_mlp_forward", "lnerf_composite_rays_train_forward", "lnerf_composite_rays_train_backward",
-                 "lnerf_mlp_backward", "lnerf_grid_encode_backward", "lnerf_adam_step"]
+                 "lnerf_mlp_backward", "lnerf_grid_encode_backward", "lnerf_adam_step", "lnerf_adam_step_multi"]
         bt = KernelTimer(names)
         B.set_profile_hook(bt.hook)
         for _ in range(20):
@@ -302,6 +301,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
+            "launch": launch, "eager_probe_steps": n_probe,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

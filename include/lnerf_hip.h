@@ -187,7 +187,17 @@ int lnerf_bg_backward(const float *dirs, int64_t N, const float *w1, const float
  * zero_grad != 0 the gradient is cleared in the same pass; if shadow_bf16 != NULL the bf16
  * copy read by the gather is refreshed in the same pass. */
 int lnerf_adam_step(float *p, float *g, float *m, float *v, void *shadow_bf16, int64_t n, float lr, float beta1,
-                    float beta2, float eps, int step, float grad_scale, int zero_grad, lnerf_stream_t stream);
+                    float beta2, float eps, int step, const int32_t *step_dev, float grad_scale, int zero_grad,
+                    lnerf_stream_t stream);
+/* `step_dev` (may be NULL): device-side step counter read by the kernels instead of the host `step`, so a
+ * captured hipGraph of the whole optimisation step can be replayed; lnerf_adam_tick() increments it. */
+int lnerf_adam_tick(int32_t *step_dev, lnerf_stream_t stream);
+/* The same update for up to 16 small tensors in ONE launch (MLP / background parameters).  The pointer
+ * and size arrays are HOST arrays of `count` entries holding device pointers. */
+int lnerf_adam_step_multi(int count, float *const *p_host, float *const *g_host, float *const *m_host,
+                          float *const *v_host, const int64_t *n_host, const float *lr_host, float beta1, float beta2,
+                          float eps, int step, const int32_t *step_dev, float grad_scale, int zero_grad,
+                          lnerf_stream_t stream);
 int lnerf_cast_f32_to_bf16(const float *src, void *dst, int64_t n, lnerf_stream_t stream);
 
 #ifdef __cplusplus

@@ -66,29 +66,45 @@ __device__ __forceinline__ int mbcnt(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
 
-// inclusive wave scan (sum) over 64 lanes
+// ---- cross-lane data movement through DPP (data-parallel primitives): no LDS crossbar traffic.
+// ctrl: 0x110+n row_shr:n (inside a 16-lane row), 0x138 wave_shr:1, 0x142 row_bcast:15, 0x143 row_bcast:31
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int old, int v) {
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, true);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+// value of lane-1 (lane 0 gets `fill`)
+__device__ __forceinline__ int lane_prev_i(int v, int fill) {
+    return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);
+}
+
+// inclusive wave scan (sum) over 64 lanes: 4 row_shr steps inside each 16-lane row, then the row
+// totals are carried across rows with row_bcast:15 (rows 1,3) and row_bcast:31 (rows 2,3)
 __device__ __forceinline__ float wave_inclusive_sum(float v) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        float o = __shfl_up(v, d, 64);
-        if (lane >= d) v += o;
-    }
+    v += dpp_f<0x111, 0xf>(v);
+    v += dpp_f<0x112, 0xf>(v);
+    v += dpp_f<0x114, 0xf>(v);
+    v += dpp_f<0x118, 0xf>(v);
+    v += dpp_f<0x142, 0xa>(v);
+    v += dpp_f<0x143, 0xc>(v);
     return v;
 }
 __device__ __forceinline__ int wave_inclusive_sum_i(int v) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int o = __shfl_up(v, d, 64);
-        if (lane >= d) v += o;
-    }
+    v += dpp_i<0x111, 0xf>(0, v);
+    v += dpp_i<0x112, 0xf>(0, v);
+    v += dpp_i<0x114, 0xf>(0, v);
+    v += dpp_i<0x118, 0xf>(0, v);
+    v += dpp_i<0x142, 0xa>(0, v);
+    v += dpp_i<0x143, 0xc>(0, v);
     return v;
 }
+// sum over the wave, returned in every lane
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+    v = wave_inclusive_sum(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }

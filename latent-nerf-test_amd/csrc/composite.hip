@@ -41,7 +41,7 @@ k_composite_train_fwd(const float *__restrict__ sigmas, const float *__restrict_
 #pragma unroll
             for (int c = 0; c < C; ++c) a_c[c] = fmaf(w, rgbs[s * C + c], a_c[c]);
         }
-        carry += __shfl(inc, 63, 64);
+        carry += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inc), 63));
         if (expf(-carry) < T_thresh) break;  // every later sample starts below the threshold
     }
     a_ws = wave_sum(a_ws);
@@ -131,8 +131,8 @@ k_composite_train_bwd(const float *__restrict__ g_ws, const float *__restrict__ 
 #pragma unroll
             for (int c = 0; c < C; ++c) d_rgbs[s * C + c] = di[c] * w;
         }
-        carry_tau += __shfl(inc, 63, 64);
-        carry_p = __shfl(pinc, 63, 64);
+        carry_tau += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inc), 63));
+        carry_p = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pinc), 63));
         if (expf(-carry_tau) < T_thresh) stopped = true;
     }
 }

@@ -204,24 +204,29 @@ struct BucketMeta {
     long long rstart[LNERF_MAX_LEVELS];  // first record slot of the level's region
 };
 
-// Sum runs of equal keys across the wavefront (lanes = consecutive samples of a ray: on coarse levels
-// they sit in the same cell, so the same vertex appears in long runs).  After the call, the LAST lane
-// of every run holds the run's sums and returns true; the other lanes return false.
-__device__ __forceinline__ bool wave_run_reduce(uint32_t key, bool valid, float &a0, float &a1) {
+// Runs of samples that sit in the same grid cell (lanes = consecutive samples of a ray: on coarse
+// levels long runs share all 8 vertices).  `start` = first lane of this lane's run, `tail` = this lane is
+// the last lane of its run.  Computed once per (wave, level) from the cell coordinates.
+struct RunInfo {
+    int start;
+    bool tail;
+};
+__device__ __forceinline__ RunInfo wave_cell_runs(uint32_t gx, uint32_t gy, uint32_t gz, bool valid) {
     const int lane = lane_id();
-    const uint32_t prev = __shfl_up(key, 1, 64);
-    const int pvalid = __shfl_up((int)valid, 1, 64);
-    int f = (lane == 0) || (prev != key) || !valid || !pvalid;  // run head
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const float t0 = __shfl_up(a0, d, 64), t1 = __shfl_up(a1, d, 64);
-        const int tf = __shfl_up(f, d, 64);
-        if (lane >= d && !f) { a0 += t0; a1 += t1; f = tf; }
-    }
-    const uint32_t next = __shfl_down(key, 1, 64);
-    const int nvalid = __shfl_down((int)valid, 1, 64);
-    const bool tail = (lane == 63) || (next != key) || !nvalid;
-    return valid && tail;
+    const int px = lane_prev_i((int)gx, -1), py = lane_prev_i((int)gy, -1), pz = lane_prev_i((int)gz, -1);
+    const int pv = lane_prev_i((int)valid, 0);
+    const bool head = (lane == 0) || px != (int)gx || py != (int)gy || pz != (int)gz || !valid || !pv;
+    const unsigned long long H = __ballot(head);  // bit 0 is always set
+    RunInfo r;
+    r.start = 63 - __clzll((long long)(H & (~0ull >> (63 - lane))));
+    r.tail = (lane == 63) || ((H >> (lane + 1)) & 1ull);
+    return r;
+}
+// sum of v over this lane's run, valid on the run's tail lane: difference of wave prefix sums
+__device__ __forceinline__ float run_sum(float v, const RunInfo &r) {
+    const float P = wave_inclusive_sum(v);
+    const float Pm = __int_as_float(__builtin_amdgcn_ds_bpermute((r.start - 1) << 2, __float_as_int(P)));
+    return r.start > 0 ? P - Pm : P;
 }
 
 template <typename TG>
@@ -277,9 +282,17 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
                 const float w = (wx * wy) * wz;
                 v0[c] = w * gg.x;
                 v1[c] = w * gg.y;
-                bool e = valid;
-                if (compact) e = wave_run_reduce(row[c], valid, v0[c], v1[c]);
-                emit |= (e ? 1u : 0u) << c;
+            }
+            if (compact) {  // wave-uniform branch
+                const RunInfo ri = wave_cell_runs(p.gx, p.gy, p.gz, valid);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    v0[c] = run_sum(v0[c], ri);
+                    v1[c] = run_sum(v1[c], ri);
+                }
+                emit = (valid && ri.tail) ? 0xFFu : 0u;
+            } else {
+                emit = valid ? 0xFFu : 0u;
             }
         }
         // ---- rank every record inside its bucket (tile-local)
@@ -291,12 +304,12 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
             if (few_buckets) {  // all lanes of a wave mostly target one or two buckets
                 unsigned long long todo = __ballot(e);
                 while (todo) {
-                    const int leader = __ffsll((long long)todo) - 1;
-                    const int bl = __shfl(b, leader, 64);
+                    const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+                    const int bl = __builtin_amdgcn_readlane(b, leader);
                     const unsigned long long mm = __ballot(e && b == bl);
                     int base = 0;
                     if (lane == leader) base = atomicAdd(&s_cnt[bl], __popcll(mm));
-                    base = __shfl(base, leader, 64);
+                    base = __builtin_amdgcn_readlane(base, leader);
                     if (e && b == bl) rank[c] = base + mbcnt(mm);
                     todo &= ~mm;
                 }

@@ -8,7 +8,17 @@ namespace lnerf {
 struct AdamArgs {
     float lr, beta1, beta2, eps, bc1, bc2, grad_scale;
     int zero_grad;
+    const int32_t *step_dev;  // optional device-side step counter (hipGraph replays): overrides bc1/bc2
 };
+
+// bias corrections from the device step counter (same value in every thread; a handful of SALU/VALU ops)
+__device__ __forceinline__ void adam_bias(AdamArgs &a) {
+    if (a.step_dev) {
+        const float t = (float)(*a.step_dev);
+        a.bc1 = 1.0f - powf(a.beta1, t);
+        a.bc2 = 1.0f - powf(a.beta2, t);
+    }
+}
 
 __device__ __forceinline__ void adam_one(float &p, float &g, float &m, float &v, const AdamArgs &a) {
     const float gs = g * a.grad_scale;
@@ -23,6 +33,7 @@ __device__ __forceinline__ void adam_one(float &p, float &g, float &m, float &v,
 __global__ void __launch_bounds__(256)
 k_adam(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
        uint16_t *__restrict__ shadow, int64_t n, AdamArgs a) {
+    adam_bias(a);
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         float4 P = reinterpret_cast<float4 *>(p)[i], G = reinterpret_cast<float4 *>(g)[i];
@@ -53,6 +64,29 @@ k_adam(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, floa
     }
 }
 
+// Many small tensors in one launch (blockIdx.y = tensor): the MLP / background parameters.
+constexpr int ADAM_MULTI_MAX = 16;
+struct AdamMulti {
+    float *p[ADAM_MULTI_MAX], *g[ADAM_MULTI_MAX], *m[ADAM_MULTI_MAX], *v[ADAM_MULTI_MAX];
+    int64_t n[ADAM_MULTI_MAX];
+    float lr[ADAM_MULTI_MAX];
+};
+__global__ void __launch_bounds__(256) k_adam_multi(AdamMulti t, AdamArgs a) {
+    adam_bias(a);
+    const int k = blockIdx.y;
+    a.lr = t.lr[k];
+    float *p = t.p[k], *g = t.g[k], *m = t.m[k], *v = t.v[k];
+    const int64_t n = t.n[k];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float P = p[i], G = g[i], Mv = m[i], V = v[i];
+        adam_one(P, G, Mv, V, a);
+        p[i] = P; m[i] = Mv; v[i] = V;
+        if (a.zero_grad) g[i] = G;
+    }
+}
+
+__global__ void k_adam_tick(int32_t *step_dev) { *step_dev += 1; }
+
 __global__ void __launch_bounds__(256) k_cast_bf16(const float *__restrict__ src, uint16_t *__restrict__ dst, int64_t n) {
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -72,10 +106,18 @@ using namespace lnerf;
 
 extern "C" {
 
+int lnerf_adam_tick(int32_t *step_dev, lnerf_stream_t stream) {
+    LNERF_REQUIRE(step_dev, "adam_tick: null counter");
+    hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, as_stream(stream), step_dev);
+    LNERF_CHECK_LAUNCH("adam_tick");
+    return LNERF_OK;
+}
+
 int lnerf_adam_step(float *p, float *g, float *m, float *v, void *shadow_bf16, int64_t n, float lr, float beta1,
-                    float beta2, float eps, int step, float grad_scale, int zero_grad, lnerf_stream_t stream) {
+                    float beta2, float eps, int step, const int32_t *step_dev, float grad_scale, int zero_grad,
+                    lnerf_stream_t stream) {
     LNERF_REQUIRE(n >= 0, "adam_step: negative n");
-    LNERF_REQUIRE(step >= 1, "adam_step: step must be >= 1 (got %d)", step);
+    LNERF_REQUIRE(step_dev || step >= 1, "adam_step: step must be >= 1 (got %d)", step);
     LNERF_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "adam_step: betas must be in [0,1)");
     if (n == 0) return LNERF_OK;
     LNERF_REQUIRE(p && g && m && v, "adam_step: null pointer");
@@ -84,16 +126,49 @@ int lnerf_adam_step(float *p, float *g, float *m, float *v, void *shadow_bf16, i
     LNERF_REQUIRE(!shadow_bf16 || ((uintptr_t)shadow_bf16 & 7) == 0, "adam_step: shadow must be 8-byte aligned");
     AdamArgs a;
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
-    a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
-    a.bc2 = (float)(1.0 - pow((double)beta2, (double)step));
+    a.bc1 = (float)(1.0 - pow((double)beta1, (double)(step < 1 ? 1 : step)));
+    a.bc2 = (float)(1.0 - pow((double)beta2, (double)(step < 1 ? 1 : step)));
     a.grad_scale = grad_scale;
     a.zero_grad = zero_grad;
+    a.step_dev = step_dev;
     int64_t blocks = div_up(div_up(n, 4), 256);
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, g, m, v,
                        (uint16_t *)shadow_bf16, n, a);
     LNERF_CHECK_LAUNCH("adam_step");
+    return LNERF_OK;
+}
+
+int lnerf_adam_step_multi(int count, float *const *p_host, float *const *g_host, float *const *m_host,
+                          float *const *v_host, const int64_t *n_host, const float *lr_host, float beta1, float beta2,
+                          float eps, int step, const int32_t *step_dev, float grad_scale, int zero_grad,
+                          lnerf_stream_t stream) {
+    LNERF_REQUIRE(count >= 0 && count <= ADAM_MULTI_MAX, "adam_step_multi: count must be in [0,%d]", ADAM_MULTI_MAX);
+    LNERF_REQUIRE(step_dev || step >= 1, "adam_step_multi: step must be >= 1 (got %d)", step);
+    if (count == 0) return LNERF_OK;
+    LNERF_REQUIRE(p_host && g_host && m_host && v_host && n_host && lr_host, "adam_step_multi: null array");
+    AdamMulti t;
+    int64_t nmax = 0;
+    for (int k = 0; k < count; ++k) {
+        LNERF_REQUIRE(p_host[k] && g_host[k] && m_host[k] && v_host[k] && n_host[k] >= 0,
+                      "adam_step_multi: bad tensor %d", k);
+        t.p[k] = p_host[k]; t.g[k] = g_host[k]; t.m[k] = m_host[k]; t.v[k] = v_host[k];
+        t.n[k] = n_host[k]; t.lr[k] = lr_host[k];
+        nmax = n_host[k] > nmax ? n_host[k] : nmax;
+    }
+    AdamArgs a;
+    a.lr = 0.f; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+    a.bc1 = (float)(1.0 - pow((double)beta1, (double)(step < 1 ? 1 : step)));
+    a.bc2 = (float)(1.0 - pow((double)beta2, (double)(step < 1 ? 1 : step)));
+    a.grad_scale = grad_scale;
+    a.zero_grad = zero_grad;
+    a.step_dev = step_dev;
+    int64_t bx = div_up(nmax, 256);
+    if (bx < 1) bx = 1;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(k_adam_multi, dim3((unsigned)bx, (unsigned)count), dim3(256), 0, as_stream(stream), t, a);
+    LNERF_CHECK_LAUNCH("adam_step_multi");
     return LNERF_OK;
 }
 

@@ -1,0 +1,56 @@
+"""Whole-step hipGraph capture: render -> backward -> (gradient sync) -> optimiser as one replayable
+graph, so the host cost of a step is one graph launch instead of ~40 Python/ctypes/autograd calls.
+
+Every C-ABI entry point only enqueues work on the current stream and never synchronises or allocates
+(include/lnerf_hip.h), data-dependent sizes stay on the device, and the optimiser keeps its step counter
+on the device (`FusedAdam(capturable=True)`), so the step is capturable as is.  With more than one rank
+the RCCL all-reduce stays OUTSIDE the graphs (graph A: render + backward, eager collectives on the
+static gradient tensors, graph B: optimiser): collectives are then launched exactly as in eager mode."""
+import torch
+
+
+class GraphedTrainStep:
+    def __init__(self, fwd_bwd, opt_step, params, sync=None, world=1, warmup=3):
+        """fwd_bwd() -> dict of output tensors (leaves `.grad` set on `params`);
+        opt_step() consumes the gradients; sync() all-reduces `.grad` in place (world > 1)."""
+        self.world = world
+        self.sync = sync
+        self.params = list(params)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                fwd_bwd()
+                if world > 1 and sync is not None:
+                    sync()
+                opt_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph_a = torch.cuda.CUDAGraph()
+        self.graph_b = None
+        if world == 1:
+            with torch.cuda.graph(self.graph_a):
+                self.out = fwd_bwd()
+                self.static_grads = [p.grad for p in self.params]  # graph-pool tensors, rewritten by every replay
+                opt_step()
+        else:
+            with torch.cuda.graph(self.graph_a):
+                self.out = fwd_bwd()
+            self.static_grads = [p.grad for p in self.params]
+            self.graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+                opt_step()
+        for p in self.params:
+            p.grad = None
+
+    def __call__(self):
+        self.graph_a.replay()
+        if self.graph_b is not None:
+            for p, g in zip(self.params, self.static_grads):
+                p.grad = g
+            if self.sync is not None:
+                self.sync()
+            self.graph_b.replay()
+            for p in self.params:
+                p.grad = None
+        return self.out

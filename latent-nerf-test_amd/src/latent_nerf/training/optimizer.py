@@ -1,0 +1,65 @@
+"""Fused HIP Adam for the NeRF parameters (betas/eps of the reference's
+src/latent_paint/training/trainer.py:93-95: Adam(betas=(0.9, 0.99), eps=1e-15)).
+
+Two launches per step whatever the number of tensors: the hash table (16 B/lane streaming pass that also
+refreshes its bf16 shadow) and one multi-tensor launch for every small parameter."""
+import ctypes
+
+import torch
+
+from ..raymarching import backend as _b
+from ..raymarching.raymarching import _p, _stream
+
+
+class FusedAdam:
+    def __init__(self, param_groups, betas=(0.9, 0.99), eps=1e-15, encoder=None, capturable=False):
+        """param_groups: [{'params': [...], 'lr': float}, ...] (as NeRFNetwork.get_params(lr)).
+        encoder: the GridEncoder whose `embeddings` are in the groups (for the bf16 shadow refresh)."""
+        self.betas, self.eps = betas, eps
+        self.encoder = encoder
+        self.step_no = 0
+        # capturable: the step counter lives on the device so that a hipGraph of the whole step can be replayed
+        self.capturable = capturable
+        self.step_dev = None
+        self.big = []    # (param, m, v, lr)
+        self.small = []
+        for group in param_groups:
+            for p in group["params"]:
+                entry = (p, torch.zeros_like(p), torch.zeros_like(p), float(group["lr"]))
+                (self.big if p.numel() >= (1 << 20) else self.small).append(entry)
+        if len(self.small) > 16:
+            raise ValueError("FusedAdam handles at most 16 small tensors per launch")
+        n = len(self.small)
+        self._pp = (ctypes.c_void_p * n)()
+        self._gp = (ctypes.c_void_p * n)()
+        self._mp = (ctypes.c_void_p * n)(*[e[1].data_ptr() for e in self.small])
+        self._vp = (ctypes.c_void_p * n)(*[e[2].data_ptr() for e in self.small])
+        self._n = (ctypes.c_int64 * n)(*[e[0].numel() for e in self.small])
+        self._lr = (ctypes.c_float * n)(*[e[3] for e in self.small])
+        if capturable:
+            dev = (self.big + self.small)[0][0].device
+            self.step_dev = torch.ones(1, device=dev, dtype=torch.int32)  # value used by the NEXT step
+
+    def step(self, grad_scale=1.0, set_to_none=True):
+        self.step_no += 1
+        b1, b2 = self.betas
+        enc = self.encoder
+        for p, m, v, lr in self.big:
+            if p.grad is None:
+                continue
+            shadow = enc.shadow() if (enc is not None and p is enc.embeddings) else None
+            _b.call("lnerf_adam_step", _p(p.data), _p(p.grad), _p(m), _p(v), _p(shadow), p.numel(), lr, b1, b2,
+                    self.eps, self.step_no, _p(self.step_dev), float(grad_scale), 0, _stream())
+        if self.small:
+            for k, (p, m, v, lr) in enumerate(self.small):
+                if p.grad is None:
+                    raise RuntimeError("FusedAdam: parameter %d has no gradient" % k)
+                self._pp[k] = p.data.data_ptr()
+                self._gp[k] = p.grad.data_ptr()
+            _b.call("lnerf_adam_step_multi", len(self.small), self._pp, self._gp, self._mp, self._vp, self._n, self._lr,
+                    b1, b2, self.eps, self.step_no, _p(self.step_dev), float(grad_scale), 0, _stream())
+        if self.step_dev is not None:
+            _b.call("lnerf_adam_tick", _p(self.step_dev), _stream())
+        if set_to_none:
+            for p, *_ in self.big + self.small:
+                p.grad = None

@@ -423,11 +423,34 @@ def test_adam_step_matches_torch(dev):
         ref.grad = g.clone() * 0.5
         opt.step()
         gd = g.to(dev)
-        B.call("lnerf_adam_step", _p(p), _p(gd), _p(m), _p(v), _p(shadow), n, 1e-2, 0.9, 0.99, 1e-15, step, 0.5, 1,
+        B.call("lnerf_adam_step", _p(p), _p(gd), _p(m), _p(v), _p(shadow), n, 1e-2, 0.9, 0.99, 1e-15, step, None, 0.5, 1,
                _stream())
         assert float(gd.abs().max()) == 0.0  # gradient cleared in the same pass
     _close(p, ref, 1e-5, 1e-6, "adam params")
     assert torch.equal(shadow.cpu(), p.cpu().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("capturable", [False, True])
+def test_fused_adam_optimizer_matches_torch(dev, capturable):
+    from src.latent_nerf.training.optimizer import FusedAdam
+    torch.manual_seed(1)
+    shapes = [(1 << 20) + 3, (64, 32), (64,), (5, 64), (5,)]
+    ps = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps]
+    groups = [{"params": [ps[0]], "lr": 1e-2}, {"params": ps[1:], "lr": 1e-3}]
+    opt = FusedAdam(groups, capturable=capturable)
+    topt = torch.optim.Adam([{"params": [ref[0]], "lr": 1e-2}, {"params": ref[1:], "lr": 1e-3}], betas=(0.9, 0.99),
+                            eps=1e-15)
+    for _ in range(3):
+        for p, r in zip(ps, ref):
+            g = torch.randn(r.shape)
+            r.grad = g * 0.25
+            p.grad = g.to(dev)
+        topt.step()
+        opt.step(grad_scale=0.25)
+        assert all(p.grad is None for p in ps)
+    for p, r in zip(ps, ref):
+        _close(p, r, 1e-5, 1e-6, "fused adam")
 
 
 def test_occupancy_helpers(dev):
