@@ -218,6 +218,9 @@ def main():
 
     from src.latent_nerf.raymarching import backend as B
     B.get_lib()  # no fallback: raise here if the HIP library is missing
+    # everything (eager steps, graph capture, replays, collectives) runs on one non-default stream
+    main_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(main_stream)
     net, pose, intr, bg, grad = build(dev, args.precision, args.gather_variant, rank)
     from src.latent_nerf.training.optimizer import FusedAdam
     opt = FusedAdam(net.get_params(LR), betas=(0.9, 0.99), eps=1e-15, encoder=net.encoder, capturable=True)
@@ -234,7 +237,8 @@ def main():
     if args.graph:
         from src.latent_nerf.training.graph_step import GraphedTrainStep
         try:
-            gstep = GraphedTrainStep(fwd_bwd, opt_step, list(net.parameters()), sync=sync, world=world, warmup=3)
+            gstep = GraphedTrainStep(fwd_bwd, opt_step, list(net.parameters()), sync=sync, world=world, warmup=3,
+                                     stream=main_stream)
             launch = "hipgraph"
         except Exception as e:  # launch mechanism only: the kernels and the maths are identical either way
             log("hipGraph capture failed (%s: %s); running eager launches" % (type(e).__name__, e))
@@ -282,6 +286,8 @@ def main():
 
     if rank == 0:
         bytes_per_sample = 588 if args.precision == "bf16" else 1164
+        if n_probe == 0:
+            raise SystemExit("no eager probe step ran inside the timed region (lower --probe-every)")
         g_ms = timer.mean_ms("lnerf_grid_encode_forward")
         s_ms = timer.mean_ms("lnerf_grid_encode_backward")
         achieved = M * bytes_per_sample / (g_ms * 1e-3) / 1e9

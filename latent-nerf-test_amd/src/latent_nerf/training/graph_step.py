@@ -10,35 +10,45 @@ import torch
 
 
 class GraphedTrainStep:
-    def __init__(self, fwd_bwd, opt_step, params, sync=None, world=1, warmup=3):
+    def __init__(self, fwd_bwd, opt_step, params, sync=None, world=1, warmup=3, stream=None):
         """fwd_bwd() -> dict of output tensors (leaves `.grad` set on `params`);
-        opt_step() consumes the gradients; sync() all-reduces `.grad` in place (world > 1)."""
+        opt_step() consumes the gradients; sync() all-reduces `.grad` in place (world > 1).
+
+        Run the whole training loop (eager steps included) on ONE non-default stream and pass it as
+        `stream` (or make it current): autograd pins each parameter's gradient accumulation to the stream
+        it first ran on, and accumulation on the legacy default stream cannot be captured."""
         self.world = world
         self.sync = sync
         self.params = list(params)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        if stream is None:
+            stream = torch.cuda.current_stream()
+            if stream == torch.cuda.default_stream():
+                stream = torch.cuda.Stream()
+        self.stream = stream
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
             for _ in range(warmup):
                 fwd_bwd()
                 if world > 1 and sync is not None:
                     sync()
                 opt_step()
-        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.current_stream().wait_stream(stream)
         torch.cuda.synchronize()
+        for p in self.params:  # gradients must be created inside the capture (graph pool), not accumulated into
+            p.grad = None
         self.graph_a = torch.cuda.CUDAGraph()
         self.graph_b = None
         if world == 1:
-            with torch.cuda.graph(self.graph_a):
+            with torch.cuda.graph(self.graph_a, stream=stream):
                 self.out = fwd_bwd()
                 self.static_grads = [p.grad for p in self.params]  # graph-pool tensors, rewritten by every replay
                 opt_step()
         else:
-            with torch.cuda.graph(self.graph_a):
+            with torch.cuda.graph(self.graph_a, stream=stream):
                 self.out = fwd_bwd()
             self.static_grads = [p.grad for p in self.params]
             self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), stream=stream):
                 opt_step()
         for p in self.params:
             p.grad = None

@@ -205,7 +205,7 @@ def test_uniform_sampler_run_and_occupancy_refresh(dev):
 def test_graphed_step_matches_eager(dev):
     """hipGraph capture of render -> backward (training/graph_step.py): a replay produces the same image
     and the same gradients as the eager launches, and a captured optimiser step advances the device-side
-    step counter."""
+    step counter.  Everything runs on one non-default stream (see GraphedTrainStep)."""
     from src.latent_nerf.training.graph_step import GraphedTrainStep
     from src.latent_nerf.training.optimizer import FusedAdam
     G, HW = 64, 32
@@ -222,28 +222,32 @@ def test_graphed_step_matches_eager(dev):
         out["image"].backward(gradient=g)
         return out
 
-    ref = fwd_bwd()
-    ref_img = ref["image"].detach().clone()
-    ref_grads = [p.grad.detach().clone() for p in plist]
-    for p in plist:
-        p.grad = None
-    gs = GraphedTrainStep(fwd_bwd, lambda: None, plist, world=1, warmup=2)
-    for _ in range(2):
-        out = gs()
     torch.cuda.synchronize()
-    e, s = _err(out["image"], ref_img)
-    assert e <= 1e-5 * max(s, 1.0), ("graph image", e, s)
-    for got, want in zip(gs.static_grads, ref_grads):
-        e, s = _err(got, want)
-        assert e <= 1e-4 * s + 1e-8, ("graph grad", e, s)
-    # with the optimiser inside the graph: parameters move on every replay, the step counter advances
-    opt = FusedAdam(net.get_params(1e-3), encoder=net.encoder, capturable=True)
-    gs2 = GraphedTrainStep(fwd_bwd, lambda: opt.step(), plist, world=1, warmup=1)
-    before = net.w2.detach().clone()
-    c0 = int(opt.step_dev.item())
-    for _ in range(3):
-        gs2()
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        ref = fwd_bwd()
+        ref_img = ref["image"].detach().clone()
+        ref_grads = [p.grad.detach().clone() for p in plist]
+        for p in plist:
+            p.grad = None
+        gs = GraphedTrainStep(fwd_bwd, lambda: None, plist, world=1, warmup=2, stream=stream)
+        for _ in range(2):
+            out = gs()
+        stream.synchronize()
+        e, s = _err(out["image"], ref_img)
+        assert e <= 1e-5 * max(s, 1.0), ("graph image", e, s)
+        for got, want in zip(gs.static_grads, ref_grads):
+            e, s = _err(got, want)
+            assert e <= 1e-4 * s + 1e-8, ("graph grad", e, s)
+        # with the optimiser inside the graph: parameters move on every replay, the step counter advances
+        opt = FusedAdam(net.get_params(1e-3), encoder=net.encoder, capturable=True)
+        gs2 = GraphedTrainStep(fwd_bwd, lambda: opt.step(), plist, world=1, warmup=1, stream=stream)
+        before = net.w2.detach().clone()
+        c0 = int(opt.step_dev.item())
+        for _ in range(3):
+            gs2()
+        stream.synchronize()
+        assert int(opt.step_dev.item()) == c0 + 3
+        assert float((net.w2.detach() - before).abs().max()) > 0
+        assert bool(torch.isfinite(net.encoder.embeddings).all())
     torch.cuda.synchronize()
-    assert int(opt.step_dev.item()) == c0 + 3
-    assert float((net.w2.detach() - before).abs().max()) > 0
-    assert bool(torch.isfinite(net.encoder.embeddings).all())
