@@ -60,7 +60,9 @@ const char *lnerf_build_info(void);
  *   "scatter_compact_max_res": levels with resolution <= value merge per-wavefront runs of equal
  *                              rows before binning (default 512).
  *   "scatter_bin_map":         workgroup->(level,tile) map of the binning pass, 0 = level on
- *                              blockIdx.y (default), 1 = XCD-aware. */
+ *                              blockIdx.y (default), 1 = XCD-aware.
+ *   "scatter_bin_staged":      1 (default) = records grouped per bucket in LDS and written coalesced,
+ *                              0 = every lane stores its own records. */
 int lnerf_set_tuning(const char *key, int value);
 
 /* ---- H1: ray generation (absent upstream: `get_rays` of nerf_utils; camera convention
@@ -140,16 +142,17 @@ int lnerf_mlp_forward(const void *feat, int feat_dtype, int64_t level_stride, co
                       const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, int out_dim,
                       float blob_scale, float blob_std, int64_t m_host, const int32_t *m_dev, float *sigmas,
                       float *rgbs, int precision, lnerf_stream_t stream);
-/* Recomputes the hidden activations.  dfeat is written (level-major, f32); d* parameter
- * gradients are ACCUMULATED (+=) deterministically: per-workgroup partial slabs in `workspace`
- * (lnerf_mlp_backward_workspace_bytes()) followed by one reduction launch. */
+/* Recomputes the hidden activations.  dfeat is written (level-major, f32); the d* parameter gradients
+ * are accumulated (accumulate != 0: +=) or overwritten (accumulate == 0) deterministically:
+ * per-workgroup partial slabs in `workspace` (lnerf_mlp_backward_workspace_bytes()) followed by one
+ * reduction launch that sums them in a fixed order. */
 size_t lnerf_mlp_backward_workspace_bytes(int out_dim);
 int lnerf_mlp_backward(const void *feat, int feat_dtype, int64_t level_stride, const float *xyzs, const float *w1,
                        const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, int out_dim,
                        float blob_scale, float blob_std, int64_t m_host, const int32_t *m_dev, const float *sigmas,
                        const float *dsigmas, const float *drgbs, float *dfeat, float *dw1, float *db1, float *dw2,
-                       float *db2, float *dw3, float *db3, void *workspace, size_t workspace_bytes, int precision,
-                       lnerf_stream_t stream);
+                       float *db2, float *dw3, float *db3, int accumulate, void *workspace, size_t workspace_bytes,
+                       int precision, lnerf_stream_t stream);
 
 /* ---- H8/H9: `raymarching.composite_rays_train_forward/backward`.  One wavefront per ray,
  * log-space prefix scan of sigma*dt across lanes.  C = colour channels (3 or 4).

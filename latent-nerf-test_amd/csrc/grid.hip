@@ -54,9 +54,13 @@ struct LevelPos {
 __device__ __forceinline__ LevelPos level_pos(const float *__restrict__ xyzs, int64_t m, float bound, float scale) {
     // x01 = (x + bound) / (2 bound); pos = x01 * scale + 0.5   (op order = oracle grid_encode)
     const float two_b = 2.0f * bound;
-    float px = (xyzs[m * 3] + bound) / two_b;
-    float py = (xyzs[m * 3 + 1] + bound) / two_b;
-    float pz = (xyzs[m * 3 + 2] + bound) / two_b;
+    float px = xyzs[m * 3] + bound, py = xyzs[m * 3 + 1] + bound, pz = xyzs[m * 3 + 2] + bound;
+    if ((__float_as_uint(two_b) & 0x007FFFFFu) == 0u) {  // power of two (wave-uniform): x / 2^k == x * 2^-k exactly
+        const float r = 1.0f / two_b;
+        px = px * r; py = py * r; pz = pz * r;
+    } else {
+        px = px / two_b; py = py / two_b; pz = pz / two_b;
+    }
     px = px * scale; py = py * scale; pz = pz * scale;
     px = px + 0.5f; py = py + 0.5f; pz = pz + 0.5f;
     const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
@@ -233,7 +237,8 @@ template <typename TG>
 __global__ void __launch_bounds__(BIN_T, 6)
 k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict__ dfeat, GridMeta meta, BucketMeta bm,
               int64_t m_host, const int32_t *__restrict__ m_dev, int64_t level_stride, int32_t *__restrict__ cursor,
-              unsigned int *__restrict__ gmax, Rec *__restrict__ recs, float *__restrict__ dtable, int variant) {
+              unsigned int *__restrict__ gmax, Rec *__restrict__ recs, float *__restrict__ dtable, int variant,
+              int staged) {
     __shared__ int s_cnt[BK_MAX_PER_LEVEL];   // records of this tile per bucket
     __shared__ int s_base[BK_MAX_PER_LEVEL];  // first slot reserved in the bucket's global region
     __shared__ int s_off[BK_MAX_PER_LEVEL];   // first slot of the bucket in the LDS stage
@@ -333,6 +338,30 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
                     atomicMax(&gmax[b0 + i], s_max[i]);
                 }
             }
+        }
+        if (!staged) {  // direct mode: every lane stores its own records as soon as the reservations are known
+#pragma unroll
+            for (int k = 0; k < (BK_MAX_PER_LEVEL + BIN_T - 1) / BIN_T; ++k) {
+                const int i = tid + k * BIN_T;
+                if (i < nb) s_base[i] = my_base[k];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if ((emit >> c) & 1u) {
+                    const int b = (int)(row[c] >> BK_SHIFT);
+                    const int slot = s_base[b] + rank[c];
+                    if (slot < cap) {
+                        Rec r;
+                        r.row = row[c]; r.v0 = v0[c]; r.v1 = v1[c];
+                        lrec[(int64_t)b * cap + slot] = r;
+                    } else {
+                        atomicAdd(lt + (int64_t)row[c] * 2, v0[c]);
+                        atomicAdd(lt + (int64_t)row[c] * 2 + 1, v1[c]);
+                    }
+                }
+            }
+            continue;  // uniform: `staged` is a kernel argument
         }
         if (tid < 64) {  // nb <= 256 -> 4 buckets per lane
             int c4[4], sum = 0;
@@ -466,6 +495,8 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
 static int g_compact_max_res = 512;
 // workgroup -> (level, tile) map of the binning pass: 0 = level on blockIdx.y, 1 = XCD-aware
 static int g_bin_map = 0;
+// 1: group a tile's records by bucket in LDS and copy them out coalesced; 0: every lane stores its own records
+static int g_bin_staged = 1;
 // TIMING-ONLY experiment switch of the reduce pass (non-zero values give wrong sums)
 static int g_reduce_dbg = 0;
 
@@ -584,6 +615,10 @@ int lnerf_set_tuning(const char *key, int value) {
         g_bin_map = value;
         return LNERF_OK;
     }
+    if (strcmp(key, "scatter_bin_staged") == 0) {
+        g_bin_staged = value ? 1 : 0;
+        return LNERF_OK;
+    }
     if (strcmp(key, "scatter_reduce_debug") == 0) {
         g_reduce_dbg = value;
         return LNERF_OK;
@@ -648,7 +683,7 @@ int lnerf_grid_encode_backward(const float *xyzs, float bound, const void *dfeat
     }
     launch_dims(g_bin_map, num_levels, div_up(m_host, BIN_T / 256), grid);  // tiles of BIN_T samples
     hipLaunchKernelGGL((k_scatter_bin<float>), grid, dim3(BIN_T), 0, s, xyzs, bound, (const float *)dfeat, meta, bm,
-                       m_host, m_dev, level_stride, cursor, gmax, rec, dtable, g_bin_map);
+                       m_host, m_dev, level_stride, cursor, gmax, rec, dtable, g_bin_map, g_bin_staged);
     LNERF_CHECK_LAUNCH("grid_encode_backward(bin)");
     hipLaunchKernelGGL(k_scatter_reduce, dim3((unsigned)nwg), dim3(512), 0, s, meta, bm, cursor, gmax, rec, dtable,
                        g_reduce_dbg);

@@ -354,9 +354,9 @@ k_mlp_backward_f32(MlpArgs a, const float *__restrict__ sigmas, const float *__r
 // 64 parameters per workgroup; 4 lane groups each sum every 4th slab (coalesced 256-B reads), then
 // the partials are added in a fixed order: deterministic.
 __global__ void __launch_bounds__(256)
-k_mlp_reduce_slabs(const float *__restrict__ slabs, int n_slabs, int out_dim, float *__restrict__ dw1,
-                   float *__restrict__ db1, float *__restrict__ dw2, float *__restrict__ db2, float *__restrict__ dw3,
-                   float *__restrict__ db3) {
+k_mlp_reduce_slabs(const float *__restrict__ slabs, int n_slabs, int out_dim, int accumulate,
+                   float *__restrict__ dw1, float *__restrict__ db1, float *__restrict__ dw2, float *__restrict__ db2,
+                   float *__restrict__ dw3, float *__restrict__ db3) {
     __shared__ float part[4][64];
     const int pi = threadIdx.x & 63, sg = threadIdx.x >> 6;
     const int p = blockIdx.x * 64 + pi;
@@ -369,12 +369,14 @@ k_mlp_reduce_slabs(const float *__restrict__ slabs, int n_slabs, int out_dim, fl
     __syncthreads();
     if (sg != 0 || p >= SLAB) return;
     s = ((part[0][pi] + part[1][pi]) + part[2][pi]) + part[3][pi];
-    if (p < SL_B1) dw1[p - SL_W1] += s;
-    else if (p < SL_W2) db1[p - SL_B1] += s;
-    else if (p < SL_B2) dw2[p - SL_W2] += s;
-    else if (p < SL_W3) db2[p - SL_B2] += s;
-    else if (p < SL_B3) { if ((p - SL_W3) / HID < out_dim) dw3[p - SL_W3] += s; }
-    else { if (p - SL_B3 < out_dim) db3[p - SL_B3] += s; }
+    float *dst = nullptr;
+    if (p < SL_B1) dst = dw1 + (p - SL_W1);
+    else if (p < SL_W2) dst = db1 + (p - SL_B1);
+    else if (p < SL_B2) dst = dw2 + (p - SL_W2);
+    else if (p < SL_W3) dst = db2 + (p - SL_B2);
+    else if (p < SL_B3) { if ((p - SL_W3) / HID < out_dim) dst = dw3 + (p - SL_W3); }
+    else { if (p - SL_B3 < out_dim) dst = db3 + (p - SL_B3); }
+    if (dst) *dst = accumulate ? *dst + s : s;
 }
 
 static int mlp_common_checks(const char *who, const void *feat, int feat_dtype, int64_t level_stride, const float *xyzs,
@@ -427,8 +429,8 @@ int lnerf_mlp_backward(const void *feat, int feat_dtype, int64_t level_stride, c
                        const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, int out_dim,
                        float blob_scale, float blob_std, int64_t m_host, const int32_t *m_dev, const float *sigmas,
                        const float *dsigmas, const float *drgbs, float *dfeat, float *dw1, float *db1, float *dw2,
-                       float *db2, float *dw3, float *db3, void *workspace, size_t workspace_bytes, int precision,
-                       lnerf_stream_t stream) {
+                       float *db2, float *dw3, float *db3, int accumulate, void *workspace, size_t workspace_bytes,
+                       int precision, lnerf_stream_t stream) {
     int rc = mlp_common_checks("mlp_backward", feat, feat_dtype, level_stride, xyzs, w1, b1, w2, b2, w3, b3, out_dim,
                                blob_std, m_host, precision);
     if (rc) return rc;
@@ -452,7 +454,7 @@ int lnerf_mlp_backward(const void *feat, int feat_dtype, int64_t level_stride, c
         LNERF_CHECK_LAUNCH("mlp_backward");
     }
     hipLaunchKernelGGL(k_mlp_reduce_slabs, dim3((unsigned)div_up(SLAB, 64)), dim3(256), 0, s,
-                       (const float *)workspace, (int)blocks, out_dim, dw1, db1, dw2, db2, dw3, db3);
+                       (const float *)workspace, (int)blocks, out_dim, accumulate, dw1, db1, dw2, db2, dw3, db3);
     LNERF_CHECK_LAUNCH("mlp_backward(reduce)");
     return LNERF_OK;
 }

@@ -238,30 +238,27 @@ __global__ void __launch_bounds__(1024) k_march_scan(int32_t *__restrict__ rays,
         }
         __syncthreads();
     }
+    __syncthreads();
+    // M: all samples when nothing was dropped, else the end of the last kept span
+    __shared__ int best_s;
+    if (tid == 0) best_s = 0;
+    __syncthreads();
+    if (drop_s > 0) {  // uniform
+        int loc = 0;
+        for (int64_t n = tid; n < N; n += 1024) {
+            const int c = rays[n * 3 + 2];
+            if (c > 0) loc = max(loc, rays[n * 3 + 1] + c);  // empty rays carry a meaningless offset
+        }
+        atomicMax(&best_s, loc);
+        __syncthreads();
+    }
     if (tid == 0) {
         const long long total = carry_s;
-        counter[0] = (int32_t)(total > capacity ? capacity : total);
+        counter[0] = drop_s > 0 ? best_s : (int32_t)(total > capacity ? capacity : total);
         counter[1] = live_s;
         counter[2] = drop_s;
         counter[3] = 0;
     }
-}
-
-// M = offset of the first dropped ray when rays were dropped (samples after it are never written)
-__global__ void k_march_fix_total(const int32_t *__restrict__ rays, int64_t N, int32_t *__restrict__ counter) {
-    // only needed when counter[2] > 0: recompute M as max(offset+count) over kept rays
-    if (counter[2] == 0) return;
-    __shared__ int best;
-    if (threadIdx.x == 0) best = 0;
-    __syncthreads();
-    int loc = 0;
-    for (int64_t n = threadIdx.x; n < N; n += blockDim.x) {
-        const int c = rays[n * 3 + 2];
-        if (c > 0) loc = max(loc, rays[n * 3 + 1] + c);  // empty rays carry a meaningless offset
-    }
-    atomicMax(&best, loc);
-    __syncthreads();
-    if (threadIdx.x == 0) counter[0] = best;
 }
 
 // ------------------------------------------------------------------ H4 inference
@@ -533,8 +530,6 @@ int lnerf_march_rays_train(const float *rays_o, const float *rays_d, const float
     LNERF_CHECK_LAUNCH("march_rays_train(count)");
     hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, s, rays, N, capacity, counter);
     LNERF_CHECK_LAUNCH("march_rays_train(scan)");
-    hipLaunchKernelGGL(k_march_fix_total, dim3(1), dim3(1024), 0, s, rays, N, counter);
-    LNERF_CHECK_LAUNCH("march_rays_train(fix)");
     if (dt_gamma == 0.f)
         hipLaunchKernelGGL((k_march_train<true, true>), grid, block, 0, s, rays_o, rays_d, nears, fars, N, bitfield, P,
                            noises, xyzs, dirs, deltas, rays);

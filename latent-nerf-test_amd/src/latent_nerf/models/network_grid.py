@@ -42,7 +42,7 @@ class _SigmaLatentMLP(torch.autograd.Function):
         dsigmas = torch.zeros_like(sigmas) if dsigmas is None else dsigmas.contiguous()
         drgbs = torch.zeros(level_stride, out_dim - 1, device=dev) if drgbs is None else drgbs.contiguous()
         dfeat = torch.empty(feat.shape, device=dev, dtype=torch.float32)
-        grads = [torch.zeros_like(t) for t in (w1, b1, w2, b2, w3, b3)]
+        grads = [torch.empty_like(t) for t in (w1, b1, w2, b2, w3, b3)]  # overwritten (accumulate = 0)
         need = _b.get_lib().lnerf_mlp_backward_workspace_bytes(out_dim)
         if workspace is None or workspace.numel() < need:
             workspace = torch.empty(need, device=dev, dtype=torch.uint8)
@@ -50,7 +50,7 @@ class _SigmaLatentMLP(torch.autograd.Function):
         _b.call("lnerf_mlp_backward", _p(feat), fdt, int(level_stride), _p(xyzs), _p(w1), _p(b1), _p(w2), _p(b2),
                 _p(w3), _p(b3), out_dim, float(blob_scale), float(blob_std), int(m_host),
                 _p(m_dev) if has_mdev else None, _p(sigmas), _chk(dsigmas, "dsigmas"), _chk(drgbs, "drgbs"),
-                _p(dfeat), *[_p(g) for g in grads], _p(workspace), workspace.numel(), precision, _stream())
+                _p(dfeat), *[_p(g) for g in grads], 0, _p(workspace), workspace.numel(), precision, _stream())
         return (dfeat, None, *grads, None, None, None, None, None, None, None)
 
 
@@ -96,14 +96,14 @@ class _HashMLPField(torch.autograd.Function):
         dsigmas = torch.zeros_like(sigmas) if dsigmas is None else dsigmas.contiguous()
         drgbs = torch.zeros(level_stride, out_dim - 1, device=dev) if drgbs is None else drgbs.contiguous()
         dfeat = torch.empty(feat.shape, device=dev, dtype=torch.float32)
-        grads = [torch.zeros_like(t) for t in (w1, b1, w2, b2, w3, b3)]
+        grads = [torch.empty_like(t) for t in (w1, b1, w2, b2, w3, b3)]  # overwritten (accumulate = 0)
         need = _b.get_lib().lnerf_mlp_backward_workspace_bytes(out_dim)
         if workspace is None or workspace.numel() < need:
             workspace = torch.empty(need, device=dev, dtype=torch.uint8)
         fdt = _b.F32 if feat.dtype == torch.float32 else _b.BF16
         _b.call("lnerf_mlp_backward", _p(feat), fdt, int(level_stride), _p(xyzs), _p(w1), _p(b1), _p(w2), _p(b2),
                 _p(w3), _p(b3), out_dim, float(blob_scale), float(blob_std), int(m_host), _p(m_dev), _p(sigmas),
-                _chk(dsigmas, "dsigmas"), _chk(drgbs, "drgbs"), _p(dfeat), *[_p(g) for g in grads], _p(workspace),
+                _chk(dsigmas, "dsigmas"), _chk(drgbs, "drgbs"), _p(dfeat), *[_p(g) for g in grads], 0, _p(workspace),
                 workspace.numel(), precision, _stream())
         dtable = torch.zeros(tshape, device=dev, dtype=torch.float32)
         E.grid_encode_backward(xyzs, bound, dfeat, encoder.levels, m_host, m_dev, level_stride, dtable,

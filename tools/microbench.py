@@ -76,13 +76,13 @@ def main():
         dfeat = torch.randn(16, cap, 2, device=dev)
         dtable = torch.zeros_like(table)
         fns = {}
-        for cmr in (128, 512, 1024, 4096):
-            def f(c=cmr):
-                B.call("lnerf_set_tuning", b"scatter_compact_max_res", c)
+        for st in (1, 0):
+            def f(c=st):
+                B.call("lnerf_set_tuning", b"scatter_bin_staged", c)
                 E.grid_encode_backward(xyzs, 1.0, dfeat, levels, cap, m_dev, cap, dtable, variant=2)
-            fns["bucketed_compact%d" % cmr] = f
+            fns["bucketed_staged%d" % st] = f
         t = timed(fns, rounds=10)
-        B.call("lnerf_set_tuning", b"scatter_compact_max_res", 512)
+        B.call("lnerf_set_tuning", b"scatter_bin_staged", 1)
         res["scatter_ms(median,min)"] = t
 
     if "scatter_levels" in which:
