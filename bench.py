@@ -292,11 +292,12 @@ def main():
         s_ms = timer.mean_ms("lnerf_grid_encode_backward")
         achieved = M * bytes_per_sample / (g_ms * 1e-3) / 1e9
         scatter = M * 1164 / (s_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = None   # HBM-side bytes per launch of the gather from the committed PMC passes (profiles/)
         pmc = os.path.join(ROOT, "profiles", "pmc_gather_latest.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                key = "bf16_table_bf16_out" if args.precision == "bf16" else "f32_table_f32_out"
+                traffic = json.load(open(pmc))["variants"][key].get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         res = {

@@ -52,7 +52,7 @@ _SIGNATURES = {
     "lnerf_mlp_forward": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _L, _P, _P, _P, _I, _P],
     "lnerf_mlp_backward_workspace_bytes": [_I],
     "lnerf_mlp_backward": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _L, _P, _P, _P, _P, _P, _P, _P, _P,
-                           _P, _P, _I, _P, _Z, _I, _P],
+                           _P, _P, _P, _I, _P, _Z, _I, _P],
     "lnerf_composite_rays_train_forward": [_P, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P, _P],
     "lnerf_composite_rays_train_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P],
     "lnerf_occ_cell_points": [_P, _L, _I, _I, _F, _P, _P, _P],

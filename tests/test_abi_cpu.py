@@ -62,3 +62,36 @@ def test_ops_refuse_cpu_tensors(built_lib):
     from src.latent_nerf.raymarching import raymarching as rm
     with pytest.raises(ValueError, match="no CPU path"):
         rm.near_far_from_aabb(torch.zeros(4, 3), torch.ones(4, 3), [-1, -1, -1, 1, 1, 1], 0.1)
+
+
+def test_ctypes_signatures_match_header():
+    """Every argtypes list of the host side agrees with the C declaration in include/lnerf_hip.h
+    (count and kind of every parameter), so a drifted binding fails here, on the CPU."""
+    import ctypes as C
+    text = open(B.HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    kinds = {C.c_void_p: "ptr", C.c_char_p: "ptr", C.c_int: "int", C.c_int64: "int64", C.c_float: "float",
+             C.c_size_t: "size_t"}
+    n = 0
+    for m in re.finditer(r"\b(lnerf_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+        name, args = m.group(1), " ".join(m.group(2).split())
+        want = []
+        if args not in ("void", ""):
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a or "lnerf_stream_t" in a:
+                    want.append("ptr")
+                elif a.startswith("int64_t"):
+                    want.append("int64")
+                elif a.startswith("size_t"):
+                    want.append("size_t")
+                elif a.startswith("float"):
+                    want.append("float")
+                elif a.startswith("int ") or a.startswith("int32_t"):
+                    want.append("int")
+                else:
+                    raise AssertionError("unparsed parameter %r of %s" % (a, name))
+        got = [kinds[t] for t in B._SIGNATURES[name]]
+        assert got == want, (name, got, want)
+        n += 1
+    assert n == len(B._SIGNATURES)
