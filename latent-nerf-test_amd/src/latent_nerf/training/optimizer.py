@@ -63,3 +63,20 @@ class FusedAdam:
         if set_to_none:
             for p, *_ in self.big + self.small:
                 p.grad = None
+
+    # ---- checkpointing (plain tensors only: loadable with torch.load(weights_only=True))
+    def state_dict(self):
+        entries = self.big + self.small
+        return {"step": self.step_no, "exp_avg": [e[1] for e in entries], "exp_avg_sq": [e[2] for e in entries],
+                "lr": [e[3] for e in entries]}
+
+    def load_state_dict(self, state):
+        entries = self.big + self.small
+        if len(state["exp_avg"]) != len(entries):
+            raise ValueError("optimizer state has %d tensors, expected %d" % (len(state["exp_avg"]), len(entries)))
+        self.step_no = int(state["step"])
+        for (p, m, v, lr), sm, sv in zip(entries, state["exp_avg"], state["exp_avg_sq"]):
+            m.copy_(sm)
+            v.copy_(sv)
+        if self.step_dev is not None:
+            self.step_dev.fill_(self.step_no + 1)

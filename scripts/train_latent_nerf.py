@@ -1,0 +1,27 @@
+"""Entry point with the reference's surface (scripts/train_latent_nerf.py:1-17 of the reference):
+
+    python -m scripts.train_latent_nerf --config_path demo_configs/latent_nerf/lego_man.yaml
+    python -m scripts.train_latent_nerf --log.exp_name lego --guide.text "a lego man" --render.nerf_type latent
+
+With pyrallis installed the reference's decorator form works unchanged on these dataclasses; here the same
+two input forms are parsed by src.latent_nerf.configs.train_config.load_config."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "latent-nerf-test_amd"))
+
+from src.latent_nerf.configs.train_config import TrainConfig, load_config  # noqa: E402
+from src.latent_nerf.training.trainer import Trainer  # noqa: E402
+
+
+def main(cfg: TrainConfig):
+    trainer = Trainer(cfg)
+    if cfg.log.eval_only:
+        trainer.full_eval()
+    else:
+        trainer.train()
+
+
+if __name__ == "__main__":
+    main(load_config())
