@@ -185,6 +185,14 @@ int lnerf_bg_forward(const float *dirs, int64_t N, const float *w1, const float 
 int lnerf_bg_backward(const float *dirs, int64_t N, const float *w1, const float *b1, const float *w2, const float *b2,
                       int C, const float *dout, float *dw1, float *db1, float *dw2, float *db2, lnerf_stream_t stream);
 
+/* ---- sketch-shape guidance (the reference names igl's winding number, README.md:119-122).
+ * triangles [F, 3, 3] f32 (vertex positions), points [n,3].  Brute force with LDS-tiled triangles; meant for a
+ * one-off evaluation on a dense grid. */
+int lnerf_mesh_winding_number(const float *points, int64_t n, const float *triangles, int n_faces, float *out,
+                              lnerf_stream_t stream);
+int lnerf_mesh_distance(const float *points, int64_t n, const float *triangles, int n_faces, float *out,
+                        lnerf_stream_t stream);
+
 /* ---- optimiser step used by the bench/trainer (Adam, src/latent_paint/training/trainer.py:93-95:
  * betas (0.9, 0.99), eps 1e-15).  g is multiplied by grad_scale (1/world_size) first; if
  * zero_grad != 0 the gradient is cleared in the same pass; if shadow_bf16 != NULL the bf16

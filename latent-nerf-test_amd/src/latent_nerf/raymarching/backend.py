@@ -60,6 +60,8 @@ _SIGNATURES = {
     "lnerf_occ_mean": [_P, _L, _P, _P, _P],
     "lnerf_bg_forward": [_P, _L, _P, _P, _P, _P, _I, _P, _P],
     "lnerf_bg_backward": [_P, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P],
+    "lnerf_mesh_winding_number": [_P, _L, _P, _I, _P, _P],
+    "lnerf_mesh_distance": [_P, _L, _P, _I, _P, _P],
     "lnerf_adam_step": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _P, _F, _I, _P],
     "lnerf_adam_tick": [_P, _P],
     "lnerf_adam_step_multi": [_I, _P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _F, _I, _P],

@@ -51,6 +51,7 @@ class Trainer:
         small = [p for p in self.nerf.parameters() if p is not self.nerf.encoder.embeddings]
         self.grad_sync = D.GradSync([self.nerf.encoder.embeddings], small)
         self.dataloaders = self.init_dataloaders()
+        self.shape_loss = self.init_shape_guidance()
         self.past_checkpoints = []
         if cfg.optim.ckpt is not None:
             self.load_checkpoint(cfg.optim.ckpt, model_only=True)
@@ -72,6 +73,20 @@ class Trainer:
             return SyntheticGuidance(self.device, channels=self.nerf.img_dims, size=self.cfg.render.train_h,
                                      seed=self.cfg.optim.seed)
         return StableDiffusionGuidance(self.device, g.diffusion_name)
+
+    def init_shape_guidance(self):
+        """`guide.shape_path` -> mesh occupancy grids + shape loss (sketch-shape guidance)."""
+        g = self.cfg.guide
+        if not g.shape_path:
+            return None
+        from .shape import MeshOccupancy, ShapeLoss, load_obj, normalize_mesh
+        verts, faces = load_obj(g.shape_path)
+        verts = normalize_mesh(verts, target_scale=g.mesh_scale, dy=0.0)
+        self.mesh_occ = MeshOccupancy(verts, faces, self.device, bound=self.nerf.bound,
+                                      resolution=self.cfg.render.grid_size)
+        self.mesh_occ.init_density_grid(self.nerf)
+        self.log("shape guidance: %d faces from %s" % (faces.shape[0], g.shape_path))
+        return ShapeLoss(self.mesh_occ, proximal_surface=g.proximal_surface)
 
     def calc_text_embeddings(self):
         """One embedding, or six direction-specific ones (src/latent_paint/training/trainer.py:82-91)."""
@@ -103,6 +118,8 @@ class Trainer:
         loss = torch.zeros((), device=self.device)
         if self.cfg.optim.lambda_sparsity > 0:
             loss = loss + self.cfg.optim.lambda_sparsity * sparsity_loss(out["weights_sum"])
+        if self.shape_loss is not None and self.cfg.optim.lambda_shape > 0:
+            loss = loss + self.cfg.optim.lambda_shape * self.shape_loss(out["xyzs"], out["sigmas"], out["counter"])
         # SDS: d(loss)/d(pred) = grad (src/latent_paint_mesh/training/trainer.py:657-658); other terms by autograd
         if loss.requires_grad:
             torch.autograd.backward([pred, loss], [grad, torch.ones_like(loss)])
