@@ -56,6 +56,8 @@ def parse():
                     help="1: replay the captured hipGraph of the whole step (every --probe-every-th timed step still runs "
                          "eagerly so that the gather can be bracketed by HIP events); 0: eager launches only")
     ap.add_argument("--probe-every", type=int, default=8)
+    ap.add_argument("--grad-transport", default="auto", choices=["auto", "f32", "bf16"],
+                    help="dtype of the table-gradient all-reduce at N > 1 (auto: follows --precision)")
     return ap.parse_args()
 
 
@@ -82,12 +84,12 @@ def build(dev, precision, variant, rank):
     return net, pose, intr, bg, grad
 
 
-def make_step(net, pose, intr, bg, grad, opt, world):
+def make_step(net, pose, intr, bg, grad, opt, world, transport=torch.float32):
     """Returns (eager_step, fwd_bwd, opt_step, sync)."""
     from src.latent_nerf.raymarching import raymarching as rm
     from src.latent_nerf.training.distributed import GradSync
     small = [p for p in net.parameters() if p is not net.encoder.embeddings]
-    sync = GradSync([net.encoder.embeddings], small)
+    sync = GradSync([net.encoder.embeddings], small, transport=transport)
 
     def fwd_bwd():
         rays_o, rays_d = rm.get_rays(pose, intr, H, W)
@@ -210,11 +212,18 @@ def main():
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d ...`"
                              % (args.gpus, args.gpus))
     import torch.distributed as dist
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    # one process per GPU; LNERF_DIST_BACKEND=gloo lets several ranks share one card for a functional rehearsal
+    backend = os.environ.get("LNERF_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    local_dev = local if backend == "nccl" else local % max(ndev, 1)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from src.latent_nerf.raymarching import backend as B
     B.get_lib()  # no fallback: raise here if the HIP library is missing
@@ -224,7 +233,9 @@ def main():
     net, pose, intr, bg, grad = build(dev, args.precision, args.gather_variant, rank)
     from src.latent_nerf.training.optimizer import FusedAdam
     opt = FusedAdam(net.get_params(LR), betas=(0.9, 0.99), eps=1e-15, encoder=net.encoder, capturable=True)
-    step, fwd_bwd, opt_step, sync = make_step(net, pose, intr, bg, grad, opt, world)
+    tr = args.precision if args.grad_transport == "auto" else args.grad_transport
+    step, fwd_bwd, opt_step, sync = make_step(net, pose, intr, bg, grad, opt, world,
+                                              torch.bfloat16 if tr == "bf16" else torch.float32)
 
     def barrier():
         if world > 1:
@@ -318,7 +329,7 @@ def main():
             "config": {"workload": "configs[1]: unconstrained latent-NeRF 64x64x4, 128^3 occupancy grid, hash grid "
                                    "L=16 F=2 T=2^19, 1 view/GPU/step, fwd+bwd+grad all-reduce+Adam",
                        "rays_per_view": H * W, "samples_per_view": M, "views_per_step": world,
-                       "parallelism": "dp%d (1 view per GPU, RCCL all-reduce of gradients)" % world},
+                       "parallelism": "dp%d (1 view per GPU, RCCL all-reduce of gradients, %s on the wire)" % (world, tr)},
             "roofline": {"kernel": "k_grid_forward (hash-grid gather, H5)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "bytes_per_sample": bytes_per_sample, "samples_per_launch": M, "kernel_ms": g_ms},

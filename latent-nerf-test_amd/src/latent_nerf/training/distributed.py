@@ -35,17 +35,25 @@ def pose_generator(seed: int, step: int, view_index: int) -> torch.Generator:
 
 class GradSync:
     """Sums gradients across ranks.  `big` tensors (the hash table gradient, 46.7 MiB) are all-reduced
-    in place, each as its own bucket; all `small` parameters travel in ONE flat bucket.
+    each as its own bucket; all `small` parameters travel in ONE flat bucket.
 
     xGMI is point-to-point (7 links per GPU): a few large collectives beat many small ones, hence
-    exactly two collectives per step regardless of the number of parameter tensors."""
+    exactly two collectives per step regardless of the number of parameter tensors.
+
+    transport: torch.float32 (exact sum, default) or torch.bfloat16 for the big buckets -- half the bytes
+    on the links; the sum is then formed in bf16 by the collective (the usual bf16-gradient trade-off of
+    mixed-precision data parallelism).  Small parameters always travel in f32."""
 
     def __init__(self, big: Iterable[torch.nn.Parameter], small: Iterable[torch.nn.Parameter],
-                 group: Optional[dist.ProcessGroup] = None):
+                 group: Optional[dist.ProcessGroup] = None, transport: torch.dtype = torch.float32):
         self.big = list(big)
         self.small = list(small)
         self.group = group
+        if transport not in (torch.float32, torch.bfloat16):
+            raise ValueError("transport must be float32 or bfloat16")
+        self.transport = transport
         self._flat = None
+        self._wire = {}
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
     def _flat_buffer(self):
@@ -54,15 +62,27 @@ class GradSync:
             self._flat = torch.empty(n, device=self.small[0].device, dtype=torch.float32)
         return self._flat
 
+    def _wire_buffer(self, p):
+        buf = self._wire.get(id(p))
+        if buf is None or buf.shape != p.shape or buf.device != p.device:
+            buf = torch.empty(p.shape, device=p.device, dtype=self.transport)
+            self._wire[id(p)] = buf
+        return buf
+
     def allreduce(self):
         """After this call every `.grad` holds the SUM over ranks (scale by 1/world in the optimiser)."""
         if self.world == 1:
             return
-        handles = []
+        pending = []
         for p in self.big:
             if p.grad is None:
                 raise RuntimeError("GradSync: a bucketed parameter has no gradient on this rank")
-            handles.append(dist.all_reduce(p.grad, group=self.group, async_op=True))
+            if self.transport == torch.float32:
+                pending.append((dist.all_reduce(p.grad, group=self.group, async_op=True), None, None))
+            else:
+                wire = self._wire_buffer(p)
+                wire.copy_(p.grad)  # f32 -> bf16 on the device
+                pending.append((dist.all_reduce(wire, group=self.group, async_op=True), wire, p))
         if self.small:
             flat = self._flat_buffer()
             o = 0
@@ -76,5 +96,7 @@ class GradSync:
             for p in self.small:
                 p.grad.copy_(flat[o:o + p.numel()].view_as(p.grad))
                 o += p.numel()
-        for h in handles:
+        for h, wire, p in pending:
             h.wait()
+            if wire is not None:
+                p.grad.copy_(wire)  # bf16 -> f32
