@@ -491,6 +491,8 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
     }
 }
 
+extern int g_mlp_fwd_blocks;  // mlp.hip
+
 // levels up to this resolution merge per-wave runs before binning (tunable: lnerf_set_tuning)
 static int g_compact_max_res = 512;
 // workgroup -> (level, tile) map of the binning pass: 0 = level on blockIdx.y, 1 = XCD-aware
@@ -613,6 +615,11 @@ int lnerf_set_tuning(const char *key, int value) {
     if (strcmp(key, "scatter_bin_map") == 0) {
         LNERF_REQUIRE(value == 0 || value == 1, "set_tuning: scatter_bin_map must be 0 or 1");
         g_bin_map = value;
+        return LNERF_OK;
+    }
+    if (strcmp(key, "mlp_fwd_blocks") == 0) {
+        LNERF_REQUIRE(value >= 1 && value <= 65535, "set_tuning: mlp_fwd_blocks out of range");
+        g_mlp_fwd_blocks = value;
         return LNERF_OK;
     }
     if (strcmp(key, "scatter_bin_staged") == 0) {

@@ -379,6 +379,8 @@ k_mlp_reduce_slabs(const float *__restrict__ slabs, int n_slabs, int out_dim, in
     if (dst) *dst = accumulate ? *dst + s : s;
 }
 
+int g_mlp_fwd_blocks = 512;
+
 static int mlp_common_checks(const char *who, const void *feat, int feat_dtype, int64_t level_stride, const float *xyzs,
                              const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
                              const float *b3, int out_dim, float blob_std, int64_t m_host, int precision) {
@@ -409,8 +411,9 @@ int lnerf_mlp_forward(const void *feat, int feat_dtype, int64_t level_stride, co
     MlpArgs a{feat, feat_dtype == LNERF_BF16, level_stride, xyzs, w1, b1, w2, b2, w3, b3, out_dim, blob_scale,
               2.0f * blob_std * blob_std, m_host, m_dev};
     if (precision == LNERF_BF16) {
+        // persistent workgroups: each builds the weight fragments once and then walks ~M/128/blocks tiles
         int64_t blocks = div_up(m_host, 128);
-        if (blocks > 2048) blocks = 2048;
+        if (blocks > g_mlp_fwd_blocks) blocks = g_mlp_fwd_blocks;
         return launch_mlp_forward_bf16(a, sigmas, rgbs, (int)blocks, as_stream(stream));
     }
     int64_t blocks = div_up(m_host, 64);

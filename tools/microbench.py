@@ -107,11 +107,18 @@ def main():
 
     if "mlp" in which:
         from src.latent_nerf.models.network_grid import _SigmaLatentMLP
-        feat = torch.randn(16, cap, 2, device=dev) * 0.3
-        with torch.no_grad():
-            t = timed({"mlp_fwd_f32": lambda: _SigmaLatentMLP.apply(feat, xyzs, net.w1, net.b1, net.w2, net.b2, net.w3, net.b3,
-                                                                   cap, m_dev, cap, 5.0, 0.2, B.F32, net._mlp_ws)})
-        res["mlp_ms(median,min)"] = t
+        featb = (torch.randn(16, cap, 2, device=dev) * 0.3).to(torch.bfloat16)
+        fns = {}
+        for nb in (256, 512, 1024, 2048, 4096):
+            def f(n=nb):
+                B.call("lnerf_set_tuning", b"mlp_fwd_blocks", n)
+                with torch.no_grad():
+                    _SigmaLatentMLP.apply(featb, xyzs, net.w1, net.b1, net.w2, net.b2, net.w3, net.b3, cap, m_dev, cap,
+                                          5.0, 0.2, B.BF16, net._mlp_ws)
+            fns["mlp_fwd_bf16_blocks%d" % nb] = f
+        res["mlp_ms(median,min)"] = timed(fns)
+        B.call("lnerf_set_tuning", b"mlp_fwd_blocks", 512)
+
     print(json.dumps(res))
 
 
