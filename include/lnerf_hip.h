@@ -194,6 +194,26 @@ int lnerf_mesh_winding_number(const float *points, int64_t n, const float *trian
 int lnerf_mesh_distance(const float *points, int64_t n, const float *triangles, int n_faces, float *out,
                         lnerf_stream_t stream);
 
+/* ---- Latent-Paint raster path (the kaolin calls of src/latent_paint/models/render.py:34-69).
+ * cam_host: 14 host floats = world->camera rotation rows (9), camera position (3), fx, fy (= 1/tan(fov/2)).
+ * prepare_vertices -> face_z [F,3] (camera z), face_xy [F,3,2] (NDC);  rasterize -> face_idx [H*W] (-1 =
+ * background) and perspective-correct barycentrics [H*W,3];  interpolate_attributes: per-face-vertex
+ * attributes [F,3,D] -> [H*W,D] (differentiable w.r.t. the attributes);  texture_map: tex [C,R,R] sampled at
+ * uv [H*W,2] with grid_sample(align_corners=False, padding 'border') semantics on (u, 1-v), mode 0 nearest /
+ * 1 bilinear; pixels with face_idx < 0 give 0.  The backward entry points ACCUMULATE (+=). */
+int lnerf_raster_prepare(const float *verts, int n_verts, const int32_t *faces, int n_faces, const float *cam_host,
+                         float *face_z, float *face_xy, lnerf_stream_t stream);
+int lnerf_rasterize(int H, int W, const float *face_z, const float *face_xy, int n_faces, int32_t *face_idx,
+                    float *bary, lnerf_stream_t stream);
+int lnerf_interpolate_attributes(const int32_t *face_idx, const float *bary, const float *attr, int n_pixels, int D,
+                                 float *feat, lnerf_stream_t stream);
+int lnerf_interpolate_attributes_backward(const int32_t *face_idx, const float *bary, const float *dfeat,
+                                          int n_pixels, int D, float *dattr, lnerf_stream_t stream);
+int lnerf_texture_map_forward(const float *uv, const int32_t *face_idx, const float *texture, int n_pixels, int C,
+                              int R, int mode, float *out, lnerf_stream_t stream);
+int lnerf_texture_map_backward(const float *uv, const int32_t *face_idx, const float *dout, int n_pixels, int C, int R,
+                               int mode, float *dtexture, lnerf_stream_t stream);
+
 /* ---- optimiser step used by the bench/trainer (Adam, src/latent_paint/training/trainer.py:93-95:
  * betas (0.9, 0.99), eps 1e-15).  g is multiplied by grad_scale (1/world_size) first; if
  * zero_grad != 0 the gradient is cleared in the same pass; if shadow_bf16 != NULL the bf16

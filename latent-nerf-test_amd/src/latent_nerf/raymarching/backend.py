@@ -62,6 +62,12 @@ _SIGNATURES = {
     "lnerf_bg_backward": [_P, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P],
     "lnerf_mesh_winding_number": [_P, _L, _P, _I, _P, _P],
     "lnerf_mesh_distance": [_P, _L, _P, _I, _P, _P],
+    "lnerf_raster_prepare": [_P, _I, _P, _I, _P, _P, _P, _P],
+    "lnerf_rasterize": [_I, _I, _P, _P, _I, _P, _P, _P],
+    "lnerf_interpolate_attributes": [_P, _P, _P, _I, _I, _P, _P],
+    "lnerf_interpolate_attributes_backward": [_P, _P, _P, _I, _I, _P, _P],
+    "lnerf_texture_map_forward": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "lnerf_texture_map_backward": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "lnerf_adam_step": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _P, _F, _I, _P],
     "lnerf_adam_tick": [_P, _P],
     "lnerf_adam_step_multi": [_I, _P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _F, _I, _P],
