@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--precision", default=os.environ.get("LNERF_BENCH_PRECISION", "bf16"), choices=["f32", "bf16"],
                     help="bf16 (BASELINE configs[1]): bf16 shadow table + bf16 features + bf16 MFMA MLP, f32 "
                          "master weights/accumulation/compositing; f32: f32 table + exact-f32 MFMA MLP")
+    ap.add_argument("--table", default="auto", choices=["auto", "f32", "bf16"],
+                    help="dtype of the hash table the gather reads (auto: f32; bf16 = half-size shadow refreshed by Adam)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--gather-variant", type=int, default=0)
@@ -61,15 +63,15 @@ def parse():
     return ap.parse_args()
 
 
-def build(dev, precision, variant, rank):
+def build(dev, precision, variant, rank, table="f32"):
     from oracle import nerf_oracle as O  # scene construction only (analytic occupancy), not measured
     from src.latent_nerf.configs.render_config import RenderConfig
     from src.latent_nerf.models.network_grid import NeRFNetwork
     from src.latent_nerf.models.nerf_utils import intrinsics_from_fov, pose_from_angles
 
     torch.manual_seed(0)
-    cfg = RenderConfig(grid_size=GRID, train_h=H, train_w=W, mlp_precision=precision,
-                       table_dtype="bf16" if precision == "bf16" else "f32", gather_variant=variant)
+    cfg = RenderConfig(grid_size=GRID, train_h=H, train_w=W, mlp_precision=precision, table_dtype=table,
+                       gather_variant=variant)
     net = NeRFNetwork(cfg)
     net.encoder.embeddings.data.normal_(0, 0.1)
     net = net.to(dev).train()
@@ -230,7 +232,8 @@ def main():
     # everything (eager steps, graph capture, replays, collectives) runs on one non-default stream
     main_stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(main_stream)
-    net, pose, intr, bg, grad = build(dev, args.precision, args.gather_variant, rank)
+    table = "f32" if args.table == "auto" else args.table
+    net, pose, intr, bg, grad = build(dev, args.precision, args.gather_variant, rank, table)
     from src.latent_nerf.training.optimizer import FusedAdam
     opt = FusedAdam(net.get_params(LR), betas=(0.9, 0.99), eps=1e-15, encoder=net.encoder, capturable=True)
     tr = args.precision if args.grad_transport == "auto" else args.grad_transport
@@ -296,7 +299,9 @@ def main():
         breakdown = {n.replace("lnerf_", ""): round(bt.mean_ms(n) * (len(bt.pairs[n]) / 20.0), 4) for n in names}
 
     if rank == 0:
-        bytes_per_sample = 588 if args.precision == "bf16" else 1164
+        # algorithmic bytes per sample of the gather: 16 levels x 8 vertices x 2 features x
+        # sizeof(table entry) gathered + 12 B position + 16 x 2 x sizeof(feature) written
+        bytes_per_sample = 16 * 8 * 2 * (2 if table == "bf16" else 4) + 12 + 32 * (2 if args.precision == "bf16" else 4)
         if n_probe == 0:
             raise SystemExit("no eager probe step ran inside the timed region (lower --probe-every)")
         g_ms = timer.mean_ms("lnerf_grid_encode_forward")
@@ -307,7 +312,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_gather_latest.json")
         if os.path.exists(pmc):
             try:
-                key = "bf16_table_bf16_out" if args.precision == "bf16" else "f32_table_f32_out"
+                key = "%s_table_%s_out" % (table, args.precision)
                 traffic = json.load(open(pmc))["variants"][key].get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None

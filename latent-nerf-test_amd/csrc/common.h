@@ -101,6 +101,16 @@ __device__ __forceinline__ int wave_inclusive_sum_i(int v) {
     v += dpp_i<0x143, 0xc>(0, v);
     return v;
 }
+// max over the wave of NON-NEGATIVE values (out-of-range DPP reads give 0), returned in every lane
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+    v = fmaxf(v, dpp_f<0x111, 0xf>(v));
+    v = fmaxf(v, dpp_f<0x112, 0xf>(v));
+    v = fmaxf(v, dpp_f<0x114, 0xf>(v));
+    v = fmaxf(v, dpp_f<0x118, 0xf>(v));
+    v = fmaxf(v, dpp_f<0x142, 0xa>(v));
+    v = fmaxf(v, dpp_f<0x143, 0xc>(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 // sum over the wave, returned in every lane
 __device__ __forceinline__ float wave_sum(float v) {
     v = wave_inclusive_sum(v);

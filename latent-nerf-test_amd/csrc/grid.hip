@@ -27,6 +27,33 @@ __device__ __forceinline__ uint32_t grid_index(uint32_t x, uint32_t y, uint32_t 
     return index % hsize;
 }
 
+// rows of the 8 vertices of a cell at once: the two integer multiplies of the spatial hash (quarter-rate
+// VALU) are shared by all corners ((y+1)*P == y*P + P mod 2^32), dense levels add strides to one base
+__device__ __forceinline__ void corner_rows(uint32_t gx, uint32_t gy, uint32_t gz, uint32_t res, uint32_t hsize,
+                                            uint32_t row[8]) {
+    const uint32_t stride = res + 1;
+    const uint64_t cube = (uint64_t)stride * stride * stride;
+    if (cube <= (uint64_t)hsize) {  // wave-uniform
+        const uint32_t s2 = stride * stride;
+        const uint32_t base = gx + gy * stride + gz * s2;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) row[c] = base + (c & 1) + ((c >> 1) & 1) * stride + ((c >> 2) & 1) * s2;
+        return;
+    }
+    const uint32_t hx[2] = {gx, gx + 1u};
+    const uint32_t y0 = gy * 2654435761u, z0 = gz * 805459861u;
+    const uint32_t hy[2] = {y0, y0 + 2654435761u};
+    const uint32_t hz[2] = {z0, z0 + 805459861u};
+    if ((hsize & (hsize - 1u)) == 0u) {
+        const uint32_t mask = hsize - 1u;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) row[c] = (hx[c & 1] ^ hy[(c >> 1) & 1] ^ hz[(c >> 2) & 1]) & mask;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) row[c] = (hx[c & 1] ^ hy[(c >> 1) & 1] ^ hz[(c >> 2) & 1]) % hsize;
+    }
+}
+
 template <typename T> struct Feat2;
 template <> struct Feat2<float> {
     static __device__ __forceinline__ float2 load(const float *base, uint32_t row) {
@@ -117,11 +144,12 @@ k_grid_forward(const float *__restrict__ xyzs, float bound, const TT *__restrict
         // issue the 8 gathers first, blend afterwards (keeps 8 loads in flight per lane)
         float2 v[8];
         float w[8];
+        uint32_t rows[8];
+        corner_rows(p.gx, p.gy, p.gz, res, hsize, rows);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const uint32_t bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
-            const uint32_t row = grid_index(p.gx + bx, p.gy + by, p.gz + bz, res, hsize);
-            v[c] = Feat2<TT>::load(lt, row);
+            v[c] = Feat2<TT>::load(lt, rows[c]);
             const float wx = bx ? p.fx : 1.0f - p.fx;
             const float wy = by ? p.fy : 1.0f - p.fy;
             const float wz = bz ? p.fz : 1.0f - p.fz;
@@ -158,10 +186,12 @@ k_grid_backward_atomic(const float *__restrict__ xyzs, float bound, const TG *__
         if (m >= M) continue;
         const LevelPos p = level_pos(xyzs, m, bound, scale);
         const float2 gg = Feat2<TG>::load(dfeat + ((int64_t)l * level_stride + m) * 2, 0);
+        uint32_t rows[8];
+        corner_rows(p.gx, p.gy, p.gz, res, hsize, rows);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const uint32_t bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
-            const uint32_t row = grid_index(p.gx + bx, p.gy + by, p.gz + bz, res, hsize);
+            const uint32_t row = rows[c];
             const float wx = bx ? p.fx : 1.0f - p.fx;
             const float wy = by ? p.fy : 1.0f - p.fy;
             const float wz = bz ? p.fz : 1.0f - p.fz;
@@ -242,7 +272,9 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
     __shared__ int s_cnt[BK_MAX_PER_LEVEL];   // records of this tile per bucket
     __shared__ int s_base[BK_MAX_PER_LEVEL];  // first slot reserved in the bucket's global region
     __shared__ int s_off[BK_MAX_PER_LEVEL];   // first slot of the bucket in the LDS stage
-    __shared__ unsigned int s_max[BK_MAX_PER_LEVEL];  // bit pattern of the largest |value| per bucket
+    __shared__ unsigned int s_max;            // bit pattern of the tile's largest |value|
+    __shared__ int s_dest[BK_MAX_PER_LEVEL];  // global slot of the bucket's first staged record, minus its stage offset
+    __shared__ int s_ovf;                     // some bucket of this tile ran past its region
     __shared__ Rec s_stage[BIN_T * 8];        // the tile's records, grouped by bucket (48 KiB)
     __shared__ int s_total;
     int64_t M = m_host;
@@ -261,7 +293,8 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
     float *lt = dtable + (int64_t)off * 2;
     const int tid = threadIdx.x, lane = tid & 63;
     for (int64_t tile = tm.tile0; tile * BIN_T < M; tile += tm.tstep) {
-        for (int i = tid; i < nb; i += BIN_T) { s_cnt[i] = 0; s_max[i] = 0u; }
+        for (int i = tid; i < nb; i += BIN_T) s_cnt[i] = 0;
+        if (tid == 0) { s_max = 0u; s_ovf = 0; }
         __syncthreads();
         const int64_t m = tile * BIN_T + tid;
         const bool valid = m < M;
@@ -277,10 +310,10 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
                 p = level_pos(xyzs, m, bound, scale);
                 gg = Feat2<TG>::load(dfeat + ((int64_t)l * level_stride + m) * 2, 0);
             }
+            corner_rows(p.gx, p.gy, p.gz, res, hsize, row);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const uint32_t bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
-                row[c] = grid_index(p.gx + bx, p.gy + by, p.gz + bz, res, hsize);
                 const float wx = bx ? p.fx : 1.0f - p.fx;
                 const float wy = by ? p.fy : 1.0f - p.fy;
                 const float wz = bz ? p.fz : 1.0f - p.fz;
@@ -321,7 +354,14 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
             } else if (e) {
                 rank[c] = atomicAdd(&s_cnt[b], 1);
             }
-            if (e) atomicMax(&s_max[b], __float_as_uint(fmaxf(fabsf(v0[c]), fabsf(v1[c]))));  // +floats order as uints
+        }
+        {   // largest |value| of the tile: per-lane max, DPP wave max, one LDS atomic per wave (+floats order as uints)
+            float mx = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if ((emit >> c) & 1u) mx = fmaxf(mx, fmaxf(fabsf(v0[c]), fabsf(v1[c])));
+            mx = wave_max_nonneg(mx);
+            if (lane == 0 && mx > 0.f) atomicMax(&s_max, __float_as_uint(mx));
         }
         __syncthreads();
         // ---- exclusive scan of the tile's bucket counts (wave 0); the global reservations (one
@@ -333,10 +373,7 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
             my_base[k] = 0;
             if (i < nb) {
                 const int c = s_cnt[i];
-                if (c) {
-                    my_base[k] = atomicAdd(&cursor[b0 + i], c);
-                    atomicMax(&gmax[b0 + i], s_max[i]);
-                }
+                if (c) my_base[k] = atomicAdd(&cursor[b0 + i], c);
             }
         }
         if (!staged) {  // direct mode: every lane stores its own records as soon as the reservations are known
@@ -363,6 +400,7 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
             }
             continue;  // uniform: `staged` is a kernel argument
         }
+        if (tid == BIN_T - 1 && s_max != 0u) atomicMax(&gmax[l], s_max);  // one value per LEVEL
         if (tid < 64) {  // nb <= 256 -> 4 buckets per lane
             int c4[4], sum = 0;
 #pragma unroll
@@ -395,20 +433,31 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
 #pragma unroll
         for (int k = 0; k < (BK_MAX_PER_LEVEL + BIN_T - 1) / BIN_T; ++k) {
             const int i = tid + k * BIN_T;
-            if (i < nb) s_base[i] = my_base[k];
+            if (i < nb) {
+                s_base[i] = my_base[k];
+                s_dest[i] = i * cap + my_base[k] - s_off[i];
+                if (my_base[k] + s_cnt[i] > cap) s_ovf = 1;
+            }
         }
         __syncthreads();
         // ---- copy out: consecutive lanes -> consecutive slots of (mostly) the same bucket: coalesced
         const int total = s_total;
-        for (int i = tid; i < total; i += BIN_T) {
-            const Rec r = s_stage[i];
-            const int b = (int)(r.row >> BK_SHIFT);
-            const int slot = s_base[b] + (i - s_off[b]);
-            if (slot < cap) {
-                lrec[(int64_t)b * cap + slot] = r;
-            } else {  // bucket region full: finish this record with global atomics
-                atomicAdd(lt + (int64_t)r.row * 2, r.v0);
-                atomicAdd(lt + (int64_t)r.row * 2 + 1, r.v1);
+        if (!s_ovf) {  // uniform fast path: every record of the tile has a slot
+            for (int i = tid; i < total; i += BIN_T) {
+                const Rec r = s_stage[i];
+                lrec[s_dest[r.row >> BK_SHIFT] + i] = r;
+            }
+        } else {
+            for (int i = tid; i < total; i += BIN_T) {
+                const Rec r = s_stage[i];
+                const int b = (int)(r.row >> BK_SHIFT);
+                const int slot = s_base[b] + (i - s_off[b]);
+                if (slot < cap) {
+                    lrec[(int64_t)b * cap + slot] = r;
+                } else {  // bucket region full: finish this record with global atomics
+                    atomicAdd(lt + (int64_t)r.row * 2, r.v0);
+                    atomicAdd(lt + (int64_t)r.row * 2 + 1, r.v1);
+                }
             }
         }
         // the next iteration's first barrier orders these LDS reads before s_stage/s_off are rewritten
@@ -418,7 +467,7 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
 
 // Pass 2.  LDS float atomics run at ~0.5 lane/clk on gfx950 while integer LDS atomics run at the
 // plain-store rate (measured: profiles/README.md, "reduce_dbg"), so the tile accumulates in 64-bit
-// FIXED POINT: every value is scaled by a power of two chosen from the bucket's largest |value|
+// FIXED POINT: every value is scaled by a power of two chosen from the level's largest |value|
 // (found by pass 1) so that |q| < 2^44, which leaves 2^17 additions of head-room in an int64.  The
 // scaling is exact, the integer sum is exact and order-independent, and the only rounding is the
 // quantisation of each addend to 2^-45 of the bucket maximum plus one final conversion to f32:
@@ -440,7 +489,7 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
     const int lo = (int)(((long long)n * s) / S), hi = (int)(((long long)n * (s + 1)) / S);
     if (hi <= lo) return;  // uniform per workgroup
     // largest |value| < 2^(e-126)  ->  scale 2^(170-e) puts it below 2^44
-    int e = (int)(gmax[bm.bstart[l] + b] >> 23);
+    int e = (int)(gmax[l] >> 23);  // largest |value| of the LEVEL (found by pass 1)
     e = e < 1 ? 1 : (e > 254 ? 254 : e);
     int k = 170 - e;               // power of two to scale by; split so that both factors are normal floats
     k = k > 200 ? 200 : k;
@@ -502,8 +551,10 @@ static int g_bin_staged = 1;
 // TIMING-ONLY experiment switch of the reduce pass (non-zero values give wrong sums)
 static int g_reduce_dbg = 0;
 
-// device header of the workspace: bucket cursors (int32) followed by bucket maxima (uint32)
-static size_t cursor_bytes(int n_buckets) { return ((size_t)n_buckets * 2 * sizeof(int32_t) + 4095) / 4096 * 4096; }
+// device header of the workspace: bucket cursors (int32) followed by the per-level maxima (uint32)
+static size_t cursor_bytes(int n_buckets) {
+    return ((size_t)(n_buckets + LNERF_MAX_LEVELS) * sizeof(int32_t) + 4095) / 4096 * 4096;
+}
 
 static int fill_bucket_meta(const GridMeta &meta, int64_t m_host, BucketMeta &bm, int64_t &total_recs,
                             int &total_buckets, int &total_wgs) {
