@@ -49,7 +49,8 @@ def parse():
                     help="bf16 (BASELINE configs[1]): bf16 shadow table + bf16 features + bf16 MFMA MLP, f32 "
                          "master weights/accumulation/compositing; f32: f32 table + exact-f32 MFMA MLP")
     ap.add_argument("--table", default="auto", choices=["auto", "f32", "bf16"],
-                    help="dtype of the hash table the gather reads (auto: f32; bf16 = half-size shadow refreshed by Adam)")
+                    help="dtype of the hash table the gather reads (auto: follows --precision, the SURVEY §8(b) dtype policy; "
+                         "bf16 = half-size shadow refreshed by the fused Adam pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--gather-variant", type=int, default=0)
@@ -232,7 +233,7 @@ def main():
     # everything (eager steps, graph capture, replays, collectives) runs on one non-default stream
     main_stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(main_stream)
-    table = "f32" if args.table == "auto" else args.table
+    table = args.precision if args.table == "auto" else args.table
     net, pose, intr, bg, grad = build(dev, args.precision, args.gather_variant, rank, table)
     from src.latent_nerf.training.optimizer import FusedAdam
     opt = FusedAdam(net.get_params(LR), betas=(0.9, 0.99), eps=1e-15, encoder=net.encoder, capturable=True)
