@@ -61,6 +61,7 @@ const char *lnerf_build_info(void);
  *                              rows before binning (default 512).
  *   "scatter_bin_map":         workgroup->(level,tile) map of the binning pass, 0 = level on
  *                              blockIdx.y (default), 1 = XCD-aware.
+ *   "gather_pair_loads":       1 (default) = x-adjacent vertices fetched with one load where adjacent.
  *   "mlp_fwd_blocks":          persistent workgroups of the bf16 MLP forward (default 512).
  *   "scatter_bin_staged":      1 (default) = records grouped per bucket in LDS and written coalesced,
  *                              0 = every lane stores its own records. */

@@ -73,6 +73,24 @@ template <> struct Feat2<uint16_t> {  // bf16 pairs in one dword
     }
 };
 
+// two consecutive table rows with one load (x-adjacent vertices are adjacent rows on dense levels, and on
+// hashed levels when x is even: row(x+1) = row(x) ^ 1): halves the L1 accesses of those lookups
+template <typename T> struct Pair2;
+template <> struct Pair2<float> {
+    static __device__ __forceinline__ void load(const float *base, uint32_t row, float2 &a, float2 &b) {
+        const float4 v = *reinterpret_cast<const float4 *>(base + (int64_t)row * 2);  // dword-aligned 16-byte load
+        a = make_float2(v.x, v.y);
+        b = make_float2(v.z, v.w);
+    }
+};
+template <> struct Pair2<uint16_t> {
+    static __device__ __forceinline__ void load(const uint16_t *base, uint32_t row, float2 &a, float2 &b) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(base + (int64_t)row * 2);    // two bf16 pairs
+        a = make_float2(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xFFFF0000u));
+        b = make_float2(__uint_as_float(v.y << 16), __uint_as_float(v.y & 0xFFFF0000u));
+    }
+};
+
 struct LevelPos {
     uint32_t gx, gy, gz;
     float fx, fy, fz;
@@ -126,7 +144,8 @@ __device__ __forceinline__ TileMap tile_map(int variant, int L) {
 template <typename TT, typename TO>
 __global__ void __launch_bounds__(256)
 k_grid_forward(const float *__restrict__ xyzs, float bound, const TT *__restrict__ table, GridMeta meta, int64_t m_host,
-               const int32_t *__restrict__ m_dev, int64_t level_stride, TO *__restrict__ feat, int variant) {
+               const int32_t *__restrict__ m_dev, int64_t level_stride, TO *__restrict__ feat, int variant,
+               int pair_loads) {
     int64_t M = m_host;
     if (m_dev) { const int64_t md = *m_dev; M = md < M ? md : M; }
     const TileMap tm = tile_map(variant, meta.num_levels);
@@ -146,10 +165,28 @@ k_grid_forward(const float *__restrict__ xyzs, float bound, const TT *__restrict
         float w[8];
         uint32_t rows[8];
         corner_rows(p.gx, p.gy, p.gz, res, hsize, rows);
+        const bool dense = (uint64_t)(res + 1) * (res + 1) * (res + 1) <= (uint64_t)hsize;  // wave-uniform
+        const bool pow2 = (hsize & (hsize - 1u)) == 0u;
+        if (pair_loads && dense) {
+#pragma unroll
+            for (int c = 0; c < 8; c += 2) Pair2<TT>::load(lt, rows[c], v[c], v[c + 1]);  // rows[c+1] == rows[c] + 1
+        } else if (pair_loads && pow2 && !(p.gx & 1u)) {
+            // hashed, x even: the two x-neighbours are the two halves of one aligned pair
+#pragma unroll
+            for (int c = 0; c < 8; c += 2) {
+                float2 lo, hi;
+                Pair2<TT>::load(lt, rows[c] & ~1u, lo, hi);
+                const bool odd = rows[c] & 1u;
+                v[c] = odd ? hi : lo;
+                v[c + 1] = odd ? lo : hi;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = Feat2<TT>::load(lt, rows[c]);
+        }
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const uint32_t bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
-            v[c] = Feat2<TT>::load(lt, rows[c]);
             const float wx = bx ? p.fx : 1.0f - p.fx;
             const float wy = by ? p.fy : 1.0f - p.fy;
             const float wz = bz ? p.fz : 1.0f - p.fz;
@@ -544,6 +581,8 @@ extern int g_mlp_fwd_blocks;  // mlp.hip
 
 // levels up to this resolution merge per-wave runs before binning (tunable: lnerf_set_tuning)
 static int g_compact_max_res = 512;
+// gather: fetch x-adjacent vertices with one load where they are adjacent rows
+static int g_gather_pairs = 1;
 // workgroup -> (level, tile) map of the binning pass: 0 = level on blockIdx.y, 1 = XCD-aware
 static int g_bin_map = 0;
 // 1: group a tile's records by bucket in LDS and copy them out coalesced; 0: every lane stores its own records
@@ -646,7 +685,7 @@ int lnerf_grid_encode_forward(const float *xyzs, float bound, const void *table,
     hipStream_t s = as_stream(stream);
 #define LAUNCH_FWD(TT, TO)                                                                                         \
     hipLaunchKernelGGL((k_grid_forward<TT, TO>), grid, dim3(256), 0, s, xyzs, bound, (const TT *)table, meta, m_host, \
-                       m_dev, level_stride, (TO *)feat, variant)
+                       m_dev, level_stride, (TO *)feat, variant, g_gather_pairs)
     if (table_dtype == LNERF_F32 && feat_dtype == LNERF_F32) LAUNCH_FWD(float, float);
     else if (table_dtype == LNERF_F32) LAUNCH_FWD(float, uint16_t);
     else if (feat_dtype == LNERF_F32) LAUNCH_FWD(uint16_t, float);
@@ -666,6 +705,10 @@ int lnerf_set_tuning(const char *key, int value) {
     if (strcmp(key, "scatter_bin_map") == 0) {
         LNERF_REQUIRE(value == 0 || value == 1, "set_tuning: scatter_bin_map must be 0 or 1");
         g_bin_map = value;
+        return LNERF_OK;
+    }
+    if (strcmp(key, "gather_pair_loads") == 0) {
+        g_gather_pairs = value ? 1 : 0;
         return LNERF_OK;
     }
     if (strcmp(key, "mlp_fwd_blocks") == 0) {

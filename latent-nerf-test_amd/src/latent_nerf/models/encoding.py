@@ -72,7 +72,10 @@ def scatter_workspace(levels: GridLevels, m_host, device):
     key = (str(device), need)
     ws = _scatter_ws.get(key)
     if ws is None:
-        _scatter_ws.clear()  # one live workspace: it can be gigabytes
+        # A workspace can be gigabytes, but a captured hipGraph may hold its address: never free one that
+        # was handed out while others might still replay.  Keep the few distinct sizes a process uses.
+        if len(_scatter_ws) >= 8:
+            raise _b.LnerfError("more than 8 distinct scatter workspaces requested in one process")
         ws = torch.empty(need, device=device, dtype=torch.uint8)
         _scatter_ws[key] = ws
     return ws

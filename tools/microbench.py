@@ -63,14 +63,20 @@ def main():
         f32o = torch.empty(16, cap, 2, device=dev)
         bf16o = torch.empty(16, cap, 2, device=dev, dtype=torch.bfloat16)
         fns = {}
-        for var in (0, 1):
-            fns["f32tab_f32out_v%d" % var] = (lambda v=var: E.grid_encode_forward(xyzs, 1.0, table, levels, cap, m_dev, cap, f32o, variant=v))
-            fns["bf16tab_f32out_v%d" % var] = (lambda v=var: E.grid_encode_forward(xyzs, 1.0, table_bf, levels, cap, m_dev, cap, f32o, variant=v))
-            fns["bf16tab_bf16out_v%d" % var] = (lambda v=var: E.grid_encode_forward(xyzs, 1.0, table_bf, levels, cap, m_dev, cap, bf16o, variant=v))
+        for pl in (0, 1):
+            def mk(tab, out, pl=pl):
+                def f():
+                    B.call("lnerf_set_tuning", b"gather_pair_loads", pl)
+                    E.grid_encode_forward(xyzs, 1.0, tab, levels, cap, m_dev, cap, out, variant=0)
+                return f
+            fns["f32tab_f32out_pairs%d" % pl] = mk(table, f32o)
+            fns["f32tab_bf16out_pairs%d" % pl] = mk(table, bf16o)
+            fns["bf16tab_bf16out_pairs%d" % pl] = mk(table_bf, bf16o)
         t = timed(fns)
         res["gather_ms(median,min)"] = t
-        res["gather_GBps_algorithmic"] = {k: round(M * (1164 if k.startswith("f32tab") else (652 if "f32out" in k else 588)) / (v[0] * 1e-3) / 1e9, 1)
-                                          for k, v in t.items()}
+        bps = lambda k: (1024 if k.startswith("f32tab") else 512) + 12 + (128 if "f32out" in k else 64)
+        res["gather_GBps_algorithmic"] = {k: round(M * bps(k) / (v[0] * 1e-3) / 1e9, 1) for k, v in t.items()}
+        B.call("lnerf_set_tuning", b"gather_pair_loads", 1)
 
     if "scatter" in which:
         dfeat = torch.randn(16, cap, 2, device=dev)
