@@ -73,9 +73,9 @@ def scatter_workspace(levels: GridLevels, m_host, device):
     ws = _scatter_ws.get(key)
     if ws is None:
         # A workspace can be gigabytes, but a captured hipGraph may hold its address: never free one that
-        # was handed out while others might still replay.  Keep the few distinct sizes a process uses.
-        if len(_scatter_ws) >= 8:
-            raise _b.LnerfError("more than 8 distinct scatter workspaces requested in one process")
+        # was handed out while others might still replay.  Keep the distinct sizes a process uses (288 GB of HBM).
+        if sum(t.numel() for t in _scatter_ws.values()) + need > (96 << 30):
+            raise _b.LnerfError("scatter workspaces of this process would exceed 96 GiB")
         ws = torch.empty(need, device=device, dtype=torch.uint8)
         _scatter_ws[key] = ws
     return ws
