@@ -256,7 +256,7 @@ k_grid_backward_atomic(const float *__restrict__ xyzs, float bound, const TG *__
 // A bucket that overflows its region falls back to global atomics for the excess records, so the
 // result is always complete.
 constexpr int BK_SHIFT = 12, BK_ROWS = 1 << BK_SHIFT;  // 4096 rows * 8 B = 32 KiB of accumulators
-constexpr int BIN_T = 512;                              // threads (= samples) per binning tile
+// threads (= samples) per binning tile: template parameter BIN_T of k_scatter_bin (256 or 512)
 constexpr int BK_MAX_PER_LEVEL = 256;                   // LDS counters per workgroup tile
 
 // one scatter record: 12 bytes
@@ -300,12 +300,12 @@ __device__ __forceinline__ float run_sum(float v, const RunInfo &r) {
     return r.start > 0 ? P - Pm : P;
 }
 
-template <typename TG>
-__global__ void __launch_bounds__(BIN_T, 6)
+template <typename TG, int BIN_T>
+__global__ void __launch_bounds__(BIN_T, BIN_T == 512 ? 6 : (BIN_T == 1024 ? 4 : 3))
 k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict__ dfeat, GridMeta meta, BucketMeta bm,
               int64_t m_host, const int32_t *__restrict__ m_dev, int64_t level_stride, int32_t *__restrict__ cursor,
               unsigned int *__restrict__ gmax, Rec *__restrict__ recs, float *__restrict__ dtable, int variant,
-              int staged) {
+              int staged, int skip_zero) {
     __shared__ int s_cnt[BK_MAX_PER_LEVEL];   // records of this tile per bucket
     __shared__ int s_base[BK_MAX_PER_LEVEL];  // first slot reserved in the bucket's global region
     __shared__ int s_off[BK_MAX_PER_LEVEL];   // first slot of the bucket in the LDS stage
@@ -343,10 +343,12 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
             LevelPos p;
             p.gx = p.gy = p.gz = 0; p.fx = p.fy = p.fz = 0.f;
             float2 gg = make_float2(0.f, 0.f);
-            if (valid) {
-                p = level_pos(xyzs, m, bound, scale);
-                gg = Feat2<TG>::load(dfeat + ((int64_t)l * level_stride + m) * 2, 0);
-            }
+            if (valid) gg = Feat2<TG>::load(dfeat + ((int64_t)l * level_stride + m) * 2, 0);
+            // a wavefront whose 64 samples all carry a zero gradient (rays past their termination point) has
+            // nothing to bin: skip its index arithmetic, it only keeps the workgroup's barriers company
+            const bool wave_live = !skip_zero || __ballot(valid && (gg.x != 0.f || gg.y != 0.f)) != 0ull;
+            if (wave_live) {
+            if (valid) p = level_pos(xyzs, m, bound, scale);
             corner_rows(p.gx, p.gy, p.gz, res, hsize, row);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -368,6 +370,17 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
                 emit = (valid && ri.tail) ? 0xFFu : 0u;
             } else {
                 emit = valid ? 0xFFu : 0u;
+            }
+            // contributions that are exactly zero add nothing: samples behind a ray's termination point
+            // (T < T_thresh) get dsigma = drgb = 0 from the compositing backward, hence dfeat = 0 -- on an
+            // opaque scene that is a large share of all samples
+            uint32_t nz = 0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) nz |= ((v0[c] != 0.f || v1[c] != 0.f) ? 1u : 0u) << c;
+            if (skip_zero) emit &= nz;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { row[c] = 0u; v0[c] = 0.f; v1[c] = 0.f; }
             }
         }
         // ---- rank every record inside its bucket (tile-local)
@@ -587,6 +600,10 @@ static int g_gather_pairs = 1;
 static int g_bin_map = 0;
 // 1: group a tile's records by bucket in LDS and copy them out coalesced; 0: every lane stores its own records
 static int g_bin_staged = 1;
+// samples per binning tile (256 or 512)
+static int g_bin_tile = 512;
+// drop contributions that are exactly zero (samples behind a ray's termination point)
+static int g_skip_zero = 1;
 // TIMING-ONLY experiment switch of the reduce pass (non-zero values give wrong sums)
 static int g_reduce_dbg = 0;
 
@@ -716,6 +733,15 @@ int lnerf_set_tuning(const char *key, int value) {
         g_mlp_fwd_blocks = value;
         return LNERF_OK;
     }
+    if (strcmp(key, "scatter_skip_zero") == 0) {
+        g_skip_zero = value ? 1 : 0;
+        return LNERF_OK;
+    }
+    if (strcmp(key, "scatter_bin_tile") == 0) {
+        LNERF_REQUIRE(value == 256 || value == 512 || value == 1024, "set_tuning: scatter_bin_tile must be 256, 512 or 1024");
+        g_bin_tile = value;
+        return LNERF_OK;
+    }
     if (strcmp(key, "scatter_bin_staged") == 0) {
         g_bin_staged = value ? 1 : 0;
         return LNERF_OK;
@@ -782,9 +808,17 @@ int lnerf_grid_encode_backward(const float *xyzs, float bound, const void *dfeat
         set_error("grid_encode_backward: hipMemsetAsync failed");
         return LNERF_ERR_HIP;
     }
-    launch_dims(g_bin_map, num_levels, div_up(m_host, BIN_T / 256), grid);  // tiles of BIN_T samples
-    hipLaunchKernelGGL((k_scatter_bin<float>), grid, dim3(BIN_T), 0, s, xyzs, bound, (const float *)dfeat, meta, bm,
-                       m_host, m_dev, level_stride, cursor, gmax, rec, dtable, g_bin_map, g_bin_staged);
+    const int BIN_T = g_bin_tile;
+    launch_dims(g_bin_map, num_levels, div_up(m_host * 256, BIN_T), grid);  // tiles of BIN_T samples
+    if (BIN_T == 256)
+        hipLaunchKernelGGL((k_scatter_bin<float, 256>), grid, dim3(256), 0, s, xyzs, bound, (const float *)dfeat, meta,
+                           bm, m_host, m_dev, level_stride, cursor, gmax, rec, dtable, g_bin_map, g_bin_staged, g_skip_zero);
+    else if (BIN_T == 1024)
+        hipLaunchKernelGGL((k_scatter_bin<float, 1024>), grid, dim3(1024), 0, s, xyzs, bound, (const float *)dfeat,
+                           meta, bm, m_host, m_dev, level_stride, cursor, gmax, rec, dtable, g_bin_map, g_bin_staged, g_skip_zero);
+    else
+    hipLaunchKernelGGL((k_scatter_bin<float, 512>), grid, dim3(BIN_T), 0, s, xyzs, bound, (const float *)dfeat, meta, bm,
+                       m_host, m_dev, level_stride, cursor, gmax, rec, dtable, g_bin_map, g_bin_staged, g_skip_zero);
     LNERF_CHECK_LAUNCH("grid_encode_backward(bin)");
     hipLaunchKernelGGL(k_scatter_reduce, dim3((unsigned)nwg), dim3(512), 0, s, meta, bm, cursor, gmax, rec, dtable,
                        g_reduce_dbg);

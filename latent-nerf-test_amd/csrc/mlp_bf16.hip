@@ -228,10 +228,8 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
     for (int64_t tile = blockIdx.x; tile * 128 < M; tile += gridDim.x) {
         const int64_t m0 = tile * 128 + w * 32;
         bf16x8 xB[2], h1B[2][2], h2B[2][2], dzB[2][2], d3B[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) xB[t] = load_x(a, m0 + 16 * t + c, m0 + 16 * t + c < M, q);
-        forward_hidden(frag, sB1, sB2, lane, xB, h1B, h2B);
         // ---- dZ3^T as a B fragment: slot (q, jj < 4) <-> output 4q + jj
+        bool live = false;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int64_t m = m0 + 16 * t + c;
@@ -242,8 +240,27 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
                 if (jj < 4 && n < a.out_dim && m < M)
                     v = n == 0 ? dsigmas[m] * fminf(sigmas[m], e15) : drgbs[m * nrgb + (n - 1)];
                 d3B[t][jj] = (__bf16)v;
+                live = live || (v != 0.f);
             }
         }
+        // 128 samples whose upstream gradient is exactly zero (rays past their termination point: the
+        // compositing backward writes zeros there) contribute nothing to any gradient: dfeat = 0, done
+        if (!__syncthreads_or(live ? 1 : 0)) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int64_t m = m0 + 16 * t + c;
+                if (m < M) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        reinterpret_cast<float2 *>(dfeat)[(int64_t)(4 * q + k) * a.level_stride + m] =
+                            make_float2(0.f, 0.f);
+                }
+            }
+            continue;  // uniform for the whole workgroup
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) xB[t] = load_x(a, m0 + 16 * t + c, m0 + 16 * t + c < M, q);
+        forward_hidden(frag, sB1, sB2, lane, xB, h1B, h2B);
         // ================= stage 1: dW3 += dZ3^T (x) H2^T
         __syncthreads();  // previous step's readers of imgA/imgD are done
 #pragma unroll

@@ -79,16 +79,29 @@ def main():
         B.call("lnerf_set_tuning", b"gather_pair_loads", 1)
 
     if "scatter" in which:
-        dfeat = torch.randn(16, cap, 2, device=dev)
+        # a REAL dfeat (from a render + backward of the bench step), so that zero gradients appear where they do
+        store = {}
+        import src.latent_nerf.models.encoding as Emod
+        orig = Emod.grid_encode_backward
+
+        def grab(xyzs_, bound_, dfeat_, *a, **k):
+            store["dfeat"] = dfeat_.clone()
+            return orig(xyzs_, bound_, dfeat_, *a, **k)
+        Emod.grid_encode_backward = grab
+        out2 = net.render(rays_o, rays_d, bg_color=bg, perturb=False)
+        out2["image"].backward(gradient=grad)
+        Emod.grid_encode_backward = orig
+        dfeat = store["dfeat"]
+        res["dfeat_zero_fraction"] = float((dfeat[:, :M, :] == 0).all(-1).float().mean())
         dtable = torch.zeros_like(table)
         fns = {}
-        for st in (1, 0):
-            def f(c=st):
-                B.call("lnerf_set_tuning", b"scatter_bin_staged", c)
+        for sz in (0, 1):
+            def f(c=sz):
+                B.call("lnerf_set_tuning", b"scatter_skip_zero", c)
                 E.grid_encode_backward(xyzs, 1.0, dfeat, levels, cap, m_dev, cap, dtable, variant=2)
-            fns["bucketed_staged%d" % st] = f
+            fns["bucketed_skipzero%d" % sz] = f
         t = timed(fns, rounds=10)
-        B.call("lnerf_set_tuning", b"scatter_bin_staged", 1)
+        B.call("lnerf_set_tuning", b"scatter_skip_zero", 1)
         res["scatter_ms(median,min)"] = t
 
     if "scatter_levels" in which:
