@@ -551,6 +551,9 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
     const Rec *rp = recs + bm.rstart[l] + (long long)b * cap;
     unsigned long long *ua = reinterpret_cast<unsigned long long *>(acc);
     const uint32_t rmask = BK_ROWS - 1;
+    // accumulator layout: dbg == 0 -> [feature][row] (a wave's 64 random rows spread over 32 bank pairs),
+    //                     dbg == 1 -> [row][feature] (16 bank groups): kept for the A/B in tools/microbench.py
+    const uint32_t rs = dbg ? 2u : 1u, fo = dbg ? 1u : (uint32_t)BK_ROWS;
     int i = lo + tid;
     for (; i + 512 < hi; i += 2 * 512) {  // two 12-byte loads in flight per lane
         const Rec r0 = rp[i], r1 = rp[i + 512];
@@ -558,17 +561,18 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
         const long long q01 = __float2ll_rn((r0.v1 * sc_a) * sc_b);
         const long long q10 = __float2ll_rn((r1.v0 * sc_a) * sc_b);
         const long long q11 = __float2ll_rn((r1.v1 * sc_a) * sc_b);
-        atomicAdd(&ua[(r0.row & rmask) * 2], (unsigned long long)q00);
-        atomicAdd(&ua[(r0.row & rmask) * 2 + 1], (unsigned long long)q01);
-        atomicAdd(&ua[(r1.row & rmask) * 2], (unsigned long long)q10);
-        atomicAdd(&ua[(r1.row & rmask) * 2 + 1], (unsigned long long)q11);
+        const uint32_t a0 = (r0.row & rmask) * rs, a1 = (r1.row & rmask) * rs;
+        atomicAdd(&ua[a0], (unsigned long long)q00);
+        atomicAdd(&ua[a0 + fo], (unsigned long long)q01);
+        atomicAdd(&ua[a1], (unsigned long long)q10);
+        atomicAdd(&ua[a1 + fo], (unsigned long long)q11);
     }
     for (; i < hi; i += 512) {
         const Rec r = rp[i];
-        atomicAdd(&ua[(r.row & rmask) * 2], (unsigned long long)__float2ll_rn((r.v0 * sc_a) * sc_b));
-        atomicAdd(&ua[(r.row & rmask) * 2 + 1], (unsigned long long)__float2ll_rn((r.v1 * sc_a) * sc_b));
+        const uint32_t a0 = (r.row & rmask) * rs;
+        atomicAdd(&ua[a0], (unsigned long long)__float2ll_rn((r.v0 * sc_a) * sc_b));
+        atomicAdd(&ua[a0 + fo], (unsigned long long)__float2ll_rn((r.v1 * sc_a) * sc_b));
     }
-    (void)dbg;
     __syncthreads();
     const int hsize = meta.offsets[l + 1] - meta.offsets[l];
     const int row0 = b << BK_SHIFT;
@@ -578,13 +582,13 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
     if (S == 1) {  // sole owner of these rows in this launch: plain read-modify-write, 8 B per lane
         for (int r = tid; r < rows; r += 512) {
             float2 d = reinterpret_cast<float2 *>(dst)[r];
-            d.x += ((float)acc[2 * r] * un_a) * un_b;
-            d.y += ((float)acc[2 * r + 1] * un_a) * un_b;
+            d.x += ((float)acc[r * rs] * un_a) * un_b;
+            d.y += ((float)acc[r * rs + fo] * un_a) * un_b;
             reinterpret_cast<float2 *>(dst)[r] = d;
         }
     } else {       // several slices share the rows: contiguous float atomics (256 B per wave instruction)
         for (int kk = tid; kk < rows * 2; kk += 512) {
-            const long long a = acc[kk];
+            const long long a = acc[(kk >> 1) * rs + (kk & 1) * fo];
             if (a != 0ll) atomicAdd(&dst[kk], ((float)a * un_a) * un_b);
         }
     }

@@ -95,13 +95,13 @@ def main():
         res["dfeat_zero_fraction"] = float((dfeat[:, :M, :] == 0).all(-1).float().mean())
         dtable = torch.zeros_like(table)
         fns = {}
-        for sz in (0, 1):
-            def f(c=sz):
-                B.call("lnerf_set_tuning", b"scatter_skip_zero", c)
+        for lay in (0, 1):
+            def f(c=lay):
+                B.call("lnerf_set_tuning", b"scatter_reduce_debug", c)
                 E.grid_encode_backward(xyzs, 1.0, dfeat, levels, cap, m_dev, cap, dtable, variant=2)
-            fns["bucketed_skipzero%d" % sz] = f
+            fns["reduce_layout_%s" % ("feature_major" if lay == 0 else "row_major")] = f
         t = timed(fns, rounds=10)
-        B.call("lnerf_set_tuning", b"scatter_skip_zero", 1)
+        B.call("lnerf_set_tuning", b"scatter_reduce_debug", 0)
         res["scatter_ms(median,min)"] = t
 
     if "scatter_levels" in which:
