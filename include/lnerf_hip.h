@@ -63,6 +63,8 @@ const char *lnerf_build_info(void);
  *                              blockIdx.y (default), 1 = XCD-aware.
  *   "gather_pair_loads":       1 (default) = x-adjacent vertices fetched with one load where adjacent.
  *   "mlp_fwd_blocks":          persistent workgroups of the bf16 MLP forward (default 512).
+ *   "scatter_split_level":     levels >= value are binned first and reduced on a side stream while the others
+ *                              are binned (default 0 = single stream; the split measured slower).
  *   "scatter_skip_zero":       1 (default) = contributions that are exactly zero are not binned.
  *   "scatter_bin_tile":        samples per binning tile, 256 or 512 (default 512).
  *   "scatter_bin_staged":      1 (default) = records grouped per bucket in LDS and written coalesced,

@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(BIN_T, BIN_T == 512 ? 6 : (BIN_T == 1024 ? 4 :
 k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict__ dfeat, GridMeta meta, BucketMeta bm,
               int64_t m_host, const int32_t *__restrict__ m_dev, int64_t level_stride, int32_t *__restrict__ cursor,
               unsigned int *__restrict__ gmax, Rec *__restrict__ recs, float *__restrict__ dtable, int variant,
-              int staged, int skip_zero) {
+              int staged, int skip_zero, int level_lo) {
     __shared__ int s_cnt[BK_MAX_PER_LEVEL];   // records of this tile per bucket
     __shared__ int s_base[BK_MAX_PER_LEVEL];  // first slot reserved in the bucket's global region
     __shared__ int s_off[BK_MAX_PER_LEVEL];   // first slot of the bucket in the LDS stage
@@ -318,7 +318,8 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
     if (m_dev) { const int64_t md = *m_dev; M = md < M ? md : M; }
     const TileMap tm = tile_map(variant, meta.num_levels);
     if (!tm.ok) return;
-    const int l = tm.level;
+    const int l = tm.level + level_lo;  // level_lo != 0 only with the blockIdx.y map (a launch over a level range)
+    if (l >= meta.num_levels) return;
     const float scale = meta.scales[l];
     const uint32_t res = (uint32_t)meta.res[l];
     const uint32_t off = (uint32_t)meta.offsets[l];
@@ -525,13 +526,14 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
 __global__ void __launch_bounds__(512)
 k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ cursor,
                  const unsigned int *__restrict__ gmax, const Rec *__restrict__ recs, float *__restrict__ dtable,
-                 int dbg) {
+                 int dbg, int wg_lo) {
     __shared__ long long acc[BK_ROWS * 2];
     // locate (level, bucket, slice) of this workgroup
+    const int wg = (int)blockIdx.x + wg_lo;
     int l = 0;
-    while (l + 1 < meta.num_levels && (int)blockIdx.x >= bm.wgstart[l + 1]) ++l;
+    while (l + 1 < meta.num_levels && wg >= bm.wgstart[l + 1]) ++l;
     const int S = bm.slices[l];
-    const int local = (int)blockIdx.x - bm.wgstart[l];
+    const int local = wg - bm.wgstart[l];
     const int b = local / S, s = local - b * S;
     const int cap = bm.cap[l];
     int n = cursor[bm.bstart[l] + b];
@@ -608,10 +610,34 @@ static int g_bin_staged = 1;
 static int g_bin_tile = 512;
 // drop contributions that are exactly zero (samples behind a ray's termination point)
 static int g_skip_zero = 1;
+// first level of group A (fine levels reduced on a side stream next to the binning of the others); 0 = no split
+static int g_scatter_split = 0;  // measured: 0.344 ms split at 8/11/13 vs 0.313 ms single stream -> off by default
 // TIMING-ONLY experiment switch of the reduce pass (non-zero values give wrong sums)
 static int g_reduce_dbg = 0;
 
 // device header of the workspace: bucket cursors (int32) followed by the per-level maxima (uint32)
+// side stream + events of the split launch, one set per device, created on the first eager call (never while
+// the caller's stream is being captured)
+struct ScatterAux {
+    hipStream_t side;
+    hipEvent_t fork, join;
+};
+static ScatterAux *scatter_aux(hipStream_t s) {
+    static ScatterAux aux[16];
+    static bool have[16] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!have[dev]) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
+        if (hipStreamCreateWithFlags(&aux[dev].side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&aux[dev].fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&aux[dev].join, hipEventDisableTiming) != hipSuccess) return nullptr;
+        have[dev] = true;
+    }
+    return &aux[dev];
+}
+
 static size_t cursor_bytes(int n_buckets) {
     return ((size_t)(n_buckets + LNERF_MAX_LEVELS) * sizeof(int32_t) + 4095) / 4096 * 4096;
 }
@@ -737,6 +763,11 @@ int lnerf_set_tuning(const char *key, int value) {
         g_mlp_fwd_blocks = value;
         return LNERF_OK;
     }
+    if (strcmp(key, "scatter_split_level") == 0) {
+        LNERF_REQUIRE(value >= 0 && value < LNERF_MAX_LEVELS, "set_tuning: scatter_split_level out of range");
+        g_scatter_split = value;
+        return LNERF_OK;
+    }
     if (strcmp(key, "scatter_skip_zero") == 0) {
         g_skip_zero = value ? 1 : 0;
         return LNERF_OK;
@@ -812,20 +843,55 @@ int lnerf_grid_encode_backward(const float *xyzs, float bound, const void *dfeat
         set_error("grid_encode_backward: hipMemsetAsync failed");
         return LNERF_ERR_HIP;
     }
+    // Optional (tuning "scatter_split_level", off by default): two level groups, A = fine levels, B = the rest,
+    // with reduce(A) on a second stream next to bin(B).  Measured slower than the single-stream order
+    // (profiles/README.md), kept as a switch for future tile shapes.
+    int split = g_scatter_split < 0 ? 0 : g_scatter_split;
+    if (split == 0 || split >= num_levels || g_bin_map != 0) split = 0;  // 0: one group
+    ScatterAux *aux = split ? scatter_aux(s) : nullptr;
+    if (!aux) split = 0;
     const int BIN_T = g_bin_tile;
-    launch_dims(g_bin_map, num_levels, div_up(m_host * 256, BIN_T), grid);  // tiles of BIN_T samples
-    if (BIN_T == 256)
-        hipLaunchKernelGGL((k_scatter_bin<float, 256>), grid, dim3(256), 0, s, xyzs, bound, (const float *)dfeat, meta,
-                           bm, m_host, m_dev, level_stride, cursor, gmax, rec, dtable, g_bin_map, g_bin_staged, g_skip_zero);
-    else if (BIN_T == 1024)
-        hipLaunchKernelGGL((k_scatter_bin<float, 1024>), grid, dim3(1024), 0, s, xyzs, bound, (const float *)dfeat,
-                           meta, bm, m_host, m_dev, level_stride, cursor, gmax, rec, dtable, g_bin_map, g_bin_staged, g_skip_zero);
-    else
-    hipLaunchKernelGGL((k_scatter_bin<float, 512>), grid, dim3(BIN_T), 0, s, xyzs, bound, (const float *)dfeat, meta, bm,
-                       m_host, m_dev, level_stride, cursor, gmax, rec, dtable, g_bin_map, g_bin_staged, g_skip_zero);
-    LNERF_CHECK_LAUNCH("grid_encode_backward(bin)");
-    hipLaunchKernelGGL(k_scatter_reduce, dim3((unsigned)nwg), dim3(512), 0, s, meta, bm, cursor, gmax, rec, dtable,
-                       g_reduce_dbg);
+    auto launch_bin = [&](int l0, int l1) {
+        dim3 g;
+        launch_dims(g_bin_map, g_bin_map == 0 ? (l1 - l0) : num_levels, div_up(m_host * 256, BIN_T), g);
+        if (BIN_T == 256)
+            hipLaunchKernelGGL((k_scatter_bin<float, 256>), g, dim3(256), 0, s, xyzs, bound, (const float *)dfeat, meta,
+                               bm, m_host, m_dev, level_stride, cursor, gmax, rec, dtable, g_bin_map, g_bin_staged,
+                               g_skip_zero, l0);
+        else if (BIN_T == 1024)
+            hipLaunchKernelGGL((k_scatter_bin<float, 1024>), g, dim3(1024), 0, s, xyzs, bound, (const float *)dfeat,
+                               meta, bm, m_host, m_dev, level_stride, cursor, gmax, rec, dtable, g_bin_map,
+                               g_bin_staged, g_skip_zero, l0);
+        else
+            hipLaunchKernelGGL((k_scatter_bin<float, 512>), g, dim3(512), 0, s, xyzs, bound, (const float *)dfeat, meta,
+                               bm, m_host, m_dev, level_stride, cursor, gmax, rec, dtable, g_bin_map, g_bin_staged,
+                               g_skip_zero, l0);
+    };
+    auto launch_reduce = [&](hipStream_t st, int l0, int l1) {
+        const int w0 = bm.wgstart[l0], w1 = bm.wgstart[l1];
+        if (w1 > w0)
+            hipLaunchKernelGGL(k_scatter_reduce, dim3((unsigned)(w1 - w0)), dim3(512), 0, st, meta, bm, cursor, gmax, rec,
+                               dtable, g_reduce_dbg, w0);
+    };
+    if (!split) {
+        launch_bin(0, num_levels);
+        LNERF_CHECK_LAUNCH("grid_encode_backward(bin)");
+        launch_reduce(s, 0, num_levels);
+    } else {
+        launch_bin(split, num_levels);                       // A: fine levels
+        LNERF_CHECK_LAUNCH("grid_encode_backward(bin A)");
+        bool ok = hipEventRecord(aux->fork, s) == hipSuccess && hipStreamWaitEvent(aux->side, aux->fork, 0) == hipSuccess;
+        launch_reduce(ok ? aux->side : s, split, num_levels);
+        LNERF_CHECK_LAUNCH("grid_encode_backward(reduce A)");
+        launch_bin(0, split);                                // B next to reduce(A)
+        LNERF_CHECK_LAUNCH("grid_encode_backward(bin B)");
+        launch_reduce(s, 0, split);
+        if (ok && !(hipEventRecord(aux->join, aux->side) == hipSuccess &&
+                    hipStreamWaitEvent(s, aux->join, 0) == hipSuccess)) {
+            set_error("grid_encode_backward: could not join the side stream");
+            return LNERF_ERR_HIP;
+        }
+    }
     LNERF_CHECK_LAUNCH("grid_encode_backward(reduce)");
     return LNERF_OK;
 }

@@ -95,13 +95,13 @@ def main():
         res["dfeat_zero_fraction"] = float((dfeat[:, :M, :] == 0).all(-1).float().mean())
         dtable = torch.zeros_like(table)
         fns = {}
-        for lay in (0, 1):
-            def f(c=lay):
-                B.call("lnerf_set_tuning", b"scatter_reduce_debug", c)
+        for sp in (0, 8, 11, 13):
+            def f(c=sp):
+                B.call("lnerf_set_tuning", b"scatter_split_level", c)
                 E.grid_encode_backward(xyzs, 1.0, dfeat, levels, cap, m_dev, cap, dtable, variant=2)
-            fns["reduce_layout_%s" % ("feature_major" if lay == 0 else "row_major")] = f
+            fns["split_level_%d" % sp] = f
         t = timed(fns, rounds=10)
-        B.call("lnerf_set_tuning", b"scatter_reduce_debug", 0)
+        B.call("lnerf_set_tuning", b"scatter_split_level", 0)
         res["scatter_ms(median,min)"] = t
 
     if "scatter_levels" in which:
