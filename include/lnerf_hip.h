@@ -60,13 +60,17 @@ const char *lnerf_build_info(void);
  *   "scatter_compact_max_res": levels with resolution <= value merge per-wavefront runs of equal
  *                              rows before binning (default 512).
  *   "scatter_bin_map":         workgroup->(level,tile) map of the binning pass, 0 = level on
- *                              blockIdx.y (default), 1 = XCD-aware.
+ *                              blockIdx.y, 1 = XCD-aware, 2 (default) = persistent workgroups that
+ *                              stride over the (tile, level) list and prefetch the next item's inputs.
+ *   "scatter_bin_wgs":         persistent workgroups of map 2 (default 768 = 3 per CU).
+ *   "scatter_bin_debug":       TIMING-ONLY experiment switch (non-zero values give wrong sums).
  *   "gather_pair_loads":       1 (default) = x-adjacent vertices fetched with one load where adjacent.
  *   "mlp_fwd_blocks":          persistent workgroups of the bf16 MLP forward (default 512).
  *   "scatter_split_level":     levels >= value are binned first and reduced on a side stream while the others
  *                              are binned (default 0 = single stream; the split measured slower).
  *   "scatter_skip_zero":       1 (default) = contributions that are exactly zero are not binned.
  *   "scatter_bin_tile":        samples per binning tile, 256 or 512 (default 512).
+ *   "scatter_reduce_threads":  threads per workgroup of the reduce pass, 512 or 1024 (default 1024).
  *   "scatter_bin_staged":      1 (default) = records grouped per bucket in LDS and written coalesced,
  *                              0 = every lane stores its own records. */
 int lnerf_set_tuning(const char *key, int value);

@@ -96,10 +96,10 @@ struct LevelPos {
     float fx, fy, fz;
 };
 
-__device__ __forceinline__ LevelPos level_pos(const float *__restrict__ xyzs, int64_t m, float bound, float scale) {
+__device__ __forceinline__ LevelPos level_pos_xyz(float x, float y, float z, float bound, float scale) {
     // x01 = (x + bound) / (2 bound); pos = x01 * scale + 0.5   (op order = oracle grid_encode)
     const float two_b = 2.0f * bound;
-    float px = xyzs[m * 3] + bound, py = xyzs[m * 3 + 1] + bound, pz = xyzs[m * 3 + 2] + bound;
+    float px = x + bound, py = y + bound, pz = z + bound;
     if ((__float_as_uint(two_b) & 0x007FFFFFu) == 0u) {  // power of two (wave-uniform): x / 2^k == x * 2^-k exactly
         const float r = 1.0f / two_b;
         px = px * r; py = py * r; pz = pz * r;
@@ -113,6 +113,9 @@ __device__ __forceinline__ LevelPos level_pos(const float *__restrict__ xyzs, in
     r.gx = (uint32_t)(int)flx; r.gy = (uint32_t)(int)fly; r.gz = (uint32_t)(int)flz;
     r.fx = px - flx; r.fy = py - fly; r.fz = pz - flz;
     return r;
+}
+__device__ __forceinline__ LevelPos level_pos(const float *__restrict__ xyzs, int64_t m, float bound, float scale) {
+    return level_pos_xyz(xyzs[m * 3], xyzs[m * 3 + 1], xyzs[m * 3 + 2], bound, scale);
 }
 
 // maps a workgroup to (level, first tile, tile step)
@@ -300,12 +303,38 @@ __device__ __forceinline__ float run_sum(float v, const RunInfo &r) {
     return r.start > 0 ? P - Pm : P;
 }
 
+// Phase stamps of the binning pass (diagnostic builds only: -DLNERF_STAMPS, tools/run_bin_stamps.sh).  Wave 0 of
+// every workgroup drains its memory counters, reads the shader clock and adds the time since the previous stamp
+// to a global per-phase total.
+#ifdef LNERF_STAMPS
+__device__ unsigned long long g_bin_stamps[16];
+#define BIN_STAMP(k)                                                                              \
+    do {                                                                                          \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                               \
+        const unsigned long long now__ = __builtin_amdgcn_s_memtime();                            \
+        stamp_acc__[k] += now__ - stamp_prev__;                                                   \
+        stamp_prev__ = now__;                                                                     \
+    } while (0)
+#define BIN_STAMP_INIT()                                                                          \
+    unsigned long long stamp_acc__[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                            \
+    unsigned long long stamp_prev__ = __builtin_amdgcn_s_memtime()
+#define BIN_STAMP_FLUSH()                                                                         \
+    do {                                                                                          \
+        if (threadIdx.x == 0)                                                                     \
+            for (int k__ = 0; k__ < 10; ++k__) atomicAdd(&g_bin_stamps[k__], stamp_acc__[k__]);   \
+    } while (0)
+#else
+#define BIN_STAMP(k) do { } while (0)
+#define BIN_STAMP_INIT() do { } while (0)
+#define BIN_STAMP_FLUSH() do { } while (0)
+#endif
+
 template <typename TG, int BIN_T>
 __global__ void __launch_bounds__(BIN_T, BIN_T == 512 ? 6 : (BIN_T == 1024 ? 4 : 3))
 k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict__ dfeat, GridMeta meta, BucketMeta bm,
               int64_t m_host, const int32_t *__restrict__ m_dev, int64_t level_stride, int32_t *__restrict__ cursor,
               unsigned int *__restrict__ gmax, Rec *__restrict__ recs, float *__restrict__ dtable, int variant,
-              int staged, int skip_zero, int level_lo) {
+              int staged, int skip_zero, int level_lo, int dbg) {
     __shared__ int s_cnt[BK_MAX_PER_LEVEL];   // records of this tile per bucket
     __shared__ int s_base[BK_MAX_PER_LEVEL];  // first slot reserved in the bucket's global region
     __shared__ int s_off[BK_MAX_PER_LEVEL];   // first slot of the bucket in the LDS stage
@@ -316,40 +345,79 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
     __shared__ int s_total;
     int64_t M = m_host;
     if (m_dev) { const int64_t md = *m_dev; M = md < M ? md : M; }
-    const TileMap tm = tile_map(variant, meta.num_levels);
-    if (!tm.ok) return;
-    const int l = tm.level + level_lo;  // level_lo != 0 only with the blockIdx.y map (a launch over a level range)
-    if (l >= meta.num_levels) return;
-    const float scale = meta.scales[l];
-    const uint32_t res = (uint32_t)meta.res[l];
-    const uint32_t off = (uint32_t)meta.offsets[l];
-    const uint32_t hsize = (uint32_t)(meta.offsets[l + 1] - meta.offsets[l]);
-    const int nb = bm.nb[l], cap = bm.cap[l], b0 = bm.bstart[l];
-    const bool compact = bm.compact[l] != 0;  // wave-uniform: coarse level, merge runs first
-    const bool few_buckets = nb <= 32;        // wave-uniform: rank with ballots instead of per-lane LDS atomics
-    Rec *lrec = recs + bm.rstart[l];
-    float *lt = dtable + (int64_t)off * 2;
+    const int L = meta.num_levels;
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int64_t tile = tm.tile0; tile * BIN_T < M; tile += tm.tstep) {
+    // Work items = (level, tile) pairs.  variant 2 (default): a PERSISTENT 1-D grid of G workgroups (G a multiple
+    // of L, ~3 per CU = what the LDS stage admits); workgroup w takes items w, w+G, w+2G, ... of the tile-major list
+    // and rotates the level by one per round, so every workgroup sees every level (balanced) and the 16 levels'
+    // bucket cursors are hit evenly.  variants 0/1: the (level, tile) maps of the gather.
+    TileMap tm;
+    tm.ok = true; tm.level = 0; tm.tile0 = 0; tm.tstep = 1;
+    if (variant != 2) tm = tile_map(variant, L);
+    const int64_t G = gridDim.x;
+    auto locate = [&](int64_t k, int &lv, int64_t &tl) -> bool {
+        if (variant == 2) {
+            tl = ((int64_t)blockIdx.x + k * G) / L;
+            lv = (int)(((int64_t)blockIdx.x + k) % L);
+        } else {
+            tl = tm.tile0 + k * tm.tstep;
+            lv = tm.level + level_lo;  // level_lo != 0 only with the blockIdx.y map (a launch over a level range)
+            if (!tm.ok || lv >= L) return false;
+        }
+        return tl * BIN_T < M;
+    };
+    // inputs of the NEXT item are fetched while the current one is ranked and staged (the pass waits on memory
+    // round trips, not on arithmetic: rocprofv3 shows 64 % of the wave cycles parked)
+    float2 n_gg = make_float2(0.f, 0.f);
+    float n_x = 0.f, n_y = 0.f, n_z = 0.f;
+    auto fetch = [&](int lv, int64_t tl) {
+        const int64_t mm = tl * BIN_T + tid;
+        n_gg = make_float2(0.f, 0.f);
+        n_x = n_y = n_z = 0.f;
+        if (mm < M) {
+            n_gg = Feat2<TG>::load(dfeat + ((int64_t)lv * level_stride + mm) * 2, 0);
+            n_x = xyzs[mm * 3]; n_y = xyzs[mm * 3 + 1]; n_z = xyzs[mm * 3 + 2];
+        }
+    };
+    int l = 0;
+    int64_t tile = 0;
+    bool have = locate(0, l, tile);
+    if (have) fetch(l, tile);
+    BIN_STAMP_INIT();
+    for (int64_t k = 0; have; ++k) {
+        const float scale = meta.scales[l];
+        const uint32_t res = (uint32_t)meta.res[l];
+        const uint32_t off = (uint32_t)meta.offsets[l];
+        const uint32_t hsize = (uint32_t)(meta.offsets[l + 1] - meta.offsets[l]);
+        const int nb = bm.nb[l], cap = bm.cap[l], b0 = bm.bstart[l];
+        const bool compact = bm.compact[l] != 0;  // wave-uniform: coarse level, merge runs first
+        const bool few_buckets = nb <= 32;        // wave-uniform: rank with ballots instead of per-lane LDS atomics
+        Rec *lrec = recs + bm.rstart[l];
+        float *lt = dtable + (int64_t)off * 2;
         for (int i = tid; i < nb; i += BIN_T) s_cnt[i] = 0;
         if (tid == 0) { s_max = 0u; s_ovf = 0; }
         __syncthreads();
+        BIN_STAMP(0);  // entry, counter reset, barrier
         const int64_t m = tile * BIN_T + tid;
         const bool valid = m < M;
         uint32_t row[8];
         float v0[8], v1[8];
         int rank[8];
         uint32_t emit = 0;  // bit c: this lane appends a record for corner c
+        int l_next = 0;
+        int64_t tile_next = 0;
+        const bool have_next = locate(k + 1, l_next, tile_next);
         {
             LevelPos p;
             p.gx = p.gy = p.gz = 0; p.fx = p.fy = p.fz = 0.f;
-            float2 gg = make_float2(0.f, 0.f);
-            if (valid) gg = Feat2<TG>::load(dfeat + ((int64_t)l * level_stride + m) * 2, 0);
+            const float2 gg = n_gg;
             // a wavefront whose 64 samples all carry a zero gradient (rays past their termination point) has
             // nothing to bin: skip its index arithmetic, it only keeps the workgroup's barriers company
             const bool wave_live = !skip_zero || __ballot(valid && (gg.x != 0.f || gg.y != 0.f)) != 0ull;
+            BIN_STAMP(1);  // inputs (prefetched)
             if (wave_live) {
-            if (valid) p = level_pos(xyzs, m, bound, scale);
+            if (valid) p = level_pos_xyz(n_x, n_y, n_z, bound, scale);
+            BIN_STAMP(2);
             corner_rows(p.gx, p.gy, p.gz, res, hsize, row);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -384,6 +452,7 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
                 for (int c = 0; c < 8; ++c) { row[c] = 0u; v0[c] = 0.f; v1[c] = 0.f; }
             }
         }
+        BIN_STAMP(3);  // rows, weights, run compaction
         // ---- rank every record inside its bucket (tile-local)
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -414,7 +483,9 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
             mx = wave_max_nonneg(mx);
             if (lane == 0 && mx > 0.f) atomicMax(&s_max, __float_as_uint(mx));
         }
+        BIN_STAMP(4);  // ranking (LDS counters) + tile max
         __syncthreads();
+        BIN_STAMP(5);  // barrier 1 (waiting for the slowest wave)
         // ---- exclusive scan of the tile's bucket counts (wave 0); the global reservations (one
         //      returning atomic per touched bucket) are issued now and consumed after the staging
         int my_base[(BK_MAX_PER_LEVEL + BIN_T - 1) / BIN_T];
@@ -424,9 +495,13 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
             my_base[k] = 0;
             if (i < nb) {
                 const int c = s_cnt[i];
-                if (c) my_base[k] = atomicAdd(&cursor[b0 + i], c);
+                // dbg (TIMING-ONLY experiments, wrong results): 1 = no reservation, every tile writes slots 0.. of
+                // the bucket; 2 = reservations made, stores folded into the first 64 slots of the bucket
+                if (c && !(dbg & 1)) my_base[k] = atomicAdd(&cursor[b0 + i], c);
             }
         }
+        if (have_next) fetch(l_next, tile_next);  // behind the reservations in the memory queue, ahead of the stores
+        BIN_STAMP(6);  // global reservations (returning atomics), waited for
         if (!staged) {  // direct mode: every lane stores its own records as soon as the reservations are known
 #pragma unroll
             for (int k = 0; k < (BK_MAX_PER_LEVEL + BIN_T - 1) / BIN_T; ++k) {
@@ -449,6 +524,7 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
                     }
                 }
             }
+            l = l_next; tile = tile_next; have = have_next;
             continue;  // uniform: `staged` is a kernel argument
         }
         if (tid == BIN_T - 1 && s_max != 0u) atomicMax(&gmax[l], s_max);  // one value per LEVEL
@@ -471,6 +547,7 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
             if (tid == 63) s_total = inc;
         }
         __syncthreads();
+        BIN_STAMP(7);  // bucket-count scan + barrier 2
         // ---- group the records by bucket in LDS
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -486,11 +563,15 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
             const int i = tid + k * BIN_T;
             if (i < nb) {
                 s_base[i] = my_base[k];
-                s_dest[i] = i * cap + my_base[k] - s_off[i];
-                if (my_base[k] + s_cnt[i] > cap) s_ovf = 1;
+                s_dest[i] = i * cap + ((dbg & 2) ? (my_base[k] & 63) : my_base[k]) - s_off[i];
+                if (!(dbg & 2) && my_base[k] + s_cnt[i] > cap) s_ovf = 1;
             }
         }
         __syncthreads();
+        BIN_STAMP(8);  // staging + barrier 3
+        // the prefetched inputs are pinned in registers here, so that the next item starts without waiting for the
+        // stores below to be acknowledged (one in-order memory counter covers loads and stores)
+        asm volatile("" : "+v"(n_gg.x), "+v"(n_gg.y), "+v"(n_x), "+v"(n_y), "+v"(n_z));
         // ---- copy out: consecutive lanes -> consecutive slots of (mostly) the same bucket: coalesced
         const int total = s_total;
         if (!s_ovf) {  // uniform fast path: every record of the tile has a slot
@@ -511,9 +592,12 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
                 }
             }
         }
+        BIN_STAMP(9);  // copy-out, stores completed
         // the next iteration's first barrier orders these LDS reads before s_stage/s_off are rewritten
         // (s_cnt is only re-zeroed, and nobody reads it after the barrier above)
+        l = l_next; tile = tile_next; have = have_next;
     }
+    BIN_STAMP_FLUSH();
 }
 
 // Pass 2.  LDS float atomics run at ~0.5 lane/clk on gfx950 while integer LDS atomics run at the
@@ -523,7 +607,11 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
 // scaling is exact, the integer sum is exact and order-independent, and the only rounding is the
 // quantisation of each addend to 2^-45 of the bucket maximum plus one final conversion to f32:
 // the result is bitwise reproducible and at least as accurate as an f32 running sum.
-__global__ void __launch_bounds__(512)
+// records per slice workgroup of pass 2 (a bucket with fewer records is reduced by one workgroup)
+constexpr int REDUCE_SLICE_RECS = 16384;
+
+template <int RT>
+__global__ void __launch_bounds__(RT)
 k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ cursor,
                  const unsigned int *__restrict__ gmax, const Rec *__restrict__ recs, float *__restrict__ dtable,
                  int dbg, int wg_lo) {
@@ -532,14 +620,19 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
     const int wg = (int)blockIdx.x + wg_lo;
     int l = 0;
     while (l + 1 < meta.num_levels && wg >= bm.wgstart[l + 1]) ++l;
-    const int S = bm.slices[l];
+    const int Smax = bm.slices[l];
     const int local = wg - bm.wgstart[l];
-    const int b = local / S, s = local - b * S;
+    const int b = local / Smax, s = local - b * Smax;
     const int cap = bm.cap[l];
     int n = cursor[bm.bstart[l] + b];
     n = n < cap ? n : cap;
+    // the launch provides slices for the worst case (every sample its own records); the bucket is cut into as many
+    // as its actual record count warrants and the other slice workgroups leave at once
+    int S = (n + REDUCE_SLICE_RECS - 1) / REDUCE_SLICE_RECS;
+    S = S < 1 ? 1 : (S > Smax ? Smax : S);
+    if (s >= S) return;    // uniform per workgroup
     const int lo = (int)(((long long)n * s) / S), hi = (int)(((long long)n * (s + 1)) / S);
-    if (hi <= lo) return;  // uniform per workgroup
+    if (hi <= lo) return;
     // largest |value| < 2^(e-126)  ->  scale 2^(170-e) puts it below 2^44
     int e = (int)(gmax[l] >> 23);  // largest |value| of the LEVEL (found by pass 1)
     e = e < 1 ? 1 : (e > 254 ? 254 : e);
@@ -548,7 +641,7 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
     const float sc_a = ldexpf(1.0f, k / 2), sc_b = ldexpf(1.0f, k - k / 2);
     const float un_a = ldexpf(1.0f, -(k / 2)), un_b = ldexpf(1.0f, -(k - k / 2));
     const int tid = threadIdx.x;
-    for (int i = tid; i < BK_ROWS * 2; i += 512) acc[i] = 0ll;
+    for (int i = tid; i < BK_ROWS * 2; i += RT) acc[i] = 0ll;
     __syncthreads();
     const Rec *rp = recs + bm.rstart[l] + (long long)b * cap;
     unsigned long long *ua = reinterpret_cast<unsigned long long *>(acc);
@@ -556,25 +649,19 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
     // accumulator layout: dbg == 0 -> [feature][row] (a wave's 64 random rows spread over 32 bank pairs),
     //                     dbg == 1 -> [row][feature] (16 bank groups): kept for the A/B in tools/microbench.py
     const uint32_t rs = dbg ? 2u : 1u, fo = dbg ? 1u : (uint32_t)BK_ROWS;
-    int i = lo + tid;
-    for (; i + 512 < hi; i += 2 * 512) {  // two 12-byte loads in flight per lane
-        const Rec r0 = rp[i], r1 = rp[i + 512];
-        const long long q00 = __float2ll_rn((r0.v0 * sc_a) * sc_b);
-        const long long q01 = __float2ll_rn((r0.v1 * sc_a) * sc_b);
-        const long long q10 = __float2ll_rn((r1.v0 * sc_a) * sc_b);
-        const long long q11 = __float2ll_rn((r1.v1 * sc_a) * sc_b);
-        const uint32_t a0 = (r0.row & rmask) * rs, a1 = (r1.row & rmask) * rs;
-        atomicAdd(&ua[a0], (unsigned long long)q00);
-        atomicAdd(&ua[a0 + fo], (unsigned long long)q01);
-        atomicAdd(&ua[a1], (unsigned long long)q10);
-        atomicAdd(&ua[a1 + fo], (unsigned long long)q11);
-    }
-    for (; i < hi; i += 512) {
-        const Rec r = rp[i];
+    auto add = [&](const Rec &r) {
         const uint32_t a0 = (r.row & rmask) * rs;
         atomicAdd(&ua[a0], (unsigned long long)__float2ll_rn((r.v0 * sc_a) * sc_b));
         atomicAdd(&ua[a0 + fo], (unsigned long long)__float2ll_rn((r.v1 * sc_a) * sc_b));
+    };
+    // the pass waits on its record loads (rocprofv3: 82 % of wave cycles parked): keep four 12-byte loads in
+    // flight per lane
+    int i = lo + tid;
+    for (; i + 3 * RT < hi; i += 4 * RT) {
+        const Rec r0 = rp[i], r1 = rp[i + RT], r2 = rp[i + 2 * RT], r3 = rp[i + 3 * RT];
+        add(r0); add(r1); add(r2); add(r3);
     }
+    for (; i < hi; i += RT) add(rp[i]);
     __syncthreads();
     const int hsize = meta.offsets[l + 1] - meta.offsets[l];
     const int row0 = b << BK_SHIFT;
@@ -582,14 +669,14 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
     rows = rows < BK_ROWS ? rows : BK_ROWS;
     float *dst = dtable + ((int64_t)meta.offsets[l] + row0) * 2;
     if (S == 1) {  // sole owner of these rows in this launch: plain read-modify-write, 8 B per lane
-        for (int r = tid; r < rows; r += 512) {
+        for (int r = tid; r < rows; r += RT) {
             float2 d = reinterpret_cast<float2 *>(dst)[r];
             d.x += ((float)acc[r * rs] * un_a) * un_b;
             d.y += ((float)acc[r * rs + fo] * un_a) * un_b;
             reinterpret_cast<float2 *>(dst)[r] = d;
         }
     } else {       // several slices share the rows: contiguous float atomics (256 B per wave instruction)
-        for (int kk = tid; kk < rows * 2; kk += 512) {
+        for (int kk = tid; kk < rows * 2; kk += RT) {
             const long long a = acc[(kk >> 1) * rs + (kk & 1) * fo];
             if (a != 0ll) atomicAdd(&dst[kk], ((float)a * un_a) * un_b);
         }
@@ -602,8 +689,11 @@ extern int g_mlp_fwd_blocks;  // mlp.hip
 static int g_compact_max_res = 512;
 // gather: fetch x-adjacent vertices with one load where they are adjacent rows
 static int g_gather_pairs = 1;
-// workgroup -> (level, tile) map of the binning pass: 0 = level on blockIdx.y, 1 = XCD-aware
-static int g_bin_map = 0;
+// workgroup -> (level, tile) map of the binning pass: 0 = level on blockIdx.y, 1 = XCD-aware, 2 = persistent
+// workgroups striding over the (tile, level) list with the level rotated per round
+static int g_bin_map = 2;
+// persistent workgroups of map 2 (3 per CU fit the 52 KiB LDS stage: 768 on 256 CUs)
+static int g_bin_wgs = 768;
 // 1: group a tile's records by bucket in LDS and copy them out coalesced; 0: every lane stores its own records
 static int g_bin_staged = 1;
 // samples per binning tile (256 or 512)
@@ -614,6 +704,10 @@ static int g_skip_zero = 1;
 static int g_scatter_split = 0;  // measured: 0.344 ms split at 8/11/13 vs 0.313 ms single stream -> off by default
 // TIMING-ONLY experiment switch of the reduce pass (non-zero values give wrong sums)
 static int g_reduce_dbg = 0;
+// TIMING-ONLY experiment switch of the binning pass (non-zero values give wrong sums)
+static int g_bin_dbg = 0;
+// threads per workgroup of the reduce pass (512 or 1024; two 64 KiB workgroups fit a CU either way)
+static int g_reduce_threads = 1024;
 
 // device header of the workspace: bucket cursors (int32) followed by the per-level maxima (uint32)
 // side stream + events of the split launch, one set per device, created on the first eager call (never while
@@ -750,8 +844,13 @@ int lnerf_set_tuning(const char *key, int value) {
         return LNERF_OK;
     }
     if (strcmp(key, "scatter_bin_map") == 0) {
-        LNERF_REQUIRE(value == 0 || value == 1, "set_tuning: scatter_bin_map must be 0 or 1");
+        LNERF_REQUIRE(value >= 0 && value <= 2, "set_tuning: scatter_bin_map must be 0, 1 or 2");
         g_bin_map = value;
+        return LNERF_OK;
+    }
+    if (strcmp(key, "scatter_bin_wgs") == 0) {
+        LNERF_REQUIRE(value >= 1 && value <= 65535, "set_tuning: scatter_bin_wgs out of range");
+        g_bin_wgs = value;
         return LNERF_OK;
     }
     if (strcmp(key, "gather_pair_loads") == 0) {
@@ -781,6 +880,15 @@ int lnerf_set_tuning(const char *key, int value) {
         g_bin_staged = value ? 1 : 0;
         return LNERF_OK;
     }
+    if (strcmp(key, "scatter_reduce_threads") == 0) {
+        LNERF_REQUIRE(value == 512 || value == 1024, "set_tuning: scatter_reduce_threads must be 512 or 1024");
+        g_reduce_threads = value;
+        return LNERF_OK;
+    }
+    if (strcmp(key, "scatter_bin_debug") == 0) {
+        g_bin_dbg = value;
+        return LNERF_OK;
+    }
     if (strcmp(key, "scatter_reduce_debug") == 0) {
         g_reduce_dbg = value;
         return LNERF_OK;
@@ -788,6 +896,16 @@ int lnerf_set_tuning(const char *key, int value) {
     set_error("set_tuning: unknown key '%s'", key);
     return LNERF_ERR_INVALID_ARG;
 }
+
+#ifdef LNERF_STAMPS
+// diagnostic builds only: read (and clear) the per-phase shader-clock totals of the binning pass
+int lnerf_debug_bin_stamps(unsigned long long *out16) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_bin_stamps), sizeof(z)) != hipSuccess) return LNERF_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_bin_stamps), z, sizeof(z)) != hipSuccess) return LNERF_ERR_HIP;
+    return LNERF_OK;
+}
+#endif
 
 size_t lnerf_grid_encode_backward_workspace_bytes(int num_levels, const int32_t *offsets_host, int64_t m_host) {
     if (num_levels < 1 || num_levels > LNERF_MAX_LEVELS || !offsets_host || m_host < 0) return 0;
@@ -853,25 +971,36 @@ int lnerf_grid_encode_backward(const float *xyzs, float bound, const void *dfeat
     const int BIN_T = g_bin_tile;
     auto launch_bin = [&](int l0, int l1) {
         dim3 g;
-        launch_dims(g_bin_map, g_bin_map == 0 ? (l1 - l0) : num_levels, div_up(m_host * 256, BIN_T), g);
+        if (g_bin_map == 2) {  // persistent: G workgroups, G a multiple of the level count
+            int64_t G = (int64_t)(g_bin_wgs / num_levels) * num_levels;
+            const int64_t items = div_up(m_host, BIN_T) * num_levels;
+            if (G > items) G = items;
+            if (G < num_levels) G = num_levels;
+            g = dim3((unsigned)G, 1, 1);
+        } else {
+            launch_dims(g_bin_map, g_bin_map == 0 ? (l1 - l0) : num_levels, div_up(m_host * 256, BIN_T), g);
+        }
         if (BIN_T == 256)
             hipLaunchKernelGGL((k_scatter_bin<float, 256>), g, dim3(256), 0, s, xyzs, bound, (const float *)dfeat, meta,
                                bm, m_host, m_dev, level_stride, cursor, gmax, rec, dtable, g_bin_map, g_bin_staged,
-                               g_skip_zero, l0);
+                               g_skip_zero, l0, g_bin_dbg);
         else if (BIN_T == 1024)
             hipLaunchKernelGGL((k_scatter_bin<float, 1024>), g, dim3(1024), 0, s, xyzs, bound, (const float *)dfeat,
                                meta, bm, m_host, m_dev, level_stride, cursor, gmax, rec, dtable, g_bin_map,
-                               g_bin_staged, g_skip_zero, l0);
+                               g_bin_staged, g_skip_zero, l0, g_bin_dbg);
         else
             hipLaunchKernelGGL((k_scatter_bin<float, 512>), g, dim3(512), 0, s, xyzs, bound, (const float *)dfeat, meta,
                                bm, m_host, m_dev, level_stride, cursor, gmax, rec, dtable, g_bin_map, g_bin_staged,
-                               g_skip_zero, l0);
+                               g_skip_zero, l0, g_bin_dbg);
     };
     auto launch_reduce = [&](hipStream_t st, int l0, int l1) {
         const int w0 = bm.wgstart[l0], w1 = bm.wgstart[l1];
-        if (w1 > w0)
-            hipLaunchKernelGGL(k_scatter_reduce, dim3((unsigned)(w1 - w0)), dim3(512), 0, st, meta, bm, cursor, gmax, rec,
-                               dtable, g_reduce_dbg, w0);
+        if (w1 > w0 && g_reduce_threads == 512)
+            hipLaunchKernelGGL(k_scatter_reduce<512>, dim3((unsigned)(w1 - w0)), dim3(512), 0, st, meta, bm, cursor, gmax,
+                               rec, dtable, g_reduce_dbg, w0);
+        else if (w1 > w0)
+            hipLaunchKernelGGL(k_scatter_reduce<1024>, dim3((unsigned)(w1 - w0)), dim3(1024), 0, st, meta, bm, cursor,
+                               gmax, rec, dtable, g_reduce_dbg, w0);
     };
     if (!split) {
         launch_bin(0, num_levels);
