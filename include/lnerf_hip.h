@@ -136,7 +136,10 @@ int lnerf_grid_encode_forward(const float *xyzs, float bound, const void *table,
  * variant 0/1: per-lane global float atomics (blockIdx.y level map / XCD-aware map); no workspace.
  * variant 2  : two-pass bucketed scatter -- records binned per 64 KiB table chunk with plain
  *              stores, then reduced in LDS and added with coalesced stores; needs `workspace`
- *              of lnerf_grid_encode_backward_workspace_bytes() bytes (16-byte aligned). */
+ *              of lnerf_grid_encode_backward_workspace_bytes() bytes (16-byte aligned).
+ * variant 3  : variant 2 with packed 8-byte records (12-bit row inside the bucket + two values rounded
+ *              to 26-bit floats, 17 mantissa bits): a third less record traffic, relative rounding
+ *              2^-18 per addend; same workspace. */
 size_t lnerf_grid_encode_backward_workspace_bytes(int num_levels, const int32_t *offsets_host, int64_t m_host);
 int lnerf_grid_encode_backward(const float *xyzs, float bound, const void *dfeat, int dfeat_dtype, int num_levels,
                                int level_dim, const int32_t *offsets_host, const float *scales_host,

@@ -262,11 +262,45 @@ constexpr int BK_SHIFT = 12, BK_ROWS = 1 << BK_SHIFT;  // 4096 rows * 8 B = 32 K
 // threads (= samples) per binning tile: template parameter BIN_T of k_scatter_bin (256 or 512)
 constexpr int BK_MAX_PER_LEVEL = 256;                   // LDS counters per workgroup tile
 
-// one scatter record: 12 bytes
-struct Rec {
-    uint32_t row;  // row inside the level (bucket = row >> BK_SHIFT)
-    float v0, v1;  // w * dfeat
+// One scatter record.
+//   Rec12 (variant 2): row inside the level + two f32 values: exact.
+//   Rec8  (variant 3): row inside the BUCKET (12 bits; the bucket is implied by the region the record sits in)
+//                      + the two values rounded (nearest-even) to 26-bit floats, sign + 8 exponent + 17 mantissa
+//                      bits: relative rounding 2^-18 per addend instead of 2^-24.  One third less record traffic
+//                      in both passes; meant for the bf16 configuration, whose gradients carry 2^-9 already.
+struct Rec12 {
+    uint32_t row;
+    float v0, v1;
+    static constexpr bool kPacked = false;
+    static __device__ __forceinline__ Rec12 make(uint32_t row, float a, float b) {
+        Rec12 r;
+        r.row = row; r.v0 = a; r.v1 = b;
+        return r;
+    }
+    __device__ __forceinline__ uint32_t row_in_bucket() const { return row & (uint32_t)(BK_ROWS - 1); }
+    __device__ __forceinline__ float a() const { return v0; }
+    __device__ __forceinline__ float b() const { return v1; }
 };
+struct alignas(8) Rec8 {
+    uint32_t lo, hi;  // bits [0,12) row in bucket, [12,38) value 0, [38,64) value 1
+    static constexpr bool kPacked = true;
+    static __device__ __forceinline__ uint32_t f26(float v) {
+        uint32_t u = __float_as_uint(v);
+        if ((u & 0x7F800000u) != 0x7F800000u) u += 0x1Fu + ((u >> 6) & 1u);  // finite: round to nearest even
+        return u >> 6;
+    }
+    static __device__ __forceinline__ Rec8 make(uint32_t row, float a, float b) {
+        const uint32_t qa = f26(a), qb = f26(b);
+        Rec8 r;
+        r.lo = (row & (uint32_t)(BK_ROWS - 1)) | (qa << 12);
+        r.hi = (qa >> 20) | (qb << 6);
+        return r;
+    }
+    __device__ __forceinline__ uint32_t row_in_bucket() const { return lo & (uint32_t)(BK_ROWS - 1); }
+    __device__ __forceinline__ float a() const { return __uint_as_float((((lo >> 12) | (hi << 20)) & 0x3FFFFFFu) << 6); }
+    __device__ __forceinline__ float b() const { return __uint_as_float((hi >> 6) << 6); }
+};
+static_assert(BK_SHIFT == 12, "Rec8 stores 12 row bits");
 
 struct BucketMeta {
     int nb[LNERF_MAX_LEVELS];            // buckets per level
@@ -329,11 +363,11 @@ __device__ unsigned long long g_bin_stamps[16];
 #define BIN_STAMP_FLUSH() do { } while (0)
 #endif
 
-template <typename TG, int BIN_T>
+template <typename TG, int BIN_T, typename REC>
 __global__ void __launch_bounds__(BIN_T, BIN_T == 512 ? 6 : (BIN_T == 1024 ? 4 : 3))
 k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict__ dfeat, GridMeta meta, BucketMeta bm,
               int64_t m_host, const int32_t *__restrict__ m_dev, int64_t level_stride, int32_t *__restrict__ cursor,
-              unsigned int *__restrict__ gmax, Rec *__restrict__ recs, float *__restrict__ dtable, int variant,
+              unsigned int *__restrict__ gmax, REC *__restrict__ recs, float *__restrict__ dtable, int variant,
               int staged, int skip_zero, int level_lo, int dbg) {
     __shared__ int s_cnt[BK_MAX_PER_LEVEL];   // records of this tile per bucket
     __shared__ int s_base[BK_MAX_PER_LEVEL];  // first slot reserved in the bucket's global region
@@ -341,7 +375,8 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
     __shared__ unsigned int s_max;            // bit pattern of the tile's largest |value|
     __shared__ int s_dest[BK_MAX_PER_LEVEL];  // global slot of the bucket's first staged record, minus its stage offset
     __shared__ int s_ovf;                     // some bucket of this tile ran past its region
-    __shared__ Rec s_stage[BIN_T * 8];        // the tile's records, grouped by bucket (48 KiB)
+    __shared__ REC s_stage[BIN_T * 8];        // the tile's records, grouped by bucket (48 KiB, 32 KiB packed)
+    __shared__ uint8_t s_bkt[REC::kPacked ? BIN_T * 8 : 4];  // packed records do not name their bucket: kept beside
     __shared__ int s_total;
     int64_t M = m_host;
     if (m_dev) { const int64_t md = *m_dev; M = md < M ? md : M; }
@@ -392,7 +427,7 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
         const int nb = bm.nb[l], cap = bm.cap[l], b0 = bm.bstart[l];
         const bool compact = bm.compact[l] != 0;  // wave-uniform: coarse level, merge runs first
         const bool few_buckets = nb <= 32;        // wave-uniform: rank with ballots instead of per-lane LDS atomics
-        Rec *lrec = recs + bm.rstart[l];
+        REC *lrec = recs + bm.rstart[l];
         float *lt = dtable + (int64_t)off * 2;
         for (int i = tid; i < nb; i += BIN_T) s_cnt[i] = 0;
         if (tid == 0) { s_max = 0u; s_ovf = 0; }
@@ -515,9 +550,7 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
                     const int b = (int)(row[c] >> BK_SHIFT);
                     const int slot = s_base[b] + rank[c];
                     if (slot < cap) {
-                        Rec r;
-                        r.row = row[c]; r.v0 = v0[c]; r.v1 = v1[c];
-                        lrec[(int64_t)b * cap + slot] = r;
+                        lrec[(int64_t)b * cap + slot] = REC::make(row[c], v0[c], v1[c]);
                     } else {
                         atomicAdd(lt + (int64_t)row[c] * 2, v0[c]);
                         atomicAdd(lt + (int64_t)row[c] * 2 + 1, v1[c]);
@@ -553,9 +586,9 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
         for (int c = 0; c < 8; ++c) {
             if ((emit >> c) & 1u) {
                 const int b = (int)(row[c] >> BK_SHIFT);
-                Rec r;
-                r.row = row[c]; r.v0 = v0[c]; r.v1 = v1[c];
-                s_stage[s_off[b] + rank[c]] = r;
+                const int slot = s_off[b] + rank[c];
+                s_stage[slot] = REC::make(row[c], v0[c], v1[c]);
+                if (REC::kPacked) s_bkt[slot] = (uint8_t)b;
             }
         }
 #pragma unroll
@@ -574,21 +607,26 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
         asm volatile("" : "+v"(n_gg.x), "+v"(n_gg.y), "+v"(n_x), "+v"(n_y), "+v"(n_z));
         // ---- copy out: consecutive lanes -> consecutive slots of (mostly) the same bucket: coalesced
         const int total = s_total;
+        auto bucket_of = [&](const REC &r, int i) -> int {
+            if constexpr (REC::kPacked) return (int)s_bkt[i];
+            else return (int)(r.row >> BK_SHIFT);
+        };
         if (!s_ovf) {  // uniform fast path: every record of the tile has a slot
             for (int i = tid; i < total; i += BIN_T) {
-                const Rec r = s_stage[i];
-                lrec[s_dest[r.row >> BK_SHIFT] + i] = r;
+                const REC r = s_stage[i];
+                lrec[s_dest[bucket_of(r, i)] + i] = r;
             }
         } else {
             for (int i = tid; i < total; i += BIN_T) {
-                const Rec r = s_stage[i];
-                const int b = (int)(r.row >> BK_SHIFT);
+                const REC r = s_stage[i];
+                const int b = bucket_of(r, i);
                 const int slot = s_base[b] + (i - s_off[b]);
                 if (slot < cap) {
                     lrec[(int64_t)b * cap + slot] = r;
                 } else {  // bucket region full: finish this record with global atomics
-                    atomicAdd(lt + (int64_t)r.row * 2, r.v0);
-                    atomicAdd(lt + (int64_t)r.row * 2 + 1, r.v1);
+                    const int64_t full_row = ((int64_t)b << BK_SHIFT) | r.row_in_bucket();
+                    atomicAdd(lt + full_row * 2, r.a());
+                    atomicAdd(lt + full_row * 2 + 1, r.b());
                 }
             }
         }
@@ -610,10 +648,10 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
 // records per slice workgroup of pass 2 (a bucket with fewer records is reduced by one workgroup)
 constexpr int REDUCE_SLICE_RECS = 16384;
 
-template <int RT>
+template <int RT, typename REC>
 __global__ void __launch_bounds__(RT)
 k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ cursor,
-                 const unsigned int *__restrict__ gmax, const Rec *__restrict__ recs, float *__restrict__ dtable,
+                 const unsigned int *__restrict__ gmax, const REC *__restrict__ recs, float *__restrict__ dtable,
                  int dbg, int wg_lo) {
     __shared__ long long acc[BK_ROWS * 2];
     // locate (level, bucket, slice) of this workgroup
@@ -643,22 +681,21 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
     const int tid = threadIdx.x;
     for (int i = tid; i < BK_ROWS * 2; i += RT) acc[i] = 0ll;
     __syncthreads();
-    const Rec *rp = recs + bm.rstart[l] + (long long)b * cap;
+    const REC *rp = recs + bm.rstart[l] + (long long)b * cap;
     unsigned long long *ua = reinterpret_cast<unsigned long long *>(acc);
-    const uint32_t rmask = BK_ROWS - 1;
     // accumulator layout: dbg == 0 -> [feature][row] (a wave's 64 random rows spread over 32 bank pairs),
     //                     dbg == 1 -> [row][feature] (16 bank groups): kept for the A/B in tools/microbench.py
     const uint32_t rs = dbg ? 2u : 1u, fo = dbg ? 1u : (uint32_t)BK_ROWS;
-    auto add = [&](const Rec &r) {
-        const uint32_t a0 = (r.row & rmask) * rs;
-        atomicAdd(&ua[a0], (unsigned long long)__float2ll_rn((r.v0 * sc_a) * sc_b));
-        atomicAdd(&ua[a0 + fo], (unsigned long long)__float2ll_rn((r.v1 * sc_a) * sc_b));
+    auto add = [&](const REC &r) {
+        const uint32_t a0 = r.row_in_bucket() * rs;
+        atomicAdd(&ua[a0], (unsigned long long)__float2ll_rn((r.a() * sc_a) * sc_b));
+        atomicAdd(&ua[a0 + fo], (unsigned long long)__float2ll_rn((r.b() * sc_a) * sc_b));
     };
     // the pass waits on its record loads (rocprofv3: 82 % of wave cycles parked): keep four 12-byte loads in
     // flight per lane
     int i = lo + tid;
     for (; i + 3 * RT < hi; i += 4 * RT) {
-        const Rec r0 = rp[i], r1 = rp[i + RT], r2 = rp[i + 2 * RT], r3 = rp[i + 3 * RT];
+        const REC r0 = rp[i], r1 = rp[i + RT], r2 = rp[i + 2 * RT], r3 = rp[i + 3 * RT];
         add(r0); add(r1); add(r2); add(r3);
     }
     for (; i < hi; i += RT) add(rp[i]);
@@ -917,7 +954,7 @@ size_t lnerf_grid_encode_backward_workspace_bytes(int num_levels, const int32_t 
     int64_t recs;
     int nbk, nwg;
     if (fill_bucket_meta(meta, m_host, bm, recs, nbk, nwg) != 0) return 0;
-    return cursor_bytes(nbk) + (size_t)recs * sizeof(Rec);  // bucket cursors, then the records
+    return cursor_bytes(nbk) + (size_t)recs * sizeof(Rec12);  // bucket cursors, then the records
 }
 
 int lnerf_grid_encode_backward(const float *xyzs, float bound, const void *dfeat, int dfeat_dtype, int num_levels,
@@ -930,7 +967,7 @@ int lnerf_grid_encode_backward(const float *xyzs, float bound, const void *dfeat
     if (rc) return rc;
     LNERF_REQUIRE(m_host >= 0 && level_stride >= m_host, "grid_encode_backward: need 0 <= m_host <= level_stride");
     LNERF_REQUIRE(bound > 0.f, "grid_encode_backward: bound must be > 0");
-    LNERF_REQUIRE(variant >= 0 && variant <= 2, "grid_encode_backward: unknown variant %d", variant);
+    LNERF_REQUIRE(variant >= 0 && variant <= 3, "grid_encode_backward: unknown variant %d", variant);
     LNERF_REQUIRE(dfeat_dtype == LNERF_F32, "grid_encode_backward: dfeat must be f32");
     if (m_host == 0) return LNERF_OK;
     LNERF_REQUIRE(xyzs && dfeat && dtable, "grid_encode_backward: null pointer");
@@ -949,14 +986,15 @@ int lnerf_grid_encode_backward(const float *xyzs, float bound, const void *dfeat
     LNERF_REQUIRE(fill_bucket_meta(meta, m_host, bm, recs, nbk, nwg) == 0,
                   "grid_encode_backward: level too large for the bucketed scatter (use variant 0/1)");
     const size_t cbytes = cursor_bytes(nbk);
-    const size_t need = cbytes + (size_t)recs * sizeof(Rec);
+    const size_t need = cbytes + (size_t)recs * sizeof(Rec12);
     LNERF_REQUIRE(workspace && workspace_bytes >= need, "grid_encode_backward: workspace too small (%zu < %zu)",
                   workspace_bytes, need);
     LNERF_REQUIRE(((uintptr_t)workspace & 15) == 0 && ((uintptr_t)dtable & 15) == 0,
                   "grid_encode_backward: workspace/dtable must be 16-byte aligned");
     int32_t *cursor = (int32_t *)workspace;
     unsigned int *gmax = (unsigned int *)workspace + nbk;
-    Rec *rec = (Rec *)((char *)workspace + cbytes);
+    void *rec = (char *)workspace + cbytes;
+    const bool packed = variant == 3;
     if (hipMemsetAsync(cursor, 0, cbytes, s) != hipSuccess) {
         set_error("grid_encode_backward: hipMemsetAsync failed");
         return LNERF_ERR_HIP;
@@ -968,7 +1006,7 @@ int lnerf_grid_encode_backward(const float *xyzs, float bound, const void *dfeat
     if (split == 0 || split >= num_levels || g_bin_map != 0) split = 0;  // 0: one group
     ScatterAux *aux = split ? scatter_aux(s) : nullptr;
     if (!aux) split = 0;
-    const int BIN_T = g_bin_tile;
+    const int BIN_T = packed ? 512 : g_bin_tile;
     auto launch_bin = [&](int l0, int l1) {
         dim3 g;
         if (g_bin_map == 2) {  // persistent: G workgroups, G a multiple of the level count
@@ -980,27 +1018,27 @@ int lnerf_grid_encode_backward(const float *xyzs, float bound, const void *dfeat
         } else {
             launch_dims(g_bin_map, g_bin_map == 0 ? (l1 - l0) : num_levels, div_up(m_host * 256, BIN_T), g);
         }
-        if (BIN_T == 256)
-            hipLaunchKernelGGL((k_scatter_bin<float, 256>), g, dim3(256), 0, s, xyzs, bound, (const float *)dfeat, meta,
-                               bm, m_host, m_dev, level_stride, cursor, gmax, rec, dtable, g_bin_map, g_bin_staged,
-                               g_skip_zero, l0, g_bin_dbg);
-        else if (BIN_T == 1024)
-            hipLaunchKernelGGL((k_scatter_bin<float, 1024>), g, dim3(1024), 0, s, xyzs, bound, (const float *)dfeat,
-                               meta, bm, m_host, m_dev, level_stride, cursor, gmax, rec, dtable, g_bin_map,
-                               g_bin_staged, g_skip_zero, l0, g_bin_dbg);
-        else
-            hipLaunchKernelGGL((k_scatter_bin<float, 512>), g, dim3(512), 0, s, xyzs, bound, (const float *)dfeat, meta,
-                               bm, m_host, m_dev, level_stride, cursor, gmax, rec, dtable, g_bin_map, g_bin_staged,
-                               g_skip_zero, l0, g_bin_dbg);
+#define LAUNCH_BIN(T, REC)                                                                                          \
+    hipLaunchKernelGGL((k_scatter_bin<float, T, REC>), g, dim3(T), 0, s, xyzs, bound, (const float *)dfeat, meta, bm, \
+                       m_host, m_dev, level_stride, cursor, gmax, (REC *)rec, dtable, g_bin_map, g_bin_staged,      \
+                       g_skip_zero, l0, g_bin_dbg)
+        if (packed) LAUNCH_BIN(512, Rec8);
+        else if (BIN_T == 256) LAUNCH_BIN(256, Rec12);
+        else if (BIN_T == 1024) LAUNCH_BIN(1024, Rec12);
+        else LAUNCH_BIN(512, Rec12);
+#undef LAUNCH_BIN
     };
     auto launch_reduce = [&](hipStream_t st, int l0, int l1) {
         const int w0 = bm.wgstart[l0], w1 = bm.wgstart[l1];
-        if (w1 > w0 && g_reduce_threads == 512)
-            hipLaunchKernelGGL(k_scatter_reduce<512>, dim3((unsigned)(w1 - w0)), dim3(512), 0, st, meta, bm, cursor, gmax,
-                               rec, dtable, g_reduce_dbg, w0);
-        else if (w1 > w0)
-            hipLaunchKernelGGL(k_scatter_reduce<1024>, dim3((unsigned)(w1 - w0)), dim3(1024), 0, st, meta, bm, cursor,
-                               gmax, rec, dtable, g_reduce_dbg, w0);
+        if (w1 <= w0) return;
+#define LAUNCH_RED(T, REC)                                                                                     \
+    hipLaunchKernelGGL((k_scatter_reduce<T, REC>), dim3((unsigned)(w1 - w0)), dim3(T), 0, st, meta, bm, cursor, \
+                       gmax, (const REC *)rec, dtable, g_reduce_dbg, w0)
+        if (packed && g_reduce_threads == 512) LAUNCH_RED(512, Rec8);
+        else if (packed) LAUNCH_RED(1024, Rec8);
+        else if (g_reduce_threads == 512) LAUNCH_RED(512, Rec12);
+        else LAUNCH_RED(1024, Rec12);
+#undef LAUNCH_RED
     };
     if (!split) {
         launch_bin(0, num_levels);

@@ -51,7 +51,9 @@ class RenderConfig:
     table_dtype: str = "f32"
     # workgroup -> (level, tile) mapping of the gather/scatter: 0 = level on grid.y (measured 1.8x faster), 1 = XCD-pinned levels
     gather_variant: int = 0
-    # hash-grid backward: 0/1 = global float atomics, 2 = two-pass bucketed scatter (LDS reduction)
-    scatter_variant: int = 2
+    # hash-grid backward: 0/1 = global float atomics, 2 = two-pass bucketed scatter (LDS reduction, exact f32
+    # records), 3 = the same with packed 8-byte records (values rounded to 17 mantissa bits),
+    # -1 = auto: 3 with mlp_precision "bf16", 2 otherwise
+    scatter_variant: int = -1
     # sample buffer capacity per view (0 = rays * min(max_steps, 256))
     max_samples: int = 0

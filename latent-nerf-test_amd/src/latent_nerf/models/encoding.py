@@ -83,9 +83,10 @@ def scatter_workspace(levels: GridLevels, m_host, device):
 
 def grid_encode_backward(xyzs, bound, dfeat, levels: GridLevels, m_host, m_dev, level_stride, dtable, variant=2):
     """dtable (f32 [rows,2]) += scatter of dfeat (level-major, f32).
-    variant 0/1: global float atomics; 2: two-pass bucketed scatter (LDS reduction)."""
+    variant 0/1: global float atomics; 2: two-pass bucketed scatter (LDS reduction); 3: the same with packed
+    8-byte records (values rounded to 17 mantissa bits)."""
     ws, ws_bytes = None, 0
-    if variant == 2:
+    if variant >= 2:
         wst = scatter_workspace(levels, m_host, xyzs.device)
         ws, ws_bytes = _p(wst), wst.numel()
     _b.call("lnerf_grid_encode_backward", _chk(xyzs, "xyzs"), float(bound), _chk(dfeat, "dfeat"), _b.F32,

@@ -123,7 +123,8 @@ class NeRFNetwork(NeRFRenderer):
         table_dtype = torch.bfloat16 if cfg.table_dtype == "bf16" else torch.float32
         self.encoder = GridEncoder(num_levels, level_dim, base_resolution, 2048 * self.bound, log2_hashmap_size,
                                    table_dtype=table_dtype, variant=cfg.gather_variant,
-                                   scatter_variant=cfg.scatter_variant)
+                                   scatter_variant=(cfg.scatter_variant if cfg.scatter_variant >= 0
+                                                    else (3 if cfg.mlp_precision == "bf16" else 2)))
         in_dim, out_dim = self.encoder.out_dim, 1 + self.img_dims
         # nn.Linear default init, kept as bare parameters: the fused kernel takes all six at once
         self.w1 = nn.Parameter(torch.empty(hidden_dim, in_dim))

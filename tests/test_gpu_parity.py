@@ -155,7 +155,7 @@ def _rand_points(M, bound=1.0, seed=0):
     return x
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("cfg", ["small", "full"])
 def test_grid_encode_forward_backward(dev, variant, cfg):
     from src.latent_nerf.models import encoding as E
@@ -193,7 +193,8 @@ def test_grid_encode_forward_backward(dev, variant, cfg):
     _close(dtable, 2 * tref.grad, 1e-3, 2e-5, "dtable accumulates")
 
 
-def test_bucketed_scatter_overflow_falls_back_to_atomics(dev):
+@pytest.mark.parametrize("variant", [2, 3])
+def test_bucketed_scatter_overflow_falls_back_to_atomics(dev, variant):
     """All samples inside one fine cell: every record of a hashed level lands in <= 8 buckets, far
     beyond their reserved regions -> the excess must take the global-atomic fallback and the sums
     must still be complete."""
@@ -208,7 +209,7 @@ def test_bucketed_scatter_overflow_falls_back_to_atomics(dev):
     O.grid_encode((x + 1) / 2, tref, lv).backward(g)
     dfeat = g.reshape(M, 16, 2).permute(1, 0, 2).contiguous().to(dev)
     dtable = torch.zeros(lv.n_rows, 2, device=dev)
-    E.grid_encode_backward(x.to(dev), 1.0, dfeat, levels, M, None, M, dtable, variant=2)
+    E.grid_encode_backward(x.to(dev), 1.0, dfeat, levels, M, None, M, dtable, variant=variant)
     _close(dtable, tref.grad, 1e-3, 2e-3, "clustered dtable")  # sums of 6000 terms of O(1)
     nz_ref = (tref.grad.abs().sum(-1) > 0)
     assert torch.equal((dtable.abs().sum(-1) > 0).cpu() | ~nz_ref, torch.ones_like(nz_ref))  # no row lost

@@ -95,15 +95,11 @@ def main():
         res["dfeat_zero_fraction"] = float((dfeat[:, :M, :] == 0).all(-1).float().mean())
         dtable = torch.zeros_like(table)
         fns = {}
-        for mp, wgs in ((0, 768), (2, 512), (2, 768), (2, 1024), (2, 1536)):
-            def f(mp=mp, wgs=wgs):
-                B.call("lnerf_set_tuning", b"scatter_bin_map", mp)
-                B.call("lnerf_set_tuning", b"scatter_bin_wgs", wgs)
-                E.grid_encode_backward(xyzs, 1.0, dfeat, levels, cap, m_dev, cap, dtable, variant=2)
-            fns["bin_map%d_wgs%d" % (mp, wgs)] = f
+        for var in (2, 3):
+            def f(var=var):
+                E.grid_encode_backward(xyzs, 1.0, dfeat, levels, cap, m_dev, cap, dtable, variant=var)
+            fns["variant%d" % var] = f
         t = timed(fns, rounds=10)
-        B.call("lnerf_set_tuning", b"scatter_bin_map", 2)
-        B.call("lnerf_set_tuning", b"scatter_bin_wgs", 768)
         res["scatter_ms(median,min)"] = t
 
     if "scatter_levels" in which:
