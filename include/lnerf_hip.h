@@ -146,6 +146,23 @@ int lnerf_grid_encode_backward(const float *xyzs, float bound, const void *dfeat
                                const int32_t *res_host, int64_t m_host, const int32_t *m_dev, int64_t level_stride,
                                float *dtable, int variant, void *workspace, size_t workspace_bytes,
                                lnerf_stream_t stream);
+/* Backward of the hash grid fused with the table's optimiser step (single-GPU training: no gradient
+ * exchange sits between the two).  Same scatter as above (variant 2 or 3), but on every level whose
+ * buckets are reduced by one workgroup each, pass 2 applies Adam(beta1, beta2, eps) to its rows
+ * straight from the LDS sums -- `table`, `exp_avg`, `exp_avg_sq` (f32 [rows, 2]) and the optional
+ * bf16 `shadow_bf16` are updated in place and the gradient of those rows never reaches HBM.  The
+ * few coarse rows below that level are summed into `dtable_zero` and finished with lnerf_adam_step.
+ * `dtable_zero` (f32 [rows, 2]) must be ZERO on entry and is zero again on return.  Arithmetic and
+ * results are identical to lnerf_grid_encode_backward + lnerf_adam_step (one shared definition).
+ * Covers `optimizer.zero_grad() ... optimizer.step()` of src/latent_paint/training/trainer.py:127-131
+ * for the table parameter only. */
+int lnerf_grid_encode_backward_adam(const float *xyzs, float bound, const void *dfeat, int dfeat_dtype, int num_levels,
+                                    int level_dim, const int32_t *offsets_host, const float *scales_host,
+                                    const int32_t *res_host, int64_t m_host, const int32_t *m_dev,
+                                    int64_t level_stride, float *dtable_zero, int variant, void *workspace,
+                                    size_t workspace_bytes, float *table, float *exp_avg, float *exp_avg_sq,
+                                    void *shadow_bf16, float lr, float beta1, float beta2, float eps, int step,
+                                    const int32_t *step_dev, float grad_scale, lnerf_stream_t stream);
 
 /* ---- H7: fused sigma/latent MLP  32 -> 64 -> 64 -> out_dim (= 1 + C), ReLU hidden.
  * Weights are PyTorch nn.Linear layout: w1 [64,32], b1 [64], w2 [64,64], b2 [64], w3 [out_dim,64],

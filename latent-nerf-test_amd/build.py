@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "liblnerf_hip.so")
 SOURCES = ["api.cc", "rays.hip", "grid.hip", "mlp.hip", "mlp_bf16.hip", "composite.hip", "optim.hip", "bg.hip", "mesh.hip", "raster.hip"]
-DEPS = ["common.h", "mlp_shared.h", os.path.join("..", "..", "include", "lnerf_hip.h")]
+DEPS = ["common.h", "mlp_shared.h", "adam_shared.h", os.path.join("..", "..", "include", "lnerf_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 

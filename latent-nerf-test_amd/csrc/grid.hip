@@ -11,6 +11,7 @@
 //            {b % 8, b % 8 + 8, ...}: each XCD's private 4 MiB L2 then only ever holds the
 //            tables of its own levels instead of all 16.
 #include "common.h"
+#include "adam_shared.h"
 
 #include <string.h>
 
@@ -648,11 +649,21 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
 // records per slice workgroup of pass 2 (a bucket with fewer records is reduced by one workgroup)
 constexpr int REDUCE_SLICE_RECS = 16384;
 
-template <int RT, typename REC>
+// Optional fused table update (lnerf_grid_encode_backward_adam): on levels >= from_level (one workgroup per
+// bucket, no slices) pass 2 owns its 4096 rows outright, so it applies the Adam step to them straight from the
+// LDS sums: the gradient of those rows never travels through HBM (42 -> 26 bytes per table entry and step).
+struct FusedUpdate {
+    float *p, *m, *v;
+    uint16_t *shadow;  // optional bf16 copy of p, refreshed in the same pass
+    AdamArgs a;
+    int from_level;
+};
+
+template <int RT, typename REC, bool FUSE>
 __global__ void __launch_bounds__(RT)
 k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ cursor,
                  const unsigned int *__restrict__ gmax, const REC *__restrict__ recs, float *__restrict__ dtable,
-                 int dbg, int wg_lo) {
+                 int dbg, int wg_lo, FusedUpdate fu) {
     __shared__ long long acc[BK_ROWS * 2];
     // locate (level, bucket, slice) of this workgroup
     const int wg = (int)blockIdx.x + wg_lo;
@@ -662,15 +673,16 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
     const int local = wg - bm.wgstart[l];
     const int b = local / Smax, s = local - b * Smax;
     const int cap = bm.cap[l];
-    int n = cursor[bm.bstart[l] + b];
-    n = n < cap ? n : cap;
+    const int n_raw = cursor[bm.bstart[l] + b];  // > cap: the excess records went to dtable with global atomics
+    const int n = n_raw < cap ? n_raw : cap;
+    const bool fuse = FUSE && l >= fu.from_level;  // the host guarantees Smax == 1 there
     // the launch provides slices for the worst case (every sample its own records); the bucket is cut into as many
     // as its actual record count warrants and the other slice workgroups leave at once
     int S = (n + REDUCE_SLICE_RECS - 1) / REDUCE_SLICE_RECS;
     S = S < 1 ? 1 : (S > Smax ? Smax : S);
     if (s >= S) return;    // uniform per workgroup
     const int lo = (int)(((long long)n * s) / S), hi = (int)(((long long)n * (s + 1)) / S);
-    if (hi <= lo) return;
+    if (hi <= lo && !fuse) return;  // (a fused bucket without records still owes its rows the Adam step, g = 0)
     // largest |value| < 2^(e-126)  ->  scale 2^(170-e) puts it below 2^44
     int e = (int)(gmax[l] >> 23);  // largest |value| of the LEVEL (found by pass 1)
     e = e < 1 ? 1 : (e > 254 ? 254 : e);
@@ -679,32 +691,102 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
     const float sc_a = ldexpf(1.0f, k / 2), sc_b = ldexpf(1.0f, k - k / 2);
     const float un_a = ldexpf(1.0f, -(k / 2)), un_b = ldexpf(1.0f, -(k - k / 2));
     const int tid = threadIdx.x;
-    for (int i = tid; i < BK_ROWS * 2; i += RT) acc[i] = 0ll;
-    __syncthreads();
-    const REC *rp = recs + bm.rstart[l] + (long long)b * cap;
-    unsigned long long *ua = reinterpret_cast<unsigned long long *>(acc);
     // accumulator layout: dbg == 0 -> [feature][row] (a wave's 64 random rows spread over 32 bank pairs),
     //                     dbg == 1 -> [row][feature] (16 bank groups): kept for the A/B in tools/microbench.py
     const uint32_t rs = dbg ? 2u : 1u, fo = dbg ? 1u : (uint32_t)BK_ROWS;
-    auto add = [&](const REC &r) {
-        const uint32_t a0 = r.row_in_bucket() * rs;
-        atomicAdd(&ua[a0], (unsigned long long)__float2ll_rn((r.a() * sc_a) * sc_b));
-        atomicAdd(&ua[a0 + fo], (unsigned long long)__float2ll_rn((r.b() * sc_a) * sc_b));
-    };
-    // the pass waits on its record loads (rocprofv3: 82 % of wave cycles parked): keep four 12-byte loads in
-    // flight per lane
-    int i = lo + tid;
-    for (; i + 3 * RT < hi; i += 4 * RT) {
-        const REC r0 = rp[i], r1 = rp[i + RT], r2 = rp[i + 2 * RT], r3 = rp[i + 3 * RT];
-        add(r0); add(r1); add(r2); add(r3);
-    }
-    for (; i < hi; i += RT) add(rp[i]);
-    __syncthreads();
+    const bool have = hi > lo;  // uniform
     const int hsize = meta.offsets[l + 1] - meta.offsets[l];
     const int row0 = b << BK_SHIFT;
     int rows = hsize - row0;
     rows = rows < BK_ROWS ? rows : BK_ROWS;
-    float *dst = dtable + ((int64_t)meta.offsets[l] + row0) * 2;
+    const int64_t R0 = (int64_t)meta.offsets[l] + row0;
+    // fused update, usual case (full bucket, even first row): two rows per lane and access (16 B).  (Fetching the
+    // lane's parameters and moments here, ahead of the record stream, was measured 35 us SLOWER.)
+    constexpr int NQ = (BK_ROWS / 2 + RT - 1) / RT;  // row pairs per lane
+    const bool fast = fuse && ((R0 | rows) & 1) == 0 && rows == BK_ROWS && (BK_ROWS / 2) % RT == 0;
+    if (have) {
+        for (int i = tid; i < BK_ROWS * 2; i += RT) acc[i] = 0ll;
+        __syncthreads();
+        const REC *rp = recs + bm.rstart[l] + (long long)b * cap;
+        unsigned long long *ua = reinterpret_cast<unsigned long long *>(acc);
+        auto add = [&](const REC &r) {
+            const uint32_t a0 = r.row_in_bucket() * rs;
+            atomicAdd(&ua[a0], (unsigned long long)__float2ll_rn((r.a() * sc_a) * sc_b));
+            atomicAdd(&ua[a0 + fo], (unsigned long long)__float2ll_rn((r.b() * sc_a) * sc_b));
+        };
+        // the pass waits on its record loads (rocprofv3: 82 % of wave cycles parked): keep four loads in flight
+        // per lane
+        int i = lo + tid;
+        for (; i + 3 * RT < hi; i += 4 * RT) {
+            const REC r0 = rp[i], r1 = rp[i + RT], r2 = rp[i + 2 * RT], r3 = rp[i + 3 * RT];
+            add(r0); add(r1); add(r2); add(r3);
+        }
+        for (; i < hi; i += RT) add(rp[i]);
+        __syncthreads();
+    }
+    float *dst = dtable + R0 * 2;
+    if (fuse) {
+        AdamArgs a = fu.a;
+        adam_bias(a);
+        a.zero_grad = 0;
+        const bool ovf = n_raw > cap;  // uniform
+        float2 *p2 = reinterpret_cast<float2 *>(fu.p) + R0, *m2 = reinterpret_cast<float2 *>(fu.m) + R0;
+        float2 *v2 = reinterpret_cast<float2 *>(fu.v) + R0;
+        uint32_t *sh = fu.shadow ? reinterpret_cast<uint32_t *>(fu.shadow) + R0 : nullptr;
+        auto grad_of = [&](int r, float &g0, float &g1) {
+            g0 = 0.f; g1 = 0.f;
+            if (have) {
+                g0 = ((float)acc[r * rs] * un_a) * un_b;
+                g1 = ((float)acc[r * rs + fo] * un_a) * un_b;
+            }
+            if (ovf) {  // what pass 1 could not place: consume it and leave dtable zero again
+                const float2 d = reinterpret_cast<float2 *>(dst)[r];
+                g0 = d.x + g0;
+                g1 = d.y + g1;
+                reinterpret_cast<float2 *>(dst)[r] = make_float2(0.f, 0.f);
+            }
+        };
+        if (fast) {
+            float4 *p4 = reinterpret_cast<float4 *>(p2), *m4 = reinterpret_cast<float4 *>(m2);
+            float4 *v4 = reinterpret_cast<float4 *>(v2);
+            uint2 *sh2 = reinterpret_cast<uint2 *>(sh);
+            float4 P[NQ], Mv[NQ], V[NQ];
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {  // all of the lane's loads first: six 16-byte loads in flight
+                const int q = tid + j * RT;
+                P[j] = p4[q]; Mv[j] = m4[q]; V[j] = v4[q];
+            }
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const int q = tid + j * RT;
+                float ga, gb, gc, gd;
+                grad_of(2 * q, ga, gb);
+                grad_of(2 * q + 1, gc, gd);
+                adam_one(P[j].x, ga, Mv[j].x, V[j].x, a);
+                adam_one(P[j].y, gb, Mv[j].y, V[j].y, a);
+                adam_one(P[j].z, gc, Mv[j].z, V[j].z, a);
+                adam_one(P[j].w, gd, Mv[j].w, V[j].w, a);
+                p4[q] = P[j]; m4[q] = Mv[j]; v4[q] = V[j];
+                if (sh) {
+                    uint2 w;
+                    w.x = (uint32_t)f32_to_bf16(P[j].x) | ((uint32_t)f32_to_bf16(P[j].y) << 16);
+                    w.y = (uint32_t)f32_to_bf16(P[j].z) | ((uint32_t)f32_to_bf16(P[j].w) << 16);
+                    sh2[q] = w;
+                }
+            }
+            return;
+        }
+        for (int r = tid; r < rows; r += RT) {
+            float2 P = p2[r], Mv = m2[r], V = v2[r];
+            float g0, g1;
+            grad_of(r, g0, g1);
+            adam_one(P.x, g0, Mv.x, V.x, a);
+            adam_one(P.y, g1, Mv.y, V.y, a);
+            p2[r] = P; m2[r] = Mv; v2[r] = V;
+            if (sh) sh[r] = (uint32_t)f32_to_bf16(P.x) | ((uint32_t)f32_to_bf16(P.y) << 16);
+        }
+        return;
+    }
     if (S == 1) {  // sole owner of these rows in this launch: plain read-modify-write, 8 B per lane
         for (int r = tid; r < rows; r += RT) {
             float2 d = reinterpret_cast<float2 *>(dst)[r];
@@ -957,11 +1039,14 @@ size_t lnerf_grid_encode_backward_workspace_bytes(int num_levels, const int32_t 
     return cursor_bytes(nbk) + (size_t)recs * sizeof(Rec12);  // bucket cursors, then the records
 }
 
-int lnerf_grid_encode_backward(const float *xyzs, float bound, const void *dfeat, int dfeat_dtype, int num_levels,
-                               int level_dim, const int32_t *offsets_host, const float *scales_host,
-                               const int32_t *res_host, int64_t m_host, const int32_t *m_dev, int64_t level_stride,
-                               float *dtable, int variant, void *workspace, size_t workspace_bytes,
-                               lnerf_stream_t stream) {
+// fu == nullptr: dtable += scatter.  fu != nullptr: levels >= the first level from which every level has one
+// pass-2 workgroup per bucket get their Adam step inside pass 2; fu->from_level is set here for the caller, who
+// finishes the rows below it with the plain Adam kernel.
+static int scatter_backward(const float *xyzs, float bound, const void *dfeat, int dfeat_dtype, int num_levels,
+                            int level_dim, const int32_t *offsets_host, const float *scales_host,
+                            const int32_t *res_host, int64_t m_host, const int32_t *m_dev, int64_t level_stride,
+                            float *dtable, int variant, void *workspace, size_t workspace_bytes,
+                            lnerf_stream_t stream, FusedUpdate *fu) {
     GridMeta meta;
     int rc = fill_meta("grid_encode_backward", meta, num_levels, level_dim, offsets_host, scales_host, res_host);
     if (rc) return rc;
@@ -969,6 +1054,7 @@ int lnerf_grid_encode_backward(const float *xyzs, float bound, const void *dfeat
     LNERF_REQUIRE(bound > 0.f, "grid_encode_backward: bound must be > 0");
     LNERF_REQUIRE(variant >= 0 && variant <= 3, "grid_encode_backward: unknown variant %d", variant);
     LNERF_REQUIRE(dfeat_dtype == LNERF_F32, "grid_encode_backward: dfeat must be f32");
+    LNERF_REQUIRE(!fu || (variant >= 2 && m_host > 0), "grid_encode_backward_adam: needs variant 2/3 and m_host > 0");
     if (m_host == 0) return LNERF_OK;
     LNERF_REQUIRE(xyzs && dfeat && dtable, "grid_encode_backward: null pointer");
     hipStream_t s = as_stream(stream);
@@ -1028,16 +1114,27 @@ int lnerf_grid_encode_backward(const float *xyzs, float bound, const void *dfeat
         else LAUNCH_BIN(512, Rec12);
 #undef LAUNCH_BIN
     };
+    FusedUpdate fu0;
+    memset(&fu0, 0, sizeof(fu0));
+    if (fu) {
+        int from = num_levels;
+        while (from > 0 && bm.slices[from - 1] == 1) --from;
+        fu->from_level = from;
+        fu0 = *fu;
+        split = 0;
+    }
     auto launch_reduce = [&](hipStream_t st, int l0, int l1) {
         const int w0 = bm.wgstart[l0], w1 = bm.wgstart[l1];
         if (w1 <= w0) return;
-#define LAUNCH_RED(T, REC)                                                                                     \
-    hipLaunchKernelGGL((k_scatter_reduce<T, REC>), dim3((unsigned)(w1 - w0)), dim3(T), 0, st, meta, bm, cursor, \
-                       gmax, (const REC *)rec, dtable, g_reduce_dbg, w0)
-        if (packed && g_reduce_threads == 512) LAUNCH_RED(512, Rec8);
-        else if (packed) LAUNCH_RED(1024, Rec8);
-        else if (g_reduce_threads == 512) LAUNCH_RED(512, Rec12);
-        else LAUNCH_RED(1024, Rec12);
+#define LAUNCH_RED(T, REC, FUSE)                                                                                  \
+    hipLaunchKernelGGL((k_scatter_reduce<T, REC, FUSE>), dim3((unsigned)(w1 - w0)), dim3(T), 0, st, meta, bm, cursor, \
+                       gmax, (const REC *)rec, dtable, g_reduce_dbg, w0, fu0)
+        if (fu && packed) LAUNCH_RED(1024, Rec8, true);
+        else if (fu) LAUNCH_RED(1024, Rec12, true);
+        else if (packed && g_reduce_threads == 512) LAUNCH_RED(512, Rec8, false);
+        else if (packed) LAUNCH_RED(1024, Rec8, false);
+        else if (g_reduce_threads == 512) LAUNCH_RED(512, Rec12, false);
+        else LAUNCH_RED(1024, Rec12, false);
 #undef LAUNCH_RED
     };
     if (!split) {
@@ -1061,6 +1158,44 @@ int lnerf_grid_encode_backward(const float *xyzs, float bound, const void *dfeat
     }
     LNERF_CHECK_LAUNCH("grid_encode_backward(reduce)");
     return LNERF_OK;
+}
+
+int lnerf_grid_encode_backward(const float *xyzs, float bound, const void *dfeat, int dfeat_dtype, int num_levels,
+                               int level_dim, const int32_t *offsets_host, const float *scales_host,
+                               const int32_t *res_host, int64_t m_host, const int32_t *m_dev, int64_t level_stride,
+                               float *dtable, int variant, void *workspace, size_t workspace_bytes,
+                               lnerf_stream_t stream) {
+    return scatter_backward(xyzs, bound, dfeat, dfeat_dtype, num_levels, level_dim, offsets_host, scales_host, res_host,
+                            m_host, m_dev, level_stride, dtable, variant, workspace, workspace_bytes, stream, nullptr);
+}
+
+int lnerf_grid_encode_backward_adam(const float *xyzs, float bound, const void *dfeat, int dfeat_dtype, int num_levels,
+                                    int level_dim, const int32_t *offsets_host, const float *scales_host,
+                                    const int32_t *res_host, int64_t m_host, const int32_t *m_dev,
+                                    int64_t level_stride, float *dtable_zero, int variant, void *workspace,
+                                    size_t workspace_bytes, float *table, float *exp_avg, float *exp_avg_sq,
+                                    void *shadow_bf16, float lr, float beta1, float beta2, float eps, int step,
+                                    const int32_t *step_dev, float grad_scale, lnerf_stream_t stream) {
+    LNERF_REQUIRE(table && exp_avg && exp_avg_sq, "grid_encode_backward_adam: null optimiser state");
+    LNERF_REQUIRE(step_dev || step >= 1, "grid_encode_backward_adam: step must be >= 1 (got %d)", step);
+    LNERF_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f,
+                  "grid_encode_backward_adam: betas must be in [0,1)");
+    LNERF_REQUIRE((((uintptr_t)table | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)dtable_zero) & 15) == 0,
+                  "grid_encode_backward_adam: buffers must be 16-byte aligned");
+    LNERF_REQUIRE(!shadow_bf16 || ((uintptr_t)shadow_bf16 & 7) == 0, "grid_encode_backward_adam: shadow must be 8-byte aligned");
+    FusedUpdate fu;
+    fu.p = table; fu.m = exp_avg; fu.v = exp_avg_sq; fu.shadow = (uint16_t *)shadow_bf16;
+    adam_host_args(fu.a, lr, beta1, beta2, eps, step, step_dev, grad_scale, 0);
+    fu.from_level = 0;
+    int rc = scatter_backward(xyzs, bound, dfeat, dfeat_dtype, num_levels, level_dim, offsets_host, scales_host, res_host,
+                              m_host, m_dev, level_stride, dtable_zero, variant, workspace, workspace_bytes, stream, &fu);
+    if (rc) return rc;
+    // rows below from_level: their sums sit in dtable (several workgroups per bucket): plain Adam pass that clears it
+    const int64_t n_low = (int64_t)offsets_host[fu.from_level] * 2;
+    if (n_low > 0)
+        rc = lnerf_adam_step(table, dtable_zero, exp_avg, exp_avg_sq, shadow_bf16, n_low, lr, beta1, beta2, eps, step,
+                             step_dev, grad_scale, 1, stream);
+    return rc;
 }
 
 }  // extern "C"

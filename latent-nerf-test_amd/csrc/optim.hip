@@ -2,33 +2,9 @@
 // over a flat f32 parameter buffer: one pass reads p,g,m,v and writes p,m,v, optionally clears g
 // and refreshes the bf16 shadow copy that the hash gather reads.  Pure HBM streaming: 16 B/lane.
 #include "common.h"
+#include "adam_shared.h"
 
 namespace lnerf {
-
-struct AdamArgs {
-    float lr, beta1, beta2, eps, bc1, bc2, grad_scale;
-    int zero_grad;
-    const int32_t *step_dev;  // optional device-side step counter (hipGraph replays): overrides bc1/bc2
-};
-
-// bias corrections from the device step counter (same value in every thread; a handful of SALU/VALU ops)
-__device__ __forceinline__ void adam_bias(AdamArgs &a) {
-    if (a.step_dev) {
-        const float t = (float)(*a.step_dev);
-        a.bc1 = 1.0f - powf(a.beta1, t);
-        a.bc2 = 1.0f - powf(a.beta2, t);
-    }
-}
-
-__device__ __forceinline__ void adam_one(float &p, float &g, float &m, float &v, const AdamArgs &a) {
-    const float gs = g * a.grad_scale;
-    m = fmaf(a.beta1, m, (1.0f - a.beta1) * gs);
-    v = fmaf(a.beta2, v, (1.0f - a.beta2) * gs * gs);
-    const float mhat = m / a.bc1;
-    const float vhat = v / a.bc2;
-    p = p - a.lr * mhat / (sqrtf(vhat) + a.eps);
-    if (a.zero_grad) g = 0.f;
-}
 
 __global__ void __launch_bounds__(256)
 k_adam(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,

@@ -54,6 +54,8 @@ class OptimConfig:
     lambda_shape: float = 5e-6
     # views per optimisation step (sharded one-per-GPU in data-parallel runs)
     views_per_step: int = 1
+    # single process and one view per step: the hash table's Adam step runs inside the scatter of the backward pass
+    fuse_table_update: bool = True
 
 
 @dataclass

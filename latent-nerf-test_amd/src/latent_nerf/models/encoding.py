@@ -96,32 +96,79 @@ def grid_encode_backward(xyzs, bound, dfeat, levels: GridLevels, m_host, m_dev, 
     return dtable
 
 
+class FusedTableUpdate:
+    """Set on a GridEncoder (`encoder.fused_update`) by FusedAdam(fuse_table_update=True).  When ARMED
+    (FusedAdam.arm(), once per step, right before the step's single backward) the scatter of that backward applies
+    the table's Adam step itself (lnerf_grid_encode_backward_adam) and the table gets no `.grad`; any other
+    backward through the encoder (unarmed) produces the ordinary gradient.  Single GPU only."""
+
+    def __init__(self, exp_avg, exp_avg_sq, lr, betas, eps, optimizer):
+        self.exp_avg, self.exp_avg_sq = exp_avg, exp_avg_sq
+        self.lr, self.betas, self.eps = float(lr), betas, float(eps)
+        self.optimizer = optimizer          # step number / device step counter live there
+        self.zero = torch.zeros_like(exp_avg)  # dtable scratch: zero between calls (coarse levels, overflow records)
+        self.applied = 0                    # fused updates since the last optimizer.step()
+        self.armed = False
+
+    def take(self):
+        """True once per arm(): the caller (a backward pass) then owes the fused update."""
+        if self.armed:
+            self.armed = False
+            return True
+        return False
+
+
+def grid_encode_backward_adam(xyzs, bound, dfeat, encoder, m_host, m_dev, level_stride, variant):
+    """Scatter of dfeat fused with the Adam step of encoder.embeddings (see include/lnerf_hip.h)."""
+    fu = encoder.fused_update
+    levels = encoder.levels
+    if variant < 2:
+        raise _b.LnerfError("the fused table update needs the bucketed scatter (variant 2 or 3)")
+    wst = scatter_workspace(levels, m_host, xyzs.device)
+    opt = fu.optimizer
+    table = encoder.embeddings.data
+    shadow = encoder.shadow()
+    b1, b2 = fu.betas
+    _b.call("lnerf_grid_encode_backward_adam", _chk(xyzs, "xyzs"), float(bound), _chk(dfeat, "dfeat"), _b.F32,
+            levels.num_levels, levels.level_dim, levels.c_offsets, levels.c_scales, levels.c_res, int(m_host),
+            _chk(m_dev, "m_dev", torch.int32, allow_none=True), int(level_stride), _p(fu.zero), int(variant), _p(wst),
+            wst.numel(), _p(table), _p(fu.exp_avg), _p(fu.exp_avg_sq), _p(shadow), fu.lr, b1, b2, fu.eps,
+            opt.step_no + 1, _p(opt.step_dev), float(opt.grad_scale), _stream())
+    fu.applied += 1
+
+
 class _GridEncode(torch.autograd.Function):
     """feat = encode(xyzs; table).  `table` is the f32 master parameter (gradient target);
     `shadow` an optional bf16 copy that the gather actually reads."""
 
     @staticmethod
     def forward(ctx, xyzs, table, shadow, levels, bound, m_host, m_dev, level_stride, feat_dtype, variant,
-                scatter_variant):
+                scatter_variant, encoder=None):
         src = table if shadow is None else shadow
         feat = grid_encode_forward(xyzs, bound, src.detach(), levels, m_host, m_dev, level_stride, None, feat_dtype,
                                    variant)
         ctx.save_for_backward(xyzs, m_dev if m_dev is not None else torch.empty(0))
         ctx.has_mdev = m_dev is not None
         ctx.meta = (levels, bound, m_host, level_stride, scatter_variant, table.shape, table.device)
+        ctx.encoder = encoder
         return feat
 
     @staticmethod
     def backward(ctx, dfeat):
         xyzs, m_dev = ctx.saved_tensors
         levels, bound, m_host, level_stride, variant, shape, dev = ctx.meta
-        dtable = torch.zeros(shape, device=dev, dtype=torch.float32)
         dfeat = dfeat.contiguous()
         if dfeat.dtype != torch.float32:
             dfeat = dfeat.float()
+        enc = ctx.encoder
+        if enc is not None and enc.fused_update is not None and enc.fused_update.take():
+            grid_encode_backward_adam(xyzs, bound, dfeat, enc, m_host, m_dev if ctx.has_mdev else None, level_stride,
+                                      variant)
+            return (None,) * 12
+        dtable = torch.zeros(shape, device=dev, dtype=torch.float32)
         grid_encode_backward(xyzs, bound, dfeat, levels, m_host, m_dev if ctx.has_mdev else None, level_stride,
                              dtable, variant)
-        return None, dtable, None, None, None, None, None, None, None, None, None
+        return None, dtable, None, None, None, None, None, None, None, None, None, None
 
 
 class GridEncoder(nn.Module):
@@ -141,6 +188,7 @@ class GridEncoder(nn.Module):
         self.reset_parameters()
         self._shadow = None
         self._shadow_version = -1
+        self.fused_update = None  # FusedTableUpdate, installed by FusedAdam(fuse_table_update=True)
 
     def reset_parameters(self):
         self.embeddings.data.uniform_(-1e-4, 1e-4)
@@ -167,7 +215,7 @@ class GridEncoder(nn.Module):
         if level_stride is None:
             level_stride = xyzs.shape[0]
         return _GridEncode.apply(xyzs, self.embeddings, self.shadow(), self.levels, bound, m_host, m_dev, level_stride,
-                                 feat_dtype, self.variant, self.scatter_variant)
+                                 feat_dtype, self.variant, self.scatter_variant, self)
 
     def forward(self, inputs, bound=1.0):
         """inputs [..., 3] in [-bound, bound] -> [..., L*2] (sample-major view, as the upstream encoder)."""

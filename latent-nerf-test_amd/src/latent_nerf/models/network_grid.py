@@ -105,9 +105,13 @@ class _HashMLPField(torch.autograd.Function):
                 _p(w3), _p(b3), out_dim, float(blob_scale), float(blob_std), int(m_host), _p(m_dev), _p(sigmas),
                 _chk(dsigmas, "dsigmas"), _chk(drgbs, "drgbs"), _p(dfeat), *[_p(g) for g in grads], 0, _p(workspace),
                 workspace.numel(), precision, _stream())
-        dtable = torch.zeros(tshape, device=dev, dtype=torch.float32)
-        E.grid_encode_backward(xyzs, bound, dfeat, encoder.levels, m_host, m_dev, level_stride, dtable,
-                               encoder.scatter_variant)
+        if encoder.fused_update is not None and encoder.fused_update.take():  # armed: the scatter applies the table's Adam step
+            E.grid_encode_backward_adam(xyzs, bound, dfeat, encoder, m_host, m_dev, level_stride, encoder.scatter_variant)
+            dtable = None
+        else:
+            dtable = torch.zeros(tshape, device=dev, dtype=torch.float32)
+            E.grid_encode_backward(xyzs, bound, dfeat, encoder.levels, m_host, m_dev, level_stride, dtable,
+                                   encoder.scatter_variant)
         return (None, dtable, None, *grads, None, None, None, None, None, None, None, None, None)
 
 

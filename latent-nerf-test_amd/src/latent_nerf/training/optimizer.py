@@ -12,12 +12,19 @@ from ..raymarching.raymarching import _p, _stream
 
 
 class FusedAdam:
-    def __init__(self, param_groups, betas=(0.9, 0.99), eps=1e-15, encoder=None, capturable=False):
+    def __init__(self, param_groups, betas=(0.9, 0.99), eps=1e-15, encoder=None, capturable=False,
+                 fuse_table_update=False):
         """param_groups: [{'params': [...], 'lr': float}, ...] (as NeRFNetwork.get_params(lr)).
-        encoder: the GridEncoder whose `embeddings` are in the groups (for the bf16 shadow refresh)."""
+        encoder: the GridEncoder whose `embeddings` are in the groups (for the bf16 shadow refresh).
+        fuse_table_update: the hash table's Adam step can be applied by the scatter of the backward pass
+        (lnerf_grid_encode_backward_adam) instead of by step(): call arm() right before the step's backward
+        (single process, ONE backward per step; set the `grad_scale` attribute first if it is not 1).  A step
+        whose backward was not armed takes the ordinary path."""
         self.betas, self.eps = betas, eps
         self.encoder = encoder
         self.step_no = 0
+        self.grad_scale = 1.0
+        self.fused = None
         # capturable: the step counter lives on the device so that a hipGraph of the whole step can be replayed
         self.capturable = capturable
         self.step_dev = None
@@ -26,7 +33,8 @@ class FusedAdam:
         for group in param_groups:
             for p in group["params"]:
                 entry = (p, torch.zeros_like(p), torch.zeros_like(p), float(group["lr"]))
-                (self.big if p.numel() >= (1 << 20) else self.small).append(entry)
+                is_table = encoder is not None and p is encoder.embeddings
+                (self.big if (is_table or p.numel() >= (1 << 20)) else self.small).append(entry)
         if len(self.small) > 16:
             raise ValueError("FusedAdam handles at most 16 small tensors per launch")
         n = len(self.small)
@@ -39,12 +47,46 @@ class FusedAdam:
         if capturable:
             dev = (self.big + self.small)[0][0].device
             self.step_dev = torch.ones(1, device=dev, dtype=torch.int32)  # value used by the NEXT step
+        if fuse_table_update:
+            if encoder is None:
+                raise ValueError("fuse_table_update needs the encoder")
+            from ..models.encoding import FusedTableUpdate
+            for p, m, v, lr in self.big:
+                if p is encoder.embeddings:
+                    self.fused = FusedTableUpdate(m, v, lr, betas, eps, self)
+                    encoder.fused_update = self.fused
+            if self.fused is None:
+                raise ValueError("fuse_table_update: encoder.embeddings is not among the parameters")
 
-    def step(self, grad_scale=1.0, set_to_none=True):
+    def arm(self):
+        """Let the NEXT backward through the encoder apply the table's Adam step (no-op without fuse_table_update)."""
+        if self.fused is not None:
+            self.fused.armed = True
+
+    def zero_grad(self):
+        """`optimizer.zero_grad()` of src/latent_paint/training/trainer.py:127 (gradients are dropped, not zeroed)."""
+        for p, *_ in self.big + self.small:
+            p.grad = None
+        if self.fused is not None and (self.fused.armed or self.fused.applied):
+            raise RuntimeError("FusedAdam.zero_grad(): a fused table update is pending or already applied this step")
+
+    def step(self, grad_scale=None, set_to_none=True):
+        if grad_scale is None:
+            grad_scale = self.grad_scale
+        elif self.fused is not None and float(grad_scale) != float(self.grad_scale):
+            raise RuntimeError("FusedAdam: with fuse_table_update set `optimizer.grad_scale` before backward()")
         self.step_no += 1
         b1, b2 = self.betas
         enc = self.encoder
         for p, m, v, lr in self.big:
+            if self.fused is not None and p is enc.embeddings and (self.fused.applied or self.fused.armed):
+                # (a captured graph replays the single update it recorded)
+                if self.fused.applied != 1 or self.fused.armed or p.grad is not None:
+                    raise RuntimeError("FusedAdam: an armed step needs exactly one backward through the encoder "
+                                       "(fused updates applied: %d, still armed: %s, extra table gradient: %s)"
+                                       % (self.fused.applied, self.fused.armed, p.grad is not None))
+                self.fused.applied = 0
+                continue
             if p.grad is None:
                 continue
             shadow = enc.shadow() if (enc is not None and p is enc.embeddings) else None

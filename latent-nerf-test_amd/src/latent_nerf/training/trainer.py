@@ -46,8 +46,10 @@ class Trainer:
         self.nerf = NeRFNetwork(cfg.render).to(self.device)
         self.diffusion = guidance if guidance is not None else self.init_diffusion()
         self.text_z = self.calc_text_embeddings()
+        n_views = len(D.views_for_rank(max(cfg.optim.views_per_step, self.world), self.rank, self.world))
+        fuse = bool(cfg.optim.fuse_table_update) and self.world == 1 and n_views == 1
         self.optimizer = FusedAdam(self.nerf.get_params(cfg.optim.lr), betas=(0.9, 0.99), eps=1e-15,
-                                   encoder=self.nerf.encoder)
+                                   encoder=self.nerf.encoder, fuse_table_update=fuse)
         small = [p for p in self.nerf.parameters() if p is not self.nerf.encoder.embeddings]
         self.grad_sync = D.GradSync([self.nerf.encoder.embeddings], small)
         self.dataloaders = self.init_dataloaders()
@@ -136,8 +138,11 @@ class Trainer:
             self.train_step += 1
             if self.nerf.cuda_ray and (self.train_step - 1) % self.cfg.render.update_extra_interval == 0:
                 self.nerf.update_extra_state()
+            self.optimizer.zero_grad()
             for v in views:
                 data = ds.collate(0, generator=D.pose_generator(self.cfg.optim.seed, self.train_step, v))
+                if len(views) == 1:
+                    self.optimizer.arm()   # one view, one process: the scatter applies the table's Adam step
                 self.train_render(data)
             self.grad_sync.allreduce()
             self.optimizer.step(grad_scale=1.0 / (len(views) * self.world))

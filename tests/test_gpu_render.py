@@ -251,3 +251,79 @@ def test_graphed_step_matches_eager(dev):
         assert float((net.w2.detach() - before).abs().max()) > 0
         assert bool(torch.isfinite(net.encoder.embeddings).all())
     torch.cuda.synchronize()
+
+
+def _run_steps(dev, fuse, precision, log2_T, steps=3):
+    from src.latent_nerf.training.optimizer import FusedAdam
+    G, HW = 64, 32
+    net, cfg, lv, table, params, grid = _make(dev, G, HW, log2_T, 16, seed=7, mlp_precision=precision,
+                                              table_dtype=precision)
+    net.train()
+    opt = FusedAdam(net.get_params(1e-2), encoder=net.encoder, fuse_table_update=fuse)
+    gen = torch.Generator().manual_seed(3)
+    bg = torch.rand(HW * HW, 4, generator=gen).to(dev)
+    for k in range(steps):
+        ro, rd = _rays(HW, 60.0, 25.0 * k, 1.3)
+        g = (torch.randn(1, HW * HW, 4, generator=gen) * 0.3).to(dev)
+        out = net.render(ro.to(dev), rd.to(dev), bg_color=bg, perturb=False)
+        opt.arm()
+        out["image"].backward(gradient=g)
+        opt.step()
+    torch.cuda.synchronize()
+    emb = net.encoder.embeddings
+    m, v = [(e[1], e[2]) for e in opt.big if e[0] is emb][0]
+    sh = net.encoder.shadow()
+    return (emb.detach().clone(), m.clone(), v.clone(), None if sh is None else sh.clone(), net.w2.detach().clone(),
+            emb.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,log2_T", [("f32", 19), ("bf16", 19), ("bf16", 14)])
+def test_fused_table_update_matches_backward_plus_adam(dev, precision, log2_T):
+    """lnerf_grid_encode_backward_adam (Adam step of the hash table inside the scatter's reduce pass) against
+    backward + FusedAdam.step() after one step: table, moments and bf16 shadow.  Levels whose buckets are reduced
+    by ONE workgroup (the 2^19-row levels: 5..15) must agree bit for bit -- same sums, same Adam arithmetic.  The
+    coarse levels are summed by several slice workgroups with float atomics in both paths (order-dependent
+    rounding, 1 ulp run to run), so they are compared to 1e-5 relative.  2^14 rows per level: nothing is fused,
+    the entry point must still be right.  Three further steps must stay finite and keep moving the table."""
+    ref = _run_steps(dev, False, precision, log2_T, steps=1)
+    got = _run_steps(dev, True, precision, log2_T, steps=1)
+    assert got[5] is None            # the table never gets a .grad in fused mode
+    net0 = _make(dev, 64, 32, log2_T, 16, seed=7)[0]
+    offs = net0.encoder.levels.offsets
+    exact_from = offs[5] if log2_T == 19 else offs[16]
+    for name, a, b in zip(("table", "exp_avg", "exp_avg_sq", "shadow"), got[:4], ref[:4]):
+        if a is None and b is None:
+            continue
+        assert torch.equal(a[exact_from:], b[exact_from:]), (name, float((a.float() - b.float())[exact_from:].abs().max()))
+        e = (a.float() - b.float())[:exact_from].abs()
+        atol = {"table": 1e-6, "exp_avg": 1e-9, "exp_avg_sq": 1e-12, "shadow": 1e-2}[name]
+        tol = 1e-5 * b.float()[:exact_from].abs() + atol
+        assert bool((e <= tol).all()), (name, float(e.max()))
+    assert torch.equal(got[4], ref[4])  # the MLP weights take the ordinary path in both
+    assert float((got[0] - net0.encoder.embeddings.detach()).abs().max()) > 0
+    more = _run_steps(dev, True, precision, log2_T, steps=4)
+    assert bool(torch.isfinite(more[0]).all()) and float((more[0] - got[0]).abs().max()) > 0
+
+
+@pytest.mark.gpu
+def test_fused_table_update_arming(dev):
+    """Only an armed backward applies the fused update; an unarmed one yields the ordinary table gradient, and a step
+    that mixes both is refused."""
+    from src.latent_nerf.training.optimizer import FusedAdam
+    net, cfg, lv, table, params, grid = _make(dev, 64, 32, 14, 16, seed=1)
+    net.train()
+    opt = FusedAdam(net.get_params(1e-3), encoder=net.encoder, fuse_table_update=True)
+    ro, rd = _rays(32)
+    g = torch.randn(1, 32 * 32, 4, device=dev)
+    emb = net.encoder.embeddings
+    before = emb.detach().clone()
+    net.render(ro.to(dev), rd.to(dev), perturb=False)["image"].backward(gradient=g)   # unarmed: plain gradient
+    assert emb.grad is not None and torch.equal(emb.detach(), before)
+    opt.step()                                                                         # ordinary Adam step
+    assert float((emb.detach() - before).abs().max()) > 0 and emb.grad is None
+    opt.arm()
+    for _ in range(2):   # the first backward takes the arm, the second leaves a gradient behind
+        net.render(ro.to(dev), rd.to(dev), perturb=False)["image"].backward(gradient=g)
+    with pytest.raises(RuntimeError, match="exactly one backward"):
+        opt.step()
