@@ -65,15 +65,6 @@ __device__ __forceinline__ void build_fragments(const MlpArgs &a, __bf16 *frag, 
     }
 }
 
-// Make the compiler wait for a prefetched fragment HERE (before a batch of stores) rather than at its first use in
-// the next loop iteration, where the single in-order memory counter would also make it wait for those stores.
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void pin(bf16x8 &v) {
-    u32x4_t r = *reinterpret_cast<u32x4_t *>(&v);
-    asm volatile("" : "+v"(r));
-    *reinterpret_cast<u32x4_t *>(&v) = r;
-}
-
 __device__ __forceinline__ bf16x8 ld_frag(const __bf16 *frag, int f, int lane) {
     return *reinterpret_cast<const bf16x8 *>(frag + (f * 64 + lane) * 8);
 }
@@ -173,37 +164,18 @@ k_mlp_forward_bf16(MlpArgs a, float *__restrict__ sigmas, float *__restrict__ rg
     if (tid < 16) sB3[tid] = tid < a.out_dim ? a.b3[tid] : 0.f;
     __syncthreads();
     const int nrgb = a.out_dim - 1;
-    // the features of the NEXT tile are fetched while this one runs through the matrix cores (the kernel is
-    // persistent: ~7 tiles per workgroup, each of which would otherwise start with an exposed HBM round trip)
-    bf16x8 xN[2];
-    {
-        const int64_t m0 = (int64_t)blockIdx.x * 128 + w * 32;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) xN[t] = load_x(a, m0 + 16 * t + c, m0 + 16 * t + c < M, q);
-    }
     for (int64_t tile = blockIdx.x; tile * 128 < M; tile += gridDim.x) {
         const int64_t m0 = tile * 128 + w * 32;
         bf16x8 xB[2], h1B[2][2], h2B[2][2];
-        xB[0] = xN[0]; xB[1] = xN[1];
-        {
-            const int64_t n0 = (tile + gridDim.x) * 128 + w * 32;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) xN[t] = load_x(a, n0 + 16 * t + c, n0 + 16 * t + c < M, q);
-        }
+        for (int t = 0; t < 2; ++t) xB[t] = load_x(a, m0 + 16 * t + c, m0 + 16 * t + c < M, q);
         forward_hidden(frag, sB1, sB2, lane, xB, h1B, h2B);
         const f32x4 b3 = ld_bias4(sB3, 4 * q);
-        f32x4 o2[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            o2[t] = b3;
+            f32x4 o = b3;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) o2[t] = MFMA32(ld_frag(frag, F_W3A + s, lane), h2B[s][t], o2[t]);
-        }
-        pin(xN[0]);
-        pin(xN[1]);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const f32x4 o = o2[t];
+            for (int s = 0; s < 2; ++s) o = MFMA32(ld_frag(frag, F_W3A + s, lane), h2B[s][t], o);
             const int64_t m = m0 + 16 * t + c;  // lane holds h[4q + r] of sample m
             if (m < M) {
 #pragma unroll
@@ -253,9 +225,11 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
     for (int i = 0; i < 4; ++i) gW2[i] = zero4;
     gW1[0] = gW1[1] = zero4;
 
-    // dZ3^T as a B fragment: slot (q, jj < 4) <-> output 4q + jj; returns whether any entry is non-zero
-    auto load_d3 = [&](int64_t m0, bf16x8 d3[2]) -> bool {
-        bool any = false;
+    for (int64_t tile = blockIdx.x; tile * 128 < M; tile += gridDim.x) {
+        const int64_t m0 = tile * 128 + w * 32;
+        bf16x8 xB[2], h1B[2][2], h2B[2][2], dzB[2][2], d3B[2];
+        // ---- dZ3^T as a B fragment: slot (q, jj < 4) <-> output 4q + jj
+        bool live = false;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int64_t m = m0 + 16 * t + c;
@@ -265,34 +239,13 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
                 float v = 0.f;
                 if (jj < 4 && n < a.out_dim && m < M)
                     v = n == 0 ? dsigmas[m] * fminf(sigmas[m], e15) : drgbs[m * nrgb + (n - 1)];
-                d3[t][jj] = (__bf16)v;
-                any = any || (v != 0.f);
+                d3B[t][jj] = (__bf16)v;
+                live = live || (v != 0.f);
             }
-        }
-        return any;
-    };
-    // the features of the NEXT tile are fetched while this one computes (persistent kernel, ~7 tiles per workgroup;
-    // fetching its upstream gradients as well costs 16 more registers and spills)
-    bf16x8 xN[2];
-    {
-        const int64_t m0 = (int64_t)blockIdx.x * 128 + w * 32;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) xN[t] = load_x(a, m0 + 16 * t + c, m0 + 16 * t + c < M, q);
-    }
-    for (int64_t tile = blockIdx.x; tile * 128 < M; tile += gridDim.x) {
-        const int64_t m0 = tile * 128 + w * 32;
-        bf16x8 xB[2], h1B[2][2], h2B[2][2], dzB[2][2], d3B[2];
-        const bool live = load_d3(m0, d3B);
-        xB[0] = xN[0]; xB[1] = xN[1];
-        {
-            const int64_t n0 = (tile + gridDim.x) * 128 + w * 32;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) xN[t] = load_x(a, n0 + 16 * t + c, n0 + 16 * t + c < M, q);
         }
         // 128 samples whose upstream gradient is exactly zero (rays past their termination point: the
         // compositing backward writes zeros there) contribute nothing to any gradient: dfeat = 0, done
         if (!__syncthreads_or(live ? 1 : 0)) {
-            pin(xN[0]); pin(xN[1]);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int64_t m = m0 + 16 * t + c;
@@ -305,6 +258,8 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
             }
             continue;  // uniform for the whole workgroup
         }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) xB[t] = load_x(a, m0 + 16 * t + c, m0 + 16 * t + c < M, q);
         forward_hidden(frag, sB1, sB2, lane, xB, h1B, h2B);
         // ================= stage 1: dW3 += dZ3^T (x) H2^T
         __syncthreads();  // previous step's readers of imgA/imgD are done
@@ -398,7 +353,6 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
             gB1 = MFMA32(dA, ones, gB1);
         }
         // ---- dX = W1^T dZ1 -> dfeat (level-major f32): lane holds features 16mt + 4q + r of its sample
-        pin(xN[0]); pin(xN[1]);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             f32x4 ax[2] = {zero4, zero4};
