@@ -71,8 +71,7 @@ const char *lnerf_build_info(void);
  *   "scatter_skip_zero":       1 (default) = contributions that are exactly zero are not binned.
  *   "scatter_bin_tile":        samples per binning tile, 256 or 512 (default 512).
  *   "scatter_reduce_threads":  threads per workgroup of the reduce pass, 512 or 1024 (default 1024).
- *   "scatter_bin_staged":      1 (default) = records grouped per bucket in LDS and written coalesced,
- *                              0 = every lane stores its own records. */
+ */
 int lnerf_set_tuning(const char *key, int value);
 
 /* ---- H1: ray generation (absent upstream: `get_rays` of nerf_utils; camera convention

@@ -369,16 +369,15 @@ __global__ void __launch_bounds__(BIN_T, BIN_T == 512 ? 6 : (BIN_T == 1024 ? 4 :
 k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict__ dfeat, GridMeta meta, BucketMeta bm,
               int64_t m_host, const int32_t *__restrict__ m_dev, int64_t level_stride, int32_t *__restrict__ cursor,
               unsigned int *__restrict__ gmax, REC *__restrict__ recs, float *__restrict__ dtable, int variant,
-              int staged, int skip_zero, int level_lo, int dbg) {
-    __shared__ int s_cnt[BK_MAX_PER_LEVEL];   // records of this tile per bucket
+              int skip_zero, int level_lo, int dbg) {
+    __shared__ int s_cnt[2][BK_MAX_PER_LEVEL];  // records of this tile per bucket (double-buffered per item)
     __shared__ int s_base[BK_MAX_PER_LEVEL];  // first slot reserved in the bucket's global region
     __shared__ int s_off[BK_MAX_PER_LEVEL];   // first slot of the bucket in the LDS stage
-    __shared__ unsigned int s_max;            // bit pattern of the tile's largest |value|
+    __shared__ unsigned int s_max[2];         // bit pattern of the tile's largest |value|
     __shared__ int s_dest[BK_MAX_PER_LEVEL];  // global slot of the bucket's first staged record, minus its stage offset
-    __shared__ int s_ovf;                     // some bucket of this tile ran past its region
+    __shared__ int s_ovf[2];                  // some bucket of this tile ran past its region
     __shared__ REC s_stage[BIN_T * 8];        // the tile's records, grouped by bucket (48 KiB, 32 KiB packed)
     __shared__ uint8_t s_bkt[REC::kPacked ? BIN_T * 8 : 4];  // packed records do not name their bucket: kept beside
-    __shared__ int s_total;
     int64_t M = m_host;
     if (m_dev) { const int64_t md = *m_dev; M = md < M ? md : M; }
     const int L = meta.num_levels;
@@ -420,7 +419,14 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
     bool have = locate(0, l, tile);
     if (have) fetch(l, tile);
     BIN_STAMP_INIT();
+    for (int i = tid; i < BK_MAX_PER_LEVEL; i += BIN_T) s_cnt[0][i] = 0;
+    if (tid == 0) { s_max[0] = 0u; s_ovf[0] = 0; }
+    __syncthreads();
     for (int64_t k = 0; have; ++k) {
+        // Two barriers per item.  Counters, tile maximum and overflow flag are double-buffered (set k & 1): the set
+        // of the next item is cleared after barrier 1, when every wave has left the previous item, and nobody
+        // touches it before barrier 3 has been passed.
+        const int cur = (int)(k & 1);
         const float scale = meta.scales[l];
         const uint32_t res = (uint32_t)meta.res[l];
         const uint32_t off = (uint32_t)meta.offsets[l];
@@ -430,66 +436,43 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
         const bool few_buckets = nb <= 32;        // wave-uniform: rank with ballots instead of per-lane LDS atomics
         REC *lrec = recs + bm.rstart[l];
         float *lt = dtable + (int64_t)off * 2;
-        for (int i = tid; i < nb; i += BIN_T) s_cnt[i] = 0;
-        if (tid == 0) { s_max = 0u; s_ovf = 0; }
-        __syncthreads();
-        BIN_STAMP(0);  // entry, counter reset, barrier
+        BIN_STAMP(0);
         const int64_t m = tile * BIN_T + tid;
         const bool valid = m < M;
-        uint32_t row[8];
-        float v0[8], v1[8];
-        int rank[8];
-        uint32_t emit = 0;  // bit c: this lane appends a record for corner c
         int l_next = 0;
         int64_t tile_next = 0;
         const bool have_next = locate(k + 1, l_next, tile_next);
-        {
-            LevelPos p;
-            p.gx = p.gy = p.gz = 0; p.fx = p.fy = p.fz = 0.f;
-            const float2 gg = n_gg;
-            // a wavefront whose 64 samples all carry a zero gradient (rays past their termination point) has
-            // nothing to bin: skip its index arithmetic, it only keeps the workgroup's barriers company
-            const bool wave_live = !skip_zero || __ballot(valid && (gg.x != 0.f || gg.y != 0.f)) != 0ull;
-            BIN_STAMP(1);  // inputs (prefetched)
-            if (wave_live) {
+        // ---- A: cell, rows, runs, and WHICH lanes append records.  Samples behind a ray's termination point
+        // (T < T_thresh) get dsigma = drgb = 0 from the compositing backward, hence dfeat = 0 exactly: a run (or
+        // sample) whose gradients are all zero appends nothing, and a wavefront of 64 such samples skips its
+        // index arithmetic altogether.  The values themselves are computed later, behind the reservations.
+        const float2 gg = n_gg;
+        const bool nzg = valid && (gg.x != 0.f || gg.y != 0.f);
+        const unsigned long long nzmask = __ballot(nzg);
+        const bool wave_live = !skip_zero || nzmask != 0ull;
+        LevelPos p;
+        p.gx = p.gy = p.gz = 0; p.fx = p.fy = p.fz = 0.f;
+        RunInfo ri;
+        ri.start = lane; ri.tail = true;
+        uint32_t row[8];
+        int rank[8];
+        uint32_t emit = 0;  // bit c: this lane appends a record for corner c
+        if (wave_live) {
             if (valid) p = level_pos_xyz(n_x, n_y, n_z, bound, scale);
-            BIN_STAMP(2);
             corner_rows(p.gx, p.gy, p.gz, res, hsize, row);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const uint32_t bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
-                const float wx = bx ? p.fx : 1.0f - p.fx;
-                const float wy = by ? p.fy : 1.0f - p.fy;
-                const float wz = bz ? p.fz : 1.0f - p.fz;
-                const float w = (wx * wy) * wz;
-                v0[c] = w * gg.x;
-                v1[c] = w * gg.y;
-            }
             if (compact) {  // wave-uniform branch
-                const RunInfo ri = wave_cell_runs(p.gx, p.gy, p.gz, valid);
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    v0[c] = run_sum(v0[c], ri);
-                    v1[c] = run_sum(v1[c], ri);
-                }
-                emit = (valid && ri.tail) ? 0xFFu : 0u;
+                ri = wave_cell_runs(p.gx, p.gy, p.gz, valid);
+                const unsigned long long seg = (nzmask >> ri.start) & ((2ull << (lane - ri.start)) - 1ull);
+                emit = (valid && ri.tail && (!skip_zero || seg != 0ull)) ? 0xFFu : 0u;
             } else {
-                emit = valid ? 0xFFu : 0u;
+                emit = (valid && (!skip_zero || nzg)) ? 0xFFu : 0u;
             }
-            // contributions that are exactly zero add nothing: samples behind a ray's termination point
-            // (T < T_thresh) get dsigma = drgb = 0 from the compositing backward, hence dfeat = 0 -- on an
-            // opaque scene that is a large share of all samples
-            uint32_t nz = 0;
+        } else {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) nz |= ((v0[c] != 0.f || v1[c] != 0.f) ? 1u : 0u) << c;
-            if (skip_zero) emit &= nz;
-            } else {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) { row[c] = 0u; v0[c] = 0.f; v1[c] = 0.f; }
-            }
+            for (int c = 0; c < 8; ++c) row[c] = 0u;
         }
-        BIN_STAMP(3);  // rows, weights, run compaction
-        // ---- rank every record inside its bucket (tile-local)
+        BIN_STAMP(1);
+        // ---- B: rank every record inside its bucket (tile-local)
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const bool e = (emit >> c) & 1u;
@@ -502,87 +485,88 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
                     const int bl = __builtin_amdgcn_readlane(b, leader);
                     const unsigned long long mm = __ballot(e && b == bl);
                     int base = 0;
-                    if (lane == leader) base = atomicAdd(&s_cnt[bl], __popcll(mm));
+                    if (lane == leader) base = atomicAdd(&s_cnt[cur][bl], __popcll(mm));
                     base = __builtin_amdgcn_readlane(base, leader);
                     if (e && b == bl) rank[c] = base + mbcnt(mm);
                     todo &= ~mm;
                 }
             } else if (e) {
-                rank[c] = atomicAdd(&s_cnt[b], 1);
+                rank[c] = atomicAdd(&s_cnt[cur][b], 1);
             }
         }
-        {   // largest |value| of the tile: per-lane max, DPP wave max, one LDS atomic per wave (+floats order as uints)
+        BIN_STAMP(2);
+        __syncthreads();  // barrier 1: the tile's bucket counts are final
+        BIN_STAMP(3);
+        for (int i = tid; i < BK_MAX_PER_LEVEL; i += BIN_T) s_cnt[cur ^ 1][i] = 0;
+        if (tid == 0) { s_max[cur ^ 1] = 0u; s_ovf[cur ^ 1] = 0; }
+        // ---- C: ONE returning global atomic per touched bucket reserves its span; the next item's inputs follow
+        // them into the memory queue; both are consumed after the arithmetic below
+        int my_base[(BK_MAX_PER_LEVEL + BIN_T - 1) / BIN_T];
+#pragma unroll
+        for (int kk = 0; kk < (BK_MAX_PER_LEVEL + BIN_T - 1) / BIN_T; ++kk) {
+            const int i = tid + kk * BIN_T;
+            my_base[kk] = 0;
+            if (i < nb) {
+                const int c = s_cnt[cur][i];
+                // dbg (TIMING-ONLY experiments, wrong results): 1 = no reservation, every tile writes slots 0.. of
+                // the bucket; 2 = reservations made, stores folded into the first 64 slots of the bucket
+                if (c && !(dbg & 1)) my_base[kk] = atomicAdd(&cursor[b0 + i], c);
+            }
+        }
+        if (have_next) fetch(l_next, tile_next);
+        // ---- D: the values w * g (run sums on coarse levels) and the tile's largest |value|
+        float v0[8], v1[8];
+        if (wave_live) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint32_t bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
+                const float wx = bx ? p.fx : 1.0f - p.fx;
+                const float wy = by ? p.fy : 1.0f - p.fy;
+                const float wz = bz ? p.fz : 1.0f - p.fz;
+                const float w = (wx * wy) * wz;
+                v0[c] = w * gg.x;
+                v1[c] = w * gg.y;
+            }
+            if (compact) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    v0[c] = run_sum(v0[c], ri);
+                    v1[c] = run_sum(v1[c], ri);
+                }
+            }
             float mx = 0.f;
 #pragma unroll
             for (int c = 0; c < 8; ++c)
                 if ((emit >> c) & 1u) mx = fmaxf(mx, fmaxf(fabsf(v0[c]), fabsf(v1[c])));
-            mx = wave_max_nonneg(mx);
-            if (lane == 0 && mx > 0.f) atomicMax(&s_max, __float_as_uint(mx));
-        }
-        BIN_STAMP(4);  // ranking (LDS counters) + tile max
-        __syncthreads();
-        BIN_STAMP(5);  // barrier 1 (waiting for the slowest wave)
-        // ---- exclusive scan of the tile's bucket counts (wave 0); the global reservations (one
-        //      returning atomic per touched bucket) are issued now and consumed after the staging
-        int my_base[(BK_MAX_PER_LEVEL + BIN_T - 1) / BIN_T];
+            mx = wave_max_nonneg(mx);  // DPP wave max, one LDS atomic per wave (+floats order as uints)
+            if (lane == 0 && mx > 0.f) atomicMax(&s_max[cur], __float_as_uint(mx));
+        } else {
 #pragma unroll
-        for (int k = 0; k < (BK_MAX_PER_LEVEL + BIN_T - 1) / BIN_T; ++k) {
-            const int i = tid + k * BIN_T;
-            my_base[k] = 0;
-            if (i < nb) {
-                const int c = s_cnt[i];
-                // dbg (TIMING-ONLY experiments, wrong results): 1 = no reservation, every tile writes slots 0.. of
-                // the bucket; 2 = reservations made, stores folded into the first 64 slots of the bucket
-                if (c && !(dbg & 1)) my_base[k] = atomicAdd(&cursor[b0 + i], c);
-            }
+            for (int c = 0; c < 8; ++c) { v0[c] = 0.f; v1[c] = 0.f; }
         }
-        if (have_next) fetch(l_next, tile_next);  // behind the reservations in the memory queue, ahead of the stores
-        BIN_STAMP(6);  // global reservations (returning atomics), waited for
-        if (!staged) {  // direct mode: every lane stores its own records as soon as the reservations are known
-#pragma unroll
-            for (int k = 0; k < (BK_MAX_PER_LEVEL + BIN_T - 1) / BIN_T; ++k) {
-                const int i = tid + k * BIN_T;
-                if (i < nb) s_base[i] = my_base[k];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                if ((emit >> c) & 1u) {
-                    const int b = (int)(row[c] >> BK_SHIFT);
-                    const int slot = s_base[b] + rank[c];
-                    if (slot < cap) {
-                        lrec[(int64_t)b * cap + slot] = REC::make(row[c], v0[c], v1[c]);
-                    } else {
-                        atomicAdd(lt + (int64_t)row[c] * 2, v0[c]);
-                        atomicAdd(lt + (int64_t)row[c] * 2 + 1, v1[c]);
-                    }
-                }
-            }
-            l = l_next; tile = tile_next; have = have_next;
-            continue;  // uniform: `staged` is a kernel argument
-        }
-        if (tid == BIN_T - 1 && s_max != 0u) atomicMax(&gmax[l], s_max);  // one value per LEVEL
-        if (tid < 64) {  // nb <= 256 -> 4 buckets per lane
+        BIN_STAMP(4);
+        // ---- E: exclusive scan of the bucket counts.  EVERY wave computes it (4 buckets per lane, one DPP scan) and
+        // writes the same offsets: a wave reads s_off only after its own writes, so no barrier and no idle waves
+        int total;
+        {
             int c4[4], sum = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = tid * 4 + k;
-                c4[k] = i < nb ? s_cnt[i] : 0;
-                sum += c4[k];
+            for (int kk = 0; kk < 4; ++kk) {
+                const int i = lane * 4 + kk;
+                c4[kk] = i < nb ? s_cnt[cur][i] : 0;
+                sum += c4[kk];
             }
             const int inc = wave_inclusive_sum_i(sum);
             int run = inc - sum;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = tid * 4 + k;
+            for (int kk = 0; kk < 4; ++kk) {
+                const int i = lane * 4 + kk;
                 if (i < nb) s_off[i] = run;
-                run += c4[k];
+                run += c4[kk];
             }
-            if (tid == 63) s_total = inc;
+            total = __builtin_amdgcn_readlane(inc, 63);
         }
-        __syncthreads();
-        BIN_STAMP(7);  // bucket-count scan + barrier 2
-        // ---- group the records by bucket in LDS
+        // ---- F: group the records by bucket in LDS
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             if ((emit >> c) & 1u) {
@@ -592,27 +576,29 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
                 if (REC::kPacked) s_bkt[slot] = (uint8_t)b;
             }
         }
+        BIN_STAMP(5);
 #pragma unroll
-        for (int k = 0; k < (BK_MAX_PER_LEVEL + BIN_T - 1) / BIN_T; ++k) {
-            const int i = tid + k * BIN_T;
+        for (int kk = 0; kk < (BK_MAX_PER_LEVEL + BIN_T - 1) / BIN_T; ++kk) {  // waits for the reservations
+            const int i = tid + kk * BIN_T;
             if (i < nb) {
-                s_base[i] = my_base[k];
-                s_dest[i] = i * cap + ((dbg & 2) ? (my_base[k] & 63) : my_base[k]) - s_off[i];
-                if (!(dbg & 2) && my_base[k] + s_cnt[i] > cap) s_ovf = 1;
+                s_base[i] = my_base[kk];
+                s_dest[i] = i * cap + ((dbg & 2) ? (my_base[kk] & 63) : my_base[kk]) - s_off[i];
+                if (!(dbg & 2) && my_base[kk] + s_cnt[cur][i] > cap) s_ovf[cur] = 1;
             }
         }
-        __syncthreads();
-        BIN_STAMP(8);  // staging + barrier 3
+        BIN_STAMP(6);
+        __syncthreads();  // barrier 3: stage, destinations, tile maximum complete
+        BIN_STAMP(7);
+        if (tid == BIN_T - 1 && s_max[cur] != 0u) atomicMax(&gmax[l], s_max[cur]);  // one value per LEVEL
         // the prefetched inputs are pinned in registers here, so that the next item starts without waiting for the
         // stores below to be acknowledged (one in-order memory counter covers loads and stores)
         asm volatile("" : "+v"(n_gg.x), "+v"(n_gg.y), "+v"(n_x), "+v"(n_y), "+v"(n_z));
-        // ---- copy out: consecutive lanes -> consecutive slots of (mostly) the same bucket: coalesced
-        const int total = s_total;
+        // ---- G: copy out: consecutive lanes -> consecutive slots of (mostly) the same bucket: coalesced
         auto bucket_of = [&](const REC &r, int i) -> int {
             if constexpr (REC::kPacked) return (int)s_bkt[i];
             else return (int)(r.row >> BK_SHIFT);
         };
-        if (!s_ovf) {  // uniform fast path: every record of the tile has a slot
+        if (!s_ovf[cur]) {  // uniform fast path: every record of the tile has a slot
             for (int i = tid; i < total; i += BIN_T) {
                 const REC r = s_stage[i];
                 lrec[s_dest[bucket_of(r, i)] + i] = r;
@@ -631,9 +617,9 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
                 }
             }
         }
-        BIN_STAMP(9);  // copy-out, stores completed
-        // the next iteration's first barrier orders these LDS reads before s_stage/s_off are rewritten
-        // (s_cnt is only re-zeroed, and nobody reads it after the barrier above)
+        BIN_STAMP(8);
+        // (the next item rewrites s_off / s_stage / s_dest only after ITS barrier 1, which every wave reaches after
+        // finishing the copy-out above)
         l = l_next; tile = tile_next; have = have_next;
     }
     BIN_STAMP_FLUSH();
@@ -813,8 +799,6 @@ static int g_gather_pairs = 1;
 static int g_bin_map = 2;
 // persistent workgroups of map 2 (3 per CU fit the 52 KiB LDS stage: 768 on 256 CUs)
 static int g_bin_wgs = 768;
-// 1: group a tile's records by bucket in LDS and copy them out coalesced; 0: every lane stores its own records
-static int g_bin_staged = 1;
 // samples per binning tile (256 or 512)
 static int g_bin_tile = 512;
 // drop contributions that are exactly zero (samples behind a ray's termination point)
@@ -995,10 +979,6 @@ int lnerf_set_tuning(const char *key, int value) {
         g_bin_tile = value;
         return LNERF_OK;
     }
-    if (strcmp(key, "scatter_bin_staged") == 0) {
-        g_bin_staged = value ? 1 : 0;
-        return LNERF_OK;
-    }
     if (strcmp(key, "scatter_reduce_threads") == 0) {
         LNERF_REQUIRE(value == 512 || value == 1024, "set_tuning: scatter_reduce_threads must be 512 or 1024");
         g_reduce_threads = value;
@@ -1106,7 +1086,7 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
         }
 #define LAUNCH_BIN(T, REC)                                                                                          \
     hipLaunchKernelGGL((k_scatter_bin<float, T, REC>), g, dim3(T), 0, s, xyzs, bound, (const float *)dfeat, meta, bm, \
-                       m_host, m_dev, level_stride, cursor, gmax, (REC *)rec, dtable, g_bin_map, g_bin_staged,      \
+                       m_host, m_dev, level_stride, cursor, gmax, (REC *)rec, dtable, g_bin_map,                    \
                        g_skip_zero, l0, g_bin_dbg)
         if (packed) LAUNCH_BIN(512, Rec8);
         else if (BIN_T == 256) LAUNCH_BIN(256, Rec12);

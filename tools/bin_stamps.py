@@ -14,8 +14,9 @@ for _p in (ROOT, os.path.join(ROOT, "latent-nerf-test_amd")):
     sys.path.insert(0, _p)
 import torch  # noqa: E402
 
-PHASES = ["entry+reset+barrier", "dfeat load", "xyz loads", "rows+weights+compaction", "ranking (LDS counters)", "barrier 1",
-          "global reservations", "count scan + barrier 2", "staging + barrier 3", "copy-out"]
+PHASES = ["0 loop top", "1 A: cell, rows, runs, emit mask", "2 B: ranking (LDS counters)", "3 barrier 1",
+          "4 C+D: reservations + prefetch issued and waited for, values, tile max", "5 E+F: count scan, staging",
+          "6 destinations", "7 barrier 3", "8 G: copy-out, stores completed"]
 
 
 def main():
@@ -59,7 +60,7 @@ def main():
     tot = sum(buf[i] for i in range(len(PHASES)))
     res = {"M": M, "tiles_per_launch": tiles, "cycles_per_tile_total": round(tot / n / tiles, 1), "phases_cycles_per_tile": {}}
     for i, name in enumerate(PHASES):
-        res["phases_cycles_per_tile"]["%d %s" % (i, name)] = round(buf[i] / n / tiles, 1)
+        res["phases_cycles_per_tile"][name] = round(buf[i] / n / tiles, 1)
     print(json.dumps(res, indent=1))
 
 
