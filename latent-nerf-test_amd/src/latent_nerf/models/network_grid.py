@@ -31,6 +31,7 @@ class _SigmaLatentMLP(torch.autograd.Function):
         ctx.save_for_backward(feat, xyzs, w1, b1, w2, b2, w3, b3, sigmas,
                               m_dev if m_dev is not None else torch.empty(0))
         ctx.meta = (m_host, m_dev is not None, level_stride, blob_scale, blob_std, precision, workspace)
+        ctx.set_materialize_grads(False)
         return sigmas, rgbs
 
     @staticmethod
@@ -82,6 +83,7 @@ class _HashMLPField(torch.autograd.Function):
                               m_dev if m_dev is not None else torch.empty(0))
         ctx.meta = (encoder, bound, m_host, m_dev is not None, level_stride, blob_scale, blob_std, precision, workspace,
                     table.shape)
+        ctx.set_materialize_grads(False)
         return sigmas, rgbs
 
     @staticmethod

@@ -200,6 +200,7 @@ class _CompositeRaysTrain(torch.autograd.Function):
                 _chk(deltas, "deltas"), _chk(rays, "rays", torch.int32), N, C, float(T_thresh),
                 _chk(bg, "bg_color", allow_none=True), _p(weights_sum), _p(depth), _p(image), _stream())
         ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, depth, image, bg)
+        ctx.set_materialize_grads(False)  # unused outputs (depth, weights_sum) arrive as None, not as zero fills
         ctx.T_thresh = float(T_thresh)
         ctx.bg_needs_grad = bg_color is not None and bg_color.requires_grad
         return weights_sum, depth, image
