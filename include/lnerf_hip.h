@@ -134,8 +134,11 @@ int lnerf_grid_encode_forward(const float *xyzs, float bound, const void *table,
 /* dtable (f32, [rows, F]) is ACCUMULATED into (+=).
  * variant 0/1: per-lane global float atomics (blockIdx.y level map / XCD-aware map); no workspace.
  * variant 2  : two-pass bucketed scatter -- records binned per 64 KiB table chunk with plain
- *              stores, then reduced in LDS and added with coalesced stores; needs `workspace`
- *              of lnerf_grid_encode_backward_workspace_bytes() bytes (16-byte aligned).
+ *              stores, then reduced in LDS in 64-bit fixed point and added with coalesced stores
+ *              (heavily loaded coarse chunks are cut into slices whose exact integer partial sums a
+ *              small finishing kernel adds up): the sums do not depend on execution order, the
+ *              gradient is bitwise reproducible.  Needs `workspace` of
+ *              lnerf_grid_encode_backward_workspace_bytes() bytes (16-byte aligned).
  * variant 3  : variant 2 with packed 8-byte records (12-bit row inside the bucket + two values rounded
  *              to 26-bit floats, 17 mantissa bits): a third less record traffic, relative rounding
  *              2^-18 per addend; same workspace. */
@@ -146,13 +149,13 @@ int lnerf_grid_encode_backward(const float *xyzs, float bound, const void *dfeat
                                float *dtable, int variant, void *workspace, size_t workspace_bytes,
                                lnerf_stream_t stream);
 /* Backward of the hash grid fused with the table's optimiser step (single-GPU training: no gradient
- * exchange sits between the two).  Same scatter as above (variant 2 or 3), but on every level whose
- * buckets are reduced by one workgroup each, pass 2 applies Adam(beta1, beta2, eps) to its rows
- * straight from the LDS sums -- `table`, `exp_avg`, `exp_avg_sq` (f32 [rows, 2]) and the optional
- * bf16 `shadow_bf16` are updated in place and the gradient of those rows never reaches HBM.  The
- * few coarse rows below that level are summed into `dtable_zero` and finished with lnerf_adam_step.
- * `dtable_zero` (f32 [rows, 2]) must be ZERO on entry and is zero again on return.  Arithmetic and
- * results are identical to lnerf_grid_encode_backward + lnerf_adam_step (one shared definition).
+ * exchange sits between the two).  Same scatter as above (variant 2 or 3), but the kernel that
+ * finishes a row's sum (pass 2, or the finishing kernel of the sliced coarse levels) applies
+ * Adam(beta1, beta2, eps) to it straight from the fixed-point sum -- `table`, `exp_avg`, `exp_avg_sq`
+ * (f32 [rows, 2]) and the optional bf16 `shadow_bf16` are updated in place and the gradient never
+ * reaches HBM.  `dtable_zero` (f32 [rows, 2]) only carries the records of overflowing buckets; it
+ * must be ZERO on entry and is zero again on return.  Arithmetic and results are bit-identical to
+ * lnerf_grid_encode_backward + lnerf_adam_step (one shared definition).
  * Covers `optimizer.zero_grad() ... optimizer.step()` of src/latent_paint/training/trainer.py:127-131
  * for the table parameter only. */
 int lnerf_grid_encode_backward_adam(const float *xyzs, float bound, const void *dfeat, int dfeat_dtype, int num_levels,

@@ -311,6 +311,8 @@ struct BucketMeta {
     int compact[LNERF_MAX_LEVELS];       // 1: merge runs of equal rows inside a wavefront before binning
     int wgstart[LNERF_MAX_LEVELS + 1];   // first pass-2 workgroup of the level
     long long rstart[LNERF_MAX_LEVELS];  // first record slot of the level's region
+    int pstart[LNERF_MAX_LEVELS];        // sliced levels: first partial-sum tile of the level (pass 2 -> finish)
+    int fstart[LNERF_MAX_LEVELS];        // sliced levels: first bucket index in the finishing pass's grid
 };
 
 // Runs of samples that sit in the same grid cell (lanes = consecutive samples of a ray: on coarse
@@ -635,22 +637,47 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
 // records per slice workgroup of pass 2 (a bucket with fewer records is reduced by one workgroup)
 constexpr int REDUCE_SLICE_RECS = 16384;
 
-// Optional fused table update (lnerf_grid_encode_backward_adam): on levels >= from_level (one workgroup per
-// bucket, no slices) pass 2 owns its 4096 rows outright, so it applies the Adam step to them straight from the
-// LDS sums: the gradient of those rows never travels through HBM (42 -> 26 bytes per table entry and step).
+// Optional fused table update (lnerf_grid_encode_backward_adam): where pass 2 (or its finishing kernel) owns a
+// row outright it applies the Adam step straight from the fixed-point sum: the gradient of the table never travels
+// through HBM (42 -> 26 bytes per table entry and step).
 struct FusedUpdate {
     float *p, *m, *v;
     uint16_t *shadow;  // optional bf16 copy of p, refreshed in the same pass
     AdamArgs a;
-    int from_level;
 };
 
+// power-of-two scale of a level's fixed-point sums: largest |value| < 2^(e-126) -> scale 2^(170-e) puts it below
+// 2^44 (2^17 additions of head-room in an int64); split so that both factors are normal floats
+struct FixScale {
+    float sc_a, sc_b, un_a, un_b;
+};
+__device__ __forceinline__ FixScale fix_scale(unsigned int gmax_bits) {
+    int e = (int)(gmax_bits >> 23);
+    e = e < 1 ? 1 : (e > 254 ? 254 : e);
+    int k = 170 - e;
+    k = k > 200 ? 200 : k;
+    FixScale f;
+    f.sc_a = ldexpf(1.0f, k / 2); f.sc_b = ldexpf(1.0f, k - k / 2);
+    f.un_a = ldexpf(1.0f, -(k / 2)); f.un_b = ldexpf(1.0f, -(k - k / 2));
+    return f;
+}
+// slices a bucket with n records is cut into (decided on the device from the actual count; the launch provides
+// `smax` workgroups per bucket for the worst case)
+__device__ __forceinline__ int active_slices(int n, int smax) {
+    int S = (n + REDUCE_SLICE_RECS - 1) / REDUCE_SLICE_RECS;
+    return S < 1 ? 1 : (S > smax ? smax : S);
+}
+
+// A bucket summed by ONE workgroup: the workgroup adds its tile to dtable (or applies the Adam step, FUSE).
+// A bucket cut into slices (few, heavily loaded coarse buckets): every slice stores its EXACT 64-bit partial sums
+// as a tile of `partials`, and k_scatter_finish adds the tiles up -- integer addition, so the result does not depend
+// on how many slices there were or in which order they ran: the whole gradient is bitwise reproducible.
 template <int RT, typename REC, bool FUSE>
 __global__ void __launch_bounds__(RT)
 k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ cursor,
                  const unsigned int *__restrict__ gmax, const REC *__restrict__ recs, float *__restrict__ dtable,
-                 int dbg, int wg_lo, FusedUpdate fu) {
-    __shared__ long long acc[BK_ROWS * 2];
+                 long long *__restrict__ partials, int wg_lo, FusedUpdate fu) {
+    __shared__ long long acc[BK_ROWS * 2];  // [feature][row]: a wave's 64 random rows spread over 32 bank pairs
     // locate (level, bucket, slice) of this workgroup
     const int wg = (int)blockIdx.x + wg_lo;
     int l = 0;
@@ -661,44 +688,29 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
     const int cap = bm.cap[l];
     const int n_raw = cursor[bm.bstart[l] + b];  // > cap: the excess records went to dtable with global atomics
     const int n = n_raw < cap ? n_raw : cap;
-    const bool fuse = FUSE && l >= fu.from_level;  // the host guarantees Smax == 1 there
-    // the launch provides slices for the worst case (every sample its own records); the bucket is cut into as many
-    // as its actual record count warrants and the other slice workgroups leave at once
-    int S = (n + REDUCE_SLICE_RECS - 1) / REDUCE_SLICE_RECS;
-    S = S < 1 ? 1 : (S > Smax ? Smax : S);
+    const int S = active_slices(n, Smax);
     if (s >= S) return;    // uniform per workgroup
+    const bool direct = S == 1;        // this workgroup sums the whole bucket: it finishes the rows itself
+    const bool fuse = FUSE && direct;
     const int lo = (int)(((long long)n * s) / S), hi = (int)(((long long)n * (s + 1)) / S);
-    if (hi <= lo && !fuse) return;  // (a fused bucket without records still owes its rows the Adam step, g = 0)
-    // largest |value| < 2^(e-126)  ->  scale 2^(170-e) puts it below 2^44
-    int e = (int)(gmax[l] >> 23);  // largest |value| of the LEVEL (found by pass 1)
-    e = e < 1 ? 1 : (e > 254 ? 254 : e);
-    int k = 170 - e;               // power of two to scale by; split so that both factors are normal floats
-    k = k > 200 ? 200 : k;
-    const float sc_a = ldexpf(1.0f, k / 2), sc_b = ldexpf(1.0f, k - k / 2);
-    const float un_a = ldexpf(1.0f, -(k / 2)), un_b = ldexpf(1.0f, -(k - k / 2));
-    const int tid = threadIdx.x;
-    // accumulator layout: dbg == 0 -> [feature][row] (a wave's 64 random rows spread over 32 bank pairs),
-    //                     dbg == 1 -> [row][feature] (16 bank groups): kept for the A/B in tools/microbench.py
-    const uint32_t rs = dbg ? 2u : 1u, fo = dbg ? 1u : (uint32_t)BK_ROWS;
     const bool have = hi > lo;  // uniform
+    if (!have && !fuse) return;  // (a fused bucket without records still owes its rows the Adam step, g = 0)
+    const FixScale fs = fix_scale(gmax[l]);  // from the largest |value| of the LEVEL (found by pass 1)
+    const int tid = threadIdx.x;
     const int hsize = meta.offsets[l + 1] - meta.offsets[l];
     const int row0 = b << BK_SHIFT;
     int rows = hsize - row0;
     rows = rows < BK_ROWS ? rows : BK_ROWS;
     const int64_t R0 = (int64_t)meta.offsets[l] + row0;
-    // fused update, usual case (full bucket, even first row): two rows per lane and access (16 B).  (Fetching the
-    // lane's parameters and moments here, ahead of the record stream, was measured 35 us SLOWER.)
-    constexpr int NQ = (BK_ROWS / 2 + RT - 1) / RT;  // row pairs per lane
-    const bool fast = fuse && ((R0 | rows) & 1) == 0 && rows == BK_ROWS && (BK_ROWS / 2) % RT == 0;
     if (have) {
         for (int i = tid; i < BK_ROWS * 2; i += RT) acc[i] = 0ll;
         __syncthreads();
         const REC *rp = recs + bm.rstart[l] + (long long)b * cap;
         unsigned long long *ua = reinterpret_cast<unsigned long long *>(acc);
         auto add = [&](const REC &r) {
-            const uint32_t a0 = r.row_in_bucket() * rs;
-            atomicAdd(&ua[a0], (unsigned long long)__float2ll_rn((r.a() * sc_a) * sc_b));
-            atomicAdd(&ua[a0 + fo], (unsigned long long)__float2ll_rn((r.b() * sc_a) * sc_b));
+            const uint32_t a0 = r.row_in_bucket();
+            atomicAdd(&ua[a0], (unsigned long long)__float2ll_rn((r.a() * fs.sc_a) * fs.sc_b));
+            atomicAdd(&ua[a0 + BK_ROWS], (unsigned long long)__float2ll_rn((r.b() * fs.sc_a) * fs.sc_b));
         };
         // the pass waits on its record loads (rocprofv3: 82 % of wave cycles parked): keep four loads in flight
         // per lane
@@ -709,6 +721,11 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
         }
         for (; i < hi; i += RT) add(rp[i]);
         __syncthreads();
+    }
+    if (!direct) {  // sliced bucket: hand the exact sums to k_scatter_finish
+        long long *pt = partials + ((int64_t)bm.pstart[l] + (int64_t)b * Smax + s) * (BK_ROWS * 2);
+        for (int i = tid; i < BK_ROWS * 2; i += RT) pt[i] = acc[i];
+        return;
     }
     float *dst = dtable + R0 * 2;
     if (fuse) {
@@ -722,8 +739,8 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
         auto grad_of = [&](int r, float &g0, float &g1) {
             g0 = 0.f; g1 = 0.f;
             if (have) {
-                g0 = ((float)acc[r * rs] * un_a) * un_b;
-                g1 = ((float)acc[r * rs + fo] * un_a) * un_b;
+                g0 = ((float)acc[r] * fs.un_a) * fs.un_b;
+                g1 = ((float)acc[r + BK_ROWS] * fs.un_a) * fs.un_b;
             }
             if (ovf) {  // what pass 1 could not place: consume it and leave dtable zero again
                 const float2 d = reinterpret_cast<float2 *>(dst)[r];
@@ -732,7 +749,10 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
                 reinterpret_cast<float2 *>(dst)[r] = make_float2(0.f, 0.f);
             }
         };
-        if (fast) {
+        // usual case (full bucket, even first row): two rows per lane and access (16 B).  (Fetching the lane's
+        // parameters and moments ahead of the record stream was measured 35 us SLOWER.)
+        constexpr int NQ = (BK_ROWS / 2 + RT - 1) / RT;  // row pairs per lane
+        if (((R0 | rows) & 1) == 0 && rows == BK_ROWS && (BK_ROWS / 2) % RT == 0) {
             float4 *p4 = reinterpret_cast<float4 *>(p2), *m4 = reinterpret_cast<float4 *>(m2);
             float4 *v4 = reinterpret_cast<float4 *>(v2);
             uint2 *sh2 = reinterpret_cast<uint2 *>(sh);
@@ -773,18 +793,69 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
         }
         return;
     }
-    if (S == 1) {  // sole owner of these rows in this launch: plain read-modify-write, 8 B per lane
-        for (int r = tid; r < rows; r += RT) {
-            float2 d = reinterpret_cast<float2 *>(dst)[r];
-            d.x += ((float)acc[r * rs] * un_a) * un_b;
-            d.y += ((float)acc[r * rs + fo] * un_a) * un_b;
-            reinterpret_cast<float2 *>(dst)[r] = d;
+    // sole owner of these rows in this launch: plain read-modify-write, 8 B per lane
+    for (int r = tid; r < rows; r += RT) {
+        float2 d = reinterpret_cast<float2 *>(dst)[r];
+        d.x += ((float)acc[r] * fs.un_a) * fs.un_b;
+        d.y += ((float)acc[r + BK_ROWS] * fs.un_a) * fs.un_b;
+        reinterpret_cast<float2 *>(dst)[r] = d;
+    }
+}
+
+// Finishing pass of the sliced levels: one thread per table row adds the active slices' exact partial sums
+// (k_scatter_reduce), converts once and adds the result to dtable -- or applies the Adam step (FUSE).
+template <bool FUSE>
+__global__ void __launch_bounds__(256)
+k_scatter_finish(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ cursor, const unsigned int *__restrict__ gmax,
+                 const long long *__restrict__ partials, float *__restrict__ dtable, FusedUpdate fu) {
+    constexpr int WG_PER_BUCKET = BK_ROWS / 256;
+    const int fb = blockIdx.x / WG_PER_BUCKET;  // index among the buckets of sliced levels
+    int l = 0;
+    while (l + 1 < meta.num_levels && (bm.slices[l] <= 1 || fb >= bm.fstart[l] + bm.nb[l])) ++l;
+    if (bm.slices[l] <= 1) return;  // (cannot happen: the grid covers sliced buckets only)
+    const int b = fb - bm.fstart[l];
+    const int Smax = bm.slices[l], cap = bm.cap[l];
+    const int n_raw = cursor[bm.bstart[l] + b];
+    const int n = n_raw < cap ? n_raw : cap;
+    const int S = active_slices(n, Smax);
+    if (S <= 1) return;  // the bucket was finished by its single pass-2 workgroup
+    const int r = (blockIdx.x % WG_PER_BUCKET) * 256 + threadIdx.x;
+    const int hsize = meta.offsets[l + 1] - meta.offsets[l];
+    const int row0 = b << BK_SHIFT;
+    if (row0 + r >= hsize) return;
+    const long long *pt = partials + ((int64_t)bm.pstart[l] + (int64_t)b * Smax) * (BK_ROWS * 2);
+    long long q0 = 0ll, q1 = 0ll;
+    for (int s = 0; s < S; ++s) {
+        q0 += pt[(int64_t)s * (BK_ROWS * 2) + r];
+        q1 += pt[(int64_t)s * (BK_ROWS * 2) + BK_ROWS + r];
+    }
+    const FixScale fs = fix_scale(gmax[l]);
+    float g0 = ((float)q0 * fs.un_a) * fs.un_b, g1 = ((float)q1 * fs.un_a) * fs.un_b;
+    const int64_t R = (int64_t)meta.offsets[l] + row0 + r;
+    float2 *d2 = reinterpret_cast<float2 *>(dtable) + R;
+    if (FUSE) {
+        if (n_raw > cap) {  // overflow records of pass 1 sit in dtable: consume them, leave it zero
+            const float2 d = *d2;
+            g0 = d.x + g0;
+            g1 = d.y + g1;
+            *d2 = make_float2(0.f, 0.f);
         }
-    } else {       // several slices share the rows: contiguous float atomics (256 B per wave instruction)
-        for (int kk = tid; kk < rows * 2; kk += RT) {
-            const long long a = acc[(kk >> 1) * rs + (kk & 1) * fo];
-            if (a != 0ll) atomicAdd(&dst[kk], ((float)a * un_a) * un_b);
-        }
+        AdamArgs a = fu.a;
+        adam_bias(a);
+        a.zero_grad = 0;
+        float2 P = reinterpret_cast<float2 *>(fu.p)[R], Mv = reinterpret_cast<float2 *>(fu.m)[R];
+        float2 V = reinterpret_cast<float2 *>(fu.v)[R];
+        adam_one(P.x, g0, Mv.x, V.x, a);
+        adam_one(P.y, g1, Mv.y, V.y, a);
+        reinterpret_cast<float2 *>(fu.p)[R] = P;
+        reinterpret_cast<float2 *>(fu.m)[R] = Mv;
+        reinterpret_cast<float2 *>(fu.v)[R] = V;
+        if (fu.shadow) reinterpret_cast<uint32_t *>(fu.shadow)[R] = (uint32_t)f32_to_bf16(P.x) | ((uint32_t)f32_to_bf16(P.y) << 16);
+    } else {
+        float2 d = *d2;
+        d.x += g0;
+        d.y += g1;
+        *d2 = d;
     }
 }
 
@@ -805,8 +876,6 @@ static int g_bin_tile = 512;
 static int g_skip_zero = 1;
 // first level of group A (fine levels reduced on a side stream next to the binning of the others); 0 = no split
 static int g_scatter_split = 0;  // measured: 0.344 ms split at 8/11/13 vs 0.313 ms single stream -> off by default
-// TIMING-ONLY experiment switch of the reduce pass (non-zero values give wrong sums)
-static int g_reduce_dbg = 0;
 // TIMING-ONLY experiment switch of the binning pass (non-zero values give wrong sums)
 static int g_bin_dbg = 0;
 // threads per workgroup of the reduce pass (512 or 1024; two 64 KiB workgroups fit a CU either way)
@@ -839,17 +908,27 @@ static size_t cursor_bytes(int n_buckets) {
     return ((size_t)(n_buckets + LNERF_MAX_LEVELS) * sizeof(int32_t) + 4095) / 4096 * 4096;
 }
 
-static int fill_bucket_meta(const GridMeta &meta, int64_t m_host, BucketMeta &bm, int64_t &total_recs,
-                            int &total_buckets, int &total_wgs) {
-    total_recs = 0;
-    total_buckets = 0;
-    total_wgs = 0;
+struct ScatterPlan {
+    int64_t recs;       // record slots
+    int buckets, wgs;   // buckets / pass-2 workgroups over all levels
+    int ptiles;         // partial-sum tiles (sliced levels: buckets x slices)
+    int fbuckets;       // buckets of sliced levels (grid of the finishing pass)
+    size_t cursor_bytes, rec_bytes, partial_bytes;
+    size_t total() const { return cursor_bytes + rec_bytes + partial_bytes; }
+};
+
+static int fill_bucket_meta(const GridMeta &meta, int64_t m_host, BucketMeta &bm, ScatterPlan &plan) {
+    int64_t total_recs = 0;
+    int total_buckets = 0, total_wgs = 0, total_ptiles = 0, total_fb = 0;
     for (int l = 0; l < meta.num_levels; ++l) {
         const int64_t hsize = meta.offsets[l + 1] - meta.offsets[l];
         const int nb = (int)div_up(hsize, BK_ROWS);
         if (nb > BK_MAX_PER_LEVEL) return -1;
         const int64_t per_bucket = div_up(8 * m_host, nb);
-        int64_t cap = per_bucket + per_bucket / 4 + 1024;  // 25 % head-room over a uniform spread
+        // head-room over a uniform spread of the worst-case record count: 25 % on hashed levels (rows are spread
+        // by the hash), 100 % on levels with few buckets (dense levels: a bucket is a slab of z layers, a compact
+        // object loads the central slabs, and the last bucket of a level is only partly filled)
+        int64_t cap = per_bucket + (nb <= 64 ? per_bucket : per_bucket / 4) + 1024;
         if (cap > 8 * m_host) cap = 8 * m_host;
         if (cap < 64) cap = 64;
         if (cap > 0x7FFFFFFF) return -1;
@@ -863,12 +942,26 @@ static int fill_bucket_meta(const GridMeta &meta, int64_t m_host, BucketMeta &bm
         bm.compact[l] = meta.res[l] <= g_compact_max_res ? 1 : 0;
         bm.wgstart[l] = total_wgs;
         bm.rstart[l] = total_recs;
+        bm.pstart[l] = slices > 1 ? total_ptiles : -1;
+        bm.fstart[l] = slices > 1 ? total_fb : -1;
+        if (slices > 1) {
+            total_ptiles += nb * slices;
+            total_fb += nb;
+        }
         total_buckets += nb;
         total_wgs += nb * slices;
         total_recs += (int64_t)nb * cap;
     }
     bm.bstart[meta.num_levels] = total_buckets;
     bm.wgstart[meta.num_levels] = total_wgs;
+    plan.recs = total_recs;
+    plan.buckets = total_buckets;
+    plan.wgs = total_wgs;
+    plan.ptiles = total_ptiles;
+    plan.fbuckets = total_fb;
+    plan.cursor_bytes = cursor_bytes(total_buckets);
+    plan.rec_bytes = ((size_t)total_recs * sizeof(Rec12) + 15) / 16 * 16;  // (packed records use two thirds of it)
+    plan.partial_bytes = (size_t)total_ptiles * BK_ROWS * 2 * sizeof(long long);
     return 0;
 }
 
@@ -988,10 +1081,6 @@ int lnerf_set_tuning(const char *key, int value) {
         g_bin_dbg = value;
         return LNERF_OK;
     }
-    if (strcmp(key, "scatter_reduce_debug") == 0) {
-        g_reduce_dbg = value;
-        return LNERF_OK;
-    }
     set_error("set_tuning: unknown key '%s'", key);
     return LNERF_ERR_INVALID_ARG;
 }
@@ -1013,15 +1102,13 @@ size_t lnerf_grid_encode_backward_workspace_bytes(int num_levels, const int32_t 
     for (int l = 0; l <= num_levels; ++l) meta.offsets[l] = offsets_host[l];
     for (int l = 0; l < num_levels; ++l) meta.res[l] = 0;
     BucketMeta bm;
-    int64_t recs;
-    int nbk, nwg;
-    if (fill_bucket_meta(meta, m_host, bm, recs, nbk, nwg) != 0) return 0;
-    return cursor_bytes(nbk) + (size_t)recs * sizeof(Rec12);  // bucket cursors, then the records
+    ScatterPlan plan;
+    if (fill_bucket_meta(meta, m_host, bm, plan) != 0) return 0;
+    return plan.total();  // bucket cursors, the records, the partial-sum tiles of the sliced levels
 }
 
-// fu == nullptr: dtable += scatter.  fu != nullptr: levels >= the first level from which every level has one
-// pass-2 workgroup per bucket get their Adam step inside pass 2; fu->from_level is set here for the caller, who
-// finishes the rows below it with the plain Adam kernel.
+// fu == nullptr: dtable += scatter.  fu != nullptr: every row's Adam step is applied by whichever kernel finishes its
+// sum (pass 2 on unsliced levels, the finishing pass on sliced ones); dtable only carries overflow records.
 static int scatter_backward(const float *xyzs, float bound, const void *dfeat, int dfeat_dtype, int num_levels,
                             int level_dim, const int32_t *offsets_host, const float *scales_host,
                             const int32_t *res_host, int64_t m_host, const int32_t *m_dev, int64_t level_stride,
@@ -1047,12 +1134,12 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
         return LNERF_OK;
     }
     BucketMeta bm;
-    int64_t recs;
-    int nbk, nwg;
-    LNERF_REQUIRE(fill_bucket_meta(meta, m_host, bm, recs, nbk, nwg) == 0,
+    ScatterPlan plan;
+    LNERF_REQUIRE(fill_bucket_meta(meta, m_host, bm, plan) == 0,
                   "grid_encode_backward: level too large for the bucketed scatter (use variant 0/1)");
-    const size_t cbytes = cursor_bytes(nbk);
-    const size_t need = cbytes + (size_t)recs * sizeof(Rec12);
+    const int nbk = plan.buckets;
+    const size_t cbytes = plan.cursor_bytes;
+    const size_t need = plan.total();
     LNERF_REQUIRE(workspace && workspace_bytes >= need, "grid_encode_backward: workspace too small (%zu < %zu)",
                   workspace_bytes, need);
     LNERF_REQUIRE(((uintptr_t)workspace & 15) == 0 && ((uintptr_t)dtable & 15) == 0,
@@ -1060,6 +1147,7 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
     int32_t *cursor = (int32_t *)workspace;
     unsigned int *gmax = (unsigned int *)workspace + nbk;
     void *rec = (char *)workspace + cbytes;
+    long long *partials = (long long *)((char *)workspace + cbytes + plan.rec_bytes);
     const bool packed = variant == 3;
     if (hipMemsetAsync(cursor, 0, cbytes, s) != hipSuccess) {
         set_error("grid_encode_backward: hipMemsetAsync failed");
@@ -1097,9 +1185,6 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
     FusedUpdate fu0;
     memset(&fu0, 0, sizeof(fu0));
     if (fu) {
-        int from = num_levels;
-        while (from > 0 && bm.slices[from - 1] == 1) --from;
-        fu->from_level = from;
         fu0 = *fu;
         split = 0;
     }
@@ -1108,7 +1193,7 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
         if (w1 <= w0) return;
 #define LAUNCH_RED(T, REC, FUSE)                                                                                  \
     hipLaunchKernelGGL((k_scatter_reduce<T, REC, FUSE>), dim3((unsigned)(w1 - w0)), dim3(T), 0, st, meta, bm, cursor, \
-                       gmax, (const REC *)rec, dtable, g_reduce_dbg, w0, fu0)
+                       gmax, (const REC *)rec, dtable, partials, w0, fu0)
         if (fu && packed) LAUNCH_RED(1024, Rec8, true);
         else if (fu) LAUNCH_RED(1024, Rec12, true);
         else if (packed && g_reduce_threads == 512) LAUNCH_RED(512, Rec8, false);
@@ -1117,10 +1202,20 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
         else LAUNCH_RED(1024, Rec12, false);
 #undef LAUNCH_RED
     };
+    auto launch_finish = [&]() {  // sliced levels: add up the slices' exact partial sums
+        if (plan.fbuckets == 0) return;
+        const dim3 g((unsigned)(plan.fbuckets * (BK_ROWS / 256)));
+        if (fu)
+            hipLaunchKernelGGL(k_scatter_finish<true>, g, dim3(256), 0, s, meta, bm, cursor, gmax, partials, dtable, fu0);
+        else
+            hipLaunchKernelGGL(k_scatter_finish<false>, g, dim3(256), 0, s, meta, bm, cursor, gmax, partials, dtable, fu0);
+    };
     if (!split) {
         launch_bin(0, num_levels);
         LNERF_CHECK_LAUNCH("grid_encode_backward(bin)");
         launch_reduce(s, 0, num_levels);
+        LNERF_CHECK_LAUNCH("grid_encode_backward(reduce)");
+        launch_finish();
     } else {
         launch_bin(split, num_levels);                       // A: fine levels
         LNERF_CHECK_LAUNCH("grid_encode_backward(bin A)");
@@ -1135,8 +1230,9 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
             set_error("grid_encode_backward: could not join the side stream");
             return LNERF_ERR_HIP;
         }
+        launch_finish();
     }
-    LNERF_CHECK_LAUNCH("grid_encode_backward(reduce)");
+    LNERF_CHECK_LAUNCH("grid_encode_backward(finish)");
     return LNERF_OK;
 }
 
@@ -1166,16 +1262,8 @@ int lnerf_grid_encode_backward_adam(const float *xyzs, float bound, const void *
     FusedUpdate fu;
     fu.p = table; fu.m = exp_avg; fu.v = exp_avg_sq; fu.shadow = (uint16_t *)shadow_bf16;
     adam_host_args(fu.a, lr, beta1, beta2, eps, step, step_dev, grad_scale, 0);
-    fu.from_level = 0;
-    int rc = scatter_backward(xyzs, bound, dfeat, dfeat_dtype, num_levels, level_dim, offsets_host, scales_host, res_host,
-                              m_host, m_dev, level_stride, dtable_zero, variant, workspace, workspace_bytes, stream, &fu);
-    if (rc) return rc;
-    // rows below from_level: their sums sit in dtable (several workgroups per bucket): plain Adam pass that clears it
-    const int64_t n_low = (int64_t)offsets_host[fu.from_level] * 2;
-    if (n_low > 0)
-        rc = lnerf_adam_step(table, dtable_zero, exp_avg, exp_avg_sq, shadow_bf16, n_low, lr, beta1, beta2, eps, step,
-                             step_dev, grad_scale, 1, stream);
-    return rc;
+    return scatter_backward(xyzs, bound, dfeat, dfeat_dtype, num_levels, level_dim, offsets_host, scales_host, res_host,
+                            m_host, m_dev, level_stride, dtable_zero, variant, workspace, workspace_bytes, stream, &fu);
 }
 
 }  // extern "C"

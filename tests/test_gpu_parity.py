@@ -194,6 +194,31 @@ def test_grid_encode_forward_backward(dev, variant, cfg):
 
 
 @pytest.mark.parametrize("variant", [2, 3])
+def test_bucketed_scatter_is_bitwise_reproducible(dev, variant):
+    """Fixed-point accumulation: the same scatter run twice (different workgroup timing, and a different number of
+    slices per coarse bucket when the capacity differs) gives the same bits.  (Points spread over the whole cube:
+    no bucket overflows -- the overflow fallback uses float atomics and is the one order-dependent path.)"""
+    from src.latent_nerf.models import encoding as E
+    levels = E.GridLevels()
+    M = 200000
+    g = torch.Generator().manual_seed(9)
+    x = ((torch.rand(M, 3, generator=g) * 2 - 1) * 0.999).to(dev)
+    dfeat = torch.randn(16, M, 2, generator=g).to(dev)
+    outs = []
+    for stride in (M, M, M + 4096 * 5):      # a larger capacity -> other slice counts / bucket regions
+        d = torch.zeros(levels.n_rows, 2, device=dev)
+        df = torch.zeros(16, stride, 2, device=dev)
+        df[:, :M] = dfeat
+        xx = torch.zeros(stride, 3, device=dev)
+        xx[:M] = x
+        m_dev = torch.tensor([M], dtype=torch.int32, device=dev)
+        E.grid_encode_backward(xx, 1.0, df, levels, stride, m_dev, stride, d, variant=variant)
+        outs.append(d)
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("variant", [2, 3])
 def test_bucketed_scatter_overflow_falls_back_to_atomics(dev, variant):
     """All samples inside one fine cell: every record of a hashed level lands in <= 8 buckets, far
     beyond their reserved regions -> the excess must take the global-atomic fallback and the sums
