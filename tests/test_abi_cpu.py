@@ -95,3 +95,35 @@ def test_ctypes_signatures_match_header():
         assert got == want, (name, got, want)
         n += 1
     assert n == len(B._SIGNATURES)
+
+
+def test_scatter_planning_and_new_entry_points_validate(built_lib):
+    """Host-side planning of the bucketed scatter and the argument checks of the fused backward+Adam entry."""
+    from src.latent_nerf.models.encoding import GridLevels
+    lib = B.get_lib()
+    P = ctypes.c_void_p
+    lv = GridLevels()
+    ws = [lib.lnerf_grid_encode_backward_workspace_bytes(lv.num_levels, lv.c_offsets, m) for m in (1 << 14, 1 << 18, 1 << 20)]
+    assert 0 < ws[0] < ws[1] < ws[2]
+    # capacity 2^20: >= 8 records x 12 B per (sample, level) plus the partial-sum tiles of the sliced coarse levels
+    assert ws[2] >= (1 << 20) * 16 * 8 * 12
+    assert lib.lnerf_grid_encode_backward_workspace_bytes(0, lv.c_offsets, 1024) == 0
+    args = [P(16), 1.0, P(16), B.F32, lv.num_levels, 2, lv.c_offsets, lv.c_scales, lv.c_res, 1024, None, 1024]
+    # the fused form needs the bucketed scatter ...
+    rc = lib.lnerf_grid_encode_backward_adam(*args, P(16), 0, P(16), 1 << 30, P(16), P(16), P(16), None, 1e-3, 0.9, 0.99,
+                                             1e-15, 1, None, 1.0, None)
+    assert rc == -1 and b"variant 2/3" in lib.lnerf_last_error()
+    # ... optimiser state, and a step number
+    rc = lib.lnerf_grid_encode_backward_adam(*args, P(16), 2, P(16), 1 << 30, None, P(16), P(16), None, 1e-3, 0.9, 0.99,
+                                             1e-15, 1, None, 1.0, None)
+    assert rc == -1 and b"optimiser state" in lib.lnerf_last_error()
+    rc = lib.lnerf_grid_encode_backward_adam(*args, P(16), 2, P(16), 1 << 30, P(16), P(16), P(16), None, 1e-3, 0.9, 0.99,
+                                             1e-15, 0, None, 1.0, None)
+    assert rc == -1 and b"step must be >= 1" in lib.lnerf_last_error()
+    # a workspace that is too small is refused before anything is launched
+    rc = lib.lnerf_grid_encode_backward(*args, P(16), 2, P(16), 4096, None)
+    assert rc == -1 and b"workspace too small" in lib.lnerf_last_error()
+    # tuning keys
+    assert lib.lnerf_set_tuning(b"scatter_bin_wgs", 768) == 0
+    assert lib.lnerf_set_tuning(b"scatter_bin_map", 7) == -1 and b"scatter_bin_map" in lib.lnerf_last_error()
+    assert lib.lnerf_set_tuning(b"no_such_knob", 1) == -1 and b"unknown key" in lib.lnerf_last_error()
