@@ -316,3 +316,28 @@ def test_fused_table_update_arming(dev):
         net.render(ro.to(dev), rd.to(dev), perturb=False)["image"].backward(gradient=g)
     with pytest.raises(RuntimeError, match="exactly one backward"):
         opt.step()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fuse", [False, True])
+def test_empty_frame_trains_without_samples(dev, fuse):
+    """A view that misses the occupied region: zero samples on the device (the host never learns the count), the
+    image is the background, backward and the optimiser step run through every kernel and change nothing."""
+    from src.latent_nerf.training.optimizer import FusedAdam
+    net, cfg, lv, table, params, grid = _make(dev, 64, 32, 19, 16, seed=2, mlp_precision="bf16", table_dtype="bf16")
+    net.train()
+    opt = FusedAdam(net.get_params(1e-2), encoder=net.encoder, fuse_table_update=fuse)
+    ro, rd = _rays(32, 60.0, 0.0, 1.3)
+    rd = -rd                                   # look away from the sphere
+    bg = torch.rand(32 * 32, 4, device=dev)
+    before = net.encoder.embeddings.detach().clone()
+    w_before = net.w1.detach().clone()
+    out = net.render(ro.to(dev), rd.to(dev), bg_color=bg, perturb=True)
+    assert int(out["counter"][0]) == 0
+    assert torch.equal(out["image"][0], bg)
+    opt.arm()
+    out["image"].backward(gradient=torch.randn(1, 32 * 32, 4, device=dev))
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(net.encoder.embeddings.detach(), before) and torch.equal(net.w1.detach(), w_before)
+    assert bool(torch.isfinite(net.encoder.shadow().float()).all())
