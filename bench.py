@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--gather-variant", type=int, default=0)
     ap.add_argument("--fuse-table-update", default="auto", choices=["auto", "0", "1"],
                     help="hash-table Adam step applied inside the scatter's reduce pass (single GPU only; auto = on at N=1)")
+    ap.add_argument("--jitter-rng", default="kernel", choices=["kernel", "torch"],
+                    help="source of the march jitter: the library's counter-based generator or torch.rand(N) per step")
+    ap.add_argument("--perturb", type=int, default=1, help="1 (training default): per-ray jitter of the march start")
     ap.add_argument("--breakdown", action="store_true", help="extra untimed pass: per-kernel event timings")
     ap.add_argument("--graph", type=int, default=1,
                     help="1: replay the captured hipGraph of the whole step (every --probe-every-th timed step still runs "
@@ -66,7 +69,7 @@ def parse():
     return ap.parse_args()
 
 
-def build(dev, precision, variant, rank, table="f32"):
+def build(dev, precision, variant, rank, table="f32", jitter_rng="kernel"):
     from oracle import nerf_oracle as O  # scene construction only (analytic occupancy), not measured
     from src.latent_nerf.configs.render_config import RenderConfig
     from src.latent_nerf.models.network_grid import NeRFNetwork
@@ -74,7 +77,7 @@ def build(dev, precision, variant, rank, table="f32"):
 
     torch.manual_seed(0)
     cfg = RenderConfig(grid_size=GRID, train_h=H, train_w=W, mlp_precision=precision, table_dtype=table,
-                       gather_variant=variant)
+                       gather_variant=variant, noise_seed=(0x5EED + rank) if jitter_rng == "kernel" else None)
     net = NeRFNetwork(cfg)
     net.encoder.embeddings.data.normal_(0, 0.1)
     net = net.to(dev).train()
@@ -89,7 +92,7 @@ def build(dev, precision, variant, rank, table="f32"):
     return net, pose, intr, bg, grad
 
 
-def make_step(net, pose, intr, bg, grad, opt, world, transport=torch.float32):
+def make_step(net, pose, intr, bg, grad, opt, world, transport=torch.float32, perturb=True):
     """Returns (eager_step, fwd_bwd, opt_step, sync)."""
     from src.latent_nerf.raymarching import raymarching as rm
     from src.latent_nerf.training.distributed import GradSync
@@ -98,7 +101,7 @@ def make_step(net, pose, intr, bg, grad, opt, world, transport=torch.float32):
 
     def fwd_bwd():
         rays_o, rays_d = rm.get_rays(pose, intr, H, W)
-        out = net.render(rays_o, rays_d, bg_color=bg, perturb=True)
+        out = net.render(rays_o, rays_d, bg_color=bg, perturb=perturb)
         opt.arm()                        # N = 1: the scatter applies the table's Adam step (no-op otherwise)
         out["image"].backward(gradient=grad)
         return out
@@ -237,7 +240,7 @@ def main():
     main_stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(main_stream)
     table = args.precision if args.table == "auto" else args.table
-    net, pose, intr, bg, grad = build(dev, args.precision, args.gather_variant, rank, table)
+    net, pose, intr, bg, grad = build(dev, args.precision, args.gather_variant, rank, table, args.jitter_rng)
     from src.latent_nerf.training.optimizer import FusedAdam
     fuse = (world == 1) if args.fuse_table_update == "auto" else (args.fuse_table_update == "1")
     if fuse and world > 1:
@@ -248,7 +251,7 @@ def main():
     scatter_call = "lnerf_grid_encode_backward_adam" if fuse else "lnerf_grid_encode_backward"
     tr = args.precision if args.grad_transport == "auto" else args.grad_transport
     step, fwd_bwd, opt_step, sync = make_step(net, pose, intr, bg, grad, opt, world,
-                                              torch.bfloat16 if tr == "bf16" else torch.float32)
+                                              torch.bfloat16 if tr == "bf16" else torch.float32, bool(args.perturb))
 
     def barrier():
         if world > 1:

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define LNERF_ABI_VERSION 1
+#define LNERF_ABI_VERSION 2
 
 #define LNERF_OK 0
 #define LNERF_ERR_INVALID_ARG (-1)
@@ -100,12 +100,19 @@ int lnerf_packbits(const float *grid, int64_t n_cells, float thresh, const float
  *   rays    int32 [N,3]  (ray id, offset, count)
  *   counter int32 [4]    [0]=M total samples written, [1]=number of rays with count>0,
  *                        [2]=rays dropped because offset+count exceeded `capacity`, [3]=reserved
- *   noises  [N] in [0,1) or NULL (no jitter)
+ *   jitter of the march start t0 = near + dt(near) * u_n, one of
+ *     noises [N] in [0,1)          the upstream form (`noises = torch.rand(N)`);
+ *     noise_counter (device int32) counter-based generator: u_n = hash(n, noise_seed, *noise_counter) in [0,1)
+ *                                  (24 bits; the hash is restated in oracle/nerf_oracle.py `march_noise`), and the
+ *                                  call advances *noise_counter by one -- fresh jitter on every replay of a
+ *                                  captured hipGraph, no host RNG state;
+ *     both NULL                    no jitter.
  *   xyzs [capacity,3], dirs [capacity,3], deltas [capacity,2] = (dt, t). */
 int lnerf_march_rays_train(const float *rays_o, const float *rays_d, const float *nears, const float *fars, int64_t N,
                            const uint8_t *bitfield, float bound, int cascade, int grid_size, int max_steps,
-                           float dt_gamma, const float *noises, int64_t capacity, float *xyzs, float *dirs,
-                           float *deltas, int32_t *rays, int32_t *counter, lnerf_stream_t stream);
+                           float dt_gamma, const float *noises, uint32_t noise_seed, int32_t *noise_counter,
+                           int64_t capacity, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
+                           lnerf_stream_t stream);
 
 /* ---- H4 (inference): `raymarching.march_rays` / `composite_rays` and the live-ray compaction
  * the upstream renderer does on the host (`rays_alive = rays_alive[rays_alive >= 0]`). */

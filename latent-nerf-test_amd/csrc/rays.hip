@@ -126,13 +126,37 @@ __device__ __forceinline__ bool cell_occupied(float x, float y, float z, float d
     return (bitfield[idx >> 3] >> (idx & 7u)) & 1u;
 }
 
+// Per-ray jitter of the march start.  Either a table of values (the upstream `noises = torch.rand(N)`), or a
+// counter-based generator: u = hash(ray, seed, *counter) in [0,1).  The counter lives on the device and is advanced
+// by the scan pass of every call, so a replayed hipGraph draws fresh jitter without any host-side RNG state
+// (torch.rand inside a captured graph costs three extra kernels per replay: measured 33 us per step).
+struct MarchNoise {
+    const float *values;     // [N] or null
+    const int32_t *counter;  // device counter or null
+    uint32_t seed;
+    int bias;                // the write pass runs after the scan pass has advanced the counter: bias 1
+};
+__host__ __device__ __forceinline__ float march_hash_uniform(uint32_t ray, uint32_t seed, uint32_t step) {
+    uint32_t x = ray * 0x9E3779B1u + seed;
+    x ^= step * 0x85EBCA77u;
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ float march_noise(const MarchNoise &nz, int64_t n) {
+    if (nz.values) return nz.values[n];
+    if (!nz.counter) return 0.0f;
+    return march_hash_uniform((uint32_t)n, nz.seed, (uint32_t)(*nz.counter - nz.bias));
+}
+
 // One wavefront per ray.  Each iteration tests 64 consecutive lattice points of the ray;
 // ballot + popcount gives the count (pass 1) or, with mbcnt, each sample's slot (pass 2).
 template <bool WRITE, bool UNIFORM_DT>
 __global__ void __launch_bounds__(256)
 k_march_train(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ nears,
               const float *__restrict__ fars, int64_t N, const uint8_t *__restrict__ bitfield, MarchParams P,
-              const float *__restrict__ noises, float *__restrict__ xyzs, float *__restrict__ dirs,
+              MarchNoise noises, float *__restrict__ xyzs, float *__restrict__ dirs,
               float *__restrict__ deltas, int32_t *__restrict__ rays) {
     const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform
     if (n >= N) return;
@@ -149,7 +173,7 @@ k_march_train(const float *__restrict__ rays_o, const float *__restrict__ rays_d
         const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
         const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
         const float dt0 = clampf(near * P.dt_gamma, P.dt_min, P.dt_max);
-        const float noise = noises ? noises[n] : 0.0f;
+        const float noise = march_noise(noises, n);
         const float t0 = near + dt0 * noise;
         float t = t0;
         if (!UNIFORM_DT) {  // lane l starts at lattice point l
@@ -197,13 +221,15 @@ k_march_train(const float *__restrict__ rays_o, const float *__restrict__ rays_d
 // Single-workgroup exclusive scan of the per-ray counts (N is a few thousand per view).
 // Also counts live rays and drops rays that would overflow `capacity`.
 __global__ void __launch_bounds__(1024) k_march_scan(int32_t *__restrict__ rays, int64_t N, int64_t capacity,
-                                                     int32_t *__restrict__ counter) {
+                                                     int32_t *__restrict__ counter, int32_t *__restrict__ noise_counter) {
     __shared__ int wave_tot[16];
     __shared__ int wave_live[16];
     __shared__ long long carry_s;
     __shared__ int live_s, drop_s;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid == 0) { carry_s = 0; live_s = 0; drop_s = 0; }
+    // the count pass has drawn this call's jitter; advance the generator (the write pass undoes the step: bias 1)
+    if (tid == 0 && noise_counter) *noise_counter += 1;
     __syncthreads();
     for (int64_t base = 0; base < N; base += 1024) {
         const int64_t n = base + tid;
@@ -505,13 +531,15 @@ static int check_march_common(const char *who, float bound, int cascade, int gri
 
 int lnerf_march_rays_train(const float *rays_o, const float *rays_d, const float *nears, const float *fars, int64_t N,
                            const uint8_t *bitfield, float bound, int cascade, int grid_size, int max_steps,
-                           float dt_gamma, const float *noises, int64_t capacity, float *xyzs, float *dirs,
-                           float *deltas, int32_t *rays, int32_t *counter, lnerf_stream_t stream) {
+                           float dt_gamma, const float *noises, uint32_t noise_seed, int32_t *noise_counter,
+                           int64_t capacity, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
+                           lnerf_stream_t stream) {
     int rc = check_march_common("march_rays_train", bound, cascade, grid_size, max_steps, dt_gamma);
     if (rc) return rc;
     LNERF_REQUIRE(N >= 0 && N <= ((int64_t)1 << 24), "march_rays_train: N out of range (%lld)", (long long)N);
     LNERF_REQUIRE(capacity >= 0 && capacity <= 0x7FFFFFFFll, "march_rays_train: capacity out of range");
     LNERF_REQUIRE(counter, "march_rays_train: null counter");
+    LNERF_REQUIRE(!(noises && noise_counter), "march_rays_train: give either a noise table or a noise counter");
     if (N == 0) {
         (void)hipMemsetAsync(counter, 0, 4 * sizeof(int32_t), as_stream(stream));
         return LNERF_OK;
@@ -521,21 +549,24 @@ int lnerf_march_rays_train(const float *rays_o, const float *rays_d, const float
     const MarchParams P = make_params(bound, cascade, grid_size, max_steps, dt_gamma);
     const dim3 block(256), grid((unsigned)div_up(N, 4));  // 4 wavefronts (rays) per workgroup
     hipStream_t s = as_stream(stream);
+    MarchNoise nz;
+    nz.values = noises; nz.counter = noise_counter; nz.seed = noise_seed; nz.bias = 0;
     if (dt_gamma == 0.f)
         hipLaunchKernelGGL((k_march_train<false, true>), grid, block, 0, s, rays_o, rays_d, nears, fars, N, bitfield, P,
-                           noises, xyzs, dirs, deltas, rays);
+                           nz, xyzs, dirs, deltas, rays);
     else
         hipLaunchKernelGGL((k_march_train<false, false>), grid, block, 0, s, rays_o, rays_d, nears, fars, N, bitfield,
-                           P, noises, xyzs, dirs, deltas, rays);
+                           P, nz, xyzs, dirs, deltas, rays);
     LNERF_CHECK_LAUNCH("march_rays_train(count)");
-    hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, s, rays, N, capacity, counter);
+    hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, s, rays, N, capacity, counter, noise_counter);
     LNERF_CHECK_LAUNCH("march_rays_train(scan)");
+    nz.bias = 1;
     if (dt_gamma == 0.f)
         hipLaunchKernelGGL((k_march_train<true, true>), grid, block, 0, s, rays_o, rays_d, nears, fars, N, bitfield, P,
-                           noises, xyzs, dirs, deltas, rays);
+                           nz, xyzs, dirs, deltas, rays);
     else
         hipLaunchKernelGGL((k_march_train<true, false>), grid, block, 0, s, rays_o, rays_d, nears, fars, N, bitfield, P,
-                           noises, xyzs, dirs, deltas, rays);
+                           nz, xyzs, dirs, deltas, rays);
     LNERF_CHECK_LAUNCH("march_rays_train(write)");
     return LNERF_OK;
 }

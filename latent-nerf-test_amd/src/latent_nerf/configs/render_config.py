@@ -3,6 +3,7 @@ still advertises for the absent package (`--render.n
 cuda_ray, max_steps 1024, update_extra_interval 16, max_ray_batch 4096, density_thresh 10,
 train 64x64, bound 1, dt_gamma 0, min_near 0.1, radius_range (1.0,1.5), fovy_range (40,70)),
 plus the MI355X-specific knobs at the bottom."""
+from typing import Optional
 from dataclasses import dataclass
 from typing import Tuple
 
@@ -55,5 +56,8 @@ class RenderConfig:
     # records), 3 = the same with packed 8-byte records (values rounded to 17 mantissa bits),
     # -1 = auto: 3 with mlp_precision "bf16", 2 otherwise
     scatter_variant: int = -1
+    # jitter of the march start (perturb=True): seed of the in-kernel counter-based generator
+    # (lnerf_march_rays_train `noise_counter`: graph-capturable, no host RNG state); None = torch.rand(N) per call
+    noise_seed: Optional[int] = 0x5EED
     # sample buffer capacity per view (0 = rays * min(max_steps, 256))
     max_samples: int = 0

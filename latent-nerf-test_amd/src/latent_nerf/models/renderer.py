@@ -40,6 +40,7 @@ class NeRFRenderer(nn.Module):
         self.iter_density = 0
         self.local_step = 0
         self._march = None
+        self._noise_counter = None
         self._occ_scratch = None
 
     # subclasses provide the field -------------------------------------------------------
@@ -81,6 +82,15 @@ class NeRFRenderer(nn.Module):
             return int(self.cfg.max_samples)
         return max(N * min(int(max_steps), 256), 64)
 
+    def _noise_state(self, dev):
+        """(seed, device counter) of the march's counter-based jitter generator (cfg.noise_seed; None = torch.rand)."""
+        seed = getattr(self.cfg, "noise_seed", None)
+        if seed is None:
+            return None
+        if self._noise_counter is None or self._noise_counter.device != dev:
+            self._noise_counter = torch.zeros(1, device=dev, dtype=torch.int32)
+        return (int(seed), self._noise_counter)
+
     def run_cuda(self, rays_o, rays_d, dt_gamma=0.0, bg_color=None, perturb=False, force_all_rays=False,
                  max_steps=1024, T_thresh=1e-4, **kwargs):
         """rays_o, rays_d [B,N,3] -> dict(image [B,N,C], depth [B,N], weights_sum [B,N]).
@@ -102,7 +112,8 @@ class NeRFRenderer(nn.Module):
             cap = self._capacity(N, max_steps)
             march = rm.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
                                         self.grid_size, nears, fars, perturb=perturb, dt_gamma=dt_gamma,
-                                        max_steps=max_steps, capacity=cap, out=self._march)
+                                        max_steps=max_steps, capacity=cap, out=self._march,
+                                        noises=kwargs.get("noises"), noise_state=self._noise_state(rays_o.device))
             self._march = march
             self.local_step += 1
             m_dev = march.counter[0:1]

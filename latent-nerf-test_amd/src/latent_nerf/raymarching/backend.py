@@ -30,6 +30,9 @@ _I = _c.c_int
 _L = _c.c_int64
 _F = _c.c_float
 _Z = _c.c_size_t
+_U = _c.c_uint32
+
+ABI_VERSION = 2  # LNERF_ABI_VERSION of include/lnerf_hip.h this host side was written against
 
 # name -> argtypes (return type int unless listed in _RESTYPES)
 _SIGNATURES = {
@@ -42,7 +45,7 @@ _SIGNATURES = {
     "lnerf_morton3d": [_P, _L, _P, _P],
     "lnerf_morton3d_invert": [_P, _L, _P, _P],
     "lnerf_packbits": [_P, _L, _F, _P, _P, _P],
-    "lnerf_march_rays_train": [_P, _P, _P, _P, _L, _P, _F, _I, _I, _I, _F, _P, _L, _P, _P, _P, _P, _P, _P],
+    "lnerf_march_rays_train": [_P, _P, _P, _P, _L, _P, _F, _I, _I, _I, _F, _P, _U, _P, _L, _P, _P, _P, _P, _P, _P],
     "lnerf_march_rays": [_L, _I, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _F, _P, _P, _P, _P],
     "lnerf_composite_rays": [_L, _I, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _P],
     "lnerf_compact_rays": [_P, _L, _P, _P, _P],
@@ -112,8 +115,8 @@ def get_lib():
             raise LnerfLibraryError("%s does not export %s (stale build?)" % (LIB_PATH, name)) from e
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, _c.c_int)
-    if lib.lnerf_abi_version() != 1:
-        raise LnerfLibraryError("ABI version mismatch: library %d, host side 1" % lib.lnerf_abi_version())
+    if lib.lnerf_abi_version() != ABI_VERSION:
+        raise LnerfLibraryError("ABI version mismatch: library %d, host side %d" % (lib.lnerf_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

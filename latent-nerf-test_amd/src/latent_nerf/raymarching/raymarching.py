@@ -120,20 +120,27 @@ class MarchResult:
 
 
 def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, perturb=False, dt_gamma=0.0,
-                     max_steps=1024, capacity=None, noises=None, out=None):
+                     max_steps=1024, capacity=None, noises=None, out=None, noise_state=None):
     """Occupancy-pruned march of N rays.  Returns a MarchResult.
 
     capacity: sample buffer size (default N * min(max_steps, 256)); rays that would overflow it
     are dropped and counted in counter[2].  `out` may pass a previous MarchResult to reuse its
-    buffers."""
+    buffers.
+    perturb: jitter of the march start.  `noises` [N] gives the values (upstream: torch.rand(N)); otherwise
+    `noise_state` = (seed, int32 device counter [1]) selects the in-kernel counter-based generator (the call
+    advances the counter; graph-capturable without host RNG state); with neither, torch.rand(N) is drawn here."""
     rays_o = rays_o.contiguous().view(-1, 3)
     rays_d = rays_d.contiguous().view(-1, 3)
     N = rays_o.shape[0]
     dev = rays_o.device
     if capacity is None:
         capacity = max(N * min(int(max_steps), 256), 64)
+    seed, noise_counter = 0, None
     if perturb and noises is None:
-        noises = torch.rand(N, device=dev, dtype=torch.float32)
+        if noise_state is not None:
+            seed, noise_counter = int(noise_state[0]) & 0xFFFFFFFF, noise_state[1]
+        else:
+            noises = torch.rand(N, device=dev, dtype=torch.float32)
     if out is not None and out.capacity == capacity and out.rays.shape[0] == N:
         xyzs, dirs, deltas, rays, counter = out.xyzs, out.dirs, out.deltas, out.rays, out.counter
     else:
@@ -144,7 +151,8 @@ def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars,
         counter = torch.empty(4, device=dev, dtype=torch.int32)
     _b.call("lnerf_march_rays_train", _chk(rays_o, "rays_o"), _chk(rays_d, "rays_d"), _chk(nears, "nears"),
             _chk(fars, "fars"), N, _chk(density_bitfield, "density_bitfield", torch.uint8), float(bound), int(C),
-            int(H), int(max_steps), float(dt_gamma), _chk(noises, "noises", allow_none=True), int(capacity), _p(xyzs),
+            int(H), int(max_steps), float(dt_gamma), _chk(noises, "noises", allow_none=True), seed,
+            _chk(noise_counter, "noise_counter", torch.int32, allow_none=True), int(capacity), _p(xyzs),
             _p(dirs), _p(deltas), _p(rays), _p(counter), _stream())
     return MarchResult(xyzs, dirs, deltas, rays, counter, capacity)
 

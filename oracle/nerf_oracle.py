@@ -232,6 +232,21 @@ def march_cell_index(x: torch.Tensor, dt: torch.Tensor, bound: float, cascade: i
     return level * (G ** 3) + morton3d(n)
 
 
+def march_noise(N: int, seed: int, step: int) -> torch.Tensor:
+    """Counter-based jitter u_n = hash(n, seed, step) in [0,1) of lnerf_march_rays_train's `noise_counter` form
+    (csrc/rays.hip march_hash_uniform; our own definition -- the upstream draws torch.rand(N)): a 32-bit integer
+    finaliser, the top 24 bits scaled by 2^-24."""
+    import numpy as np
+    M32 = np.uint64(0xFFFFFFFF)
+    n = np.arange(N, dtype=np.uint64)
+    x = (n * np.uint64(0x9E3779B1) + np.uint64(seed & 0xFFFFFFFF)) & M32
+    x ^= (np.uint64(step & 0xFFFFFFFF) * np.uint64(0x85EBCA77)) & M32
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7FEB352D)) & M32
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846CA68B)) & M32
+    x ^= x >> np.uint64(16)
+    return torch.from_numpy(((x >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)))
+
+
 def march_rays_train(rays_o, rays_d, nears, fars, bitfield, bound: float, cascade: int, G: int,
                      max_steps: int = 1024, dt_gamma: float = 0.0, noises: Optional[torch.Tensor] = None):
     """H4.  For every ray walk the step lattice t_0 = near + dt(near)*noise,

@@ -23,7 +23,7 @@ def test_header_symbols_all_exported(built_lib):
 
 def test_library_loads_and_reports_gfx950(built_lib):
     lib = B.get_lib()
-    assert lib.lnerf_abi_version() == 1
+    assert lib.lnerf_abi_version() == B.ABI_VERSION == 2
     assert lib.lnerf_build_info().decode().startswith("gfx950;")
     assert lib.lnerf_mlp_backward_workspace_bytes(5) > 0
 
@@ -41,9 +41,13 @@ def test_argument_validation_fails_loudly(built_lib):
     rc = lib.lnerf_packbits(P(16), 7, 0.5, None, P(16), None)
     assert rc == -1 and b"multiple of 8" in lib.lnerf_last_error()
     # march: cascade out of range
-    rc = lib.lnerf_march_rays_train(P(16), P(16), P(16), P(16), 4, P(16), 1.0, 0, 128, 1024, 0.0, None, 64, P(16), P(16),
-                                    P(16), P(16), P(16), None)
+    rc = lib.lnerf_march_rays_train(P(16), P(16), P(16), P(16), 4, P(16), 1.0, 0, 128, 1024, 0.0, None, 0, None, 64, P(16),
+                                    P(16), P(16), P(16), P(16), None)
     assert rc == -1 and b"cascade" in lib.lnerf_last_error()
+    # march: a noise table AND a noise counter
+    rc = lib.lnerf_march_rays_train(P(16), P(16), P(16), P(16), 4, P(16), 1.0, 1, 128, 1024, 0.0, P(16), 7, P(16), 64,
+                                    P(16), P(16), P(16), P(16), P(16), None)
+    assert rc == -1 and b"either a noise table or a noise counter" in lib.lnerf_last_error()
     # composite: unsupported channel count
     rc = lib.lnerf_composite_rays_train_forward(P(16), P(16), P(16), P(16), 4, 7, 1e-4, None, P(16), P(16), P(16), None)
     assert rc == -1 and b"C must be 3 or 4" in lib.lnerf_last_error()
@@ -71,7 +75,7 @@ def test_ctypes_signatures_match_header():
     text = open(B.HEADER_PATH).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     kinds = {C.c_void_p: "ptr", C.c_char_p: "ptr", C.c_int: "int", C.c_int64: "int64", C.c_float: "float",
-             C.c_size_t: "size_t"}
+             C.c_size_t: "size_t", C.c_uint32: "uint32"}
     n = 0
     for m in re.finditer(r"\b(lnerf_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
         name, args = m.group(1), " ".join(m.group(2).split())
@@ -87,6 +91,8 @@ def test_ctypes_signatures_match_header():
                     want.append("size_t")
                 elif a.startswith("float"):
                     want.append("float")
+                elif a.startswith("uint32_t"):
+                    want.append("uint32")
                 elif a.startswith("int ") or a.startswith("int32_t"):
                     want.append("int")
                 else:

@@ -117,6 +117,32 @@ def test_march_rays_train_bit_exact(dev, dt_gamma, perturb):
     assert torch.equal(res.dirs[:M].cpu(), dirs)
 
 
+def test_march_counter_based_jitter_matches_oracle_hash(dev):
+    """The in-kernel generator (noise_counter form): call k draws u_n = hash(n, seed, k) -- the same samples, bit
+    for bit, as the table form fed with the oracle's restatement of the hash; the device counter advances by one
+    per call (count and write pass of one call see the same jitter)."""
+    from src.latent_nerf.raymarching import raymarching as rm
+    G = 64
+    _, bits, _, _, ro, rd = _scene(G=G, HW=32)
+    N = ro.shape[0]
+    seed = 0x5EED
+    counter = torch.zeros(1, dtype=torch.int32, device=dev)
+    aabb = [-1.0] * 3 + [1.0] * 3
+    nears, fars = O.near_far_from_aabb(ro, rd, aabb, 0.1)
+    args = (ro.to(dev), rd.to(dev), 1.0, bits.to(dev), 1, G, nears.to(dev), fars.to(dev))
+    seen = []
+    for k in range(3):
+        res = rm.march_rays_train(*args, perturb=True, max_steps=512, noise_state=(seed, counter))
+        assert int(counter[0]) == k + 1
+        u = O.march_noise(N, seed, k)
+        assert 0.0 <= float(u.min()) and float(u.max()) < 1.0
+        (xyzs, dirs, deltas, rays, M), _ = _march_both(dev, ro, rd, bits, 1.0, 1, G, 512, 0.0, u)
+        assert int(res.counter[0]) == M and torch.equal(res.rays.cpu(), rays)
+        assert torch.equal(res.xyzs[:M].cpu(), xyzs) and torch.equal(res.deltas[:M].cpu(), deltas)
+        seen.append(res.xyzs[:64].cpu().clone())
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])   # fresh jitter every call
+
+
 def test_march_cascades_cap_and_capacity(dev):
     G = 32
     # two cascades, fully occupied: per-ray cap binds (oracle test_march_max_steps_cap)
