@@ -8,9 +8,12 @@
 // phi = 32 s + 16 (jj >> 2) + 4 q + (jj & 3)); the weight fragments are built once per workgroup with
 // the same permutation baked in and live in LDS in fragment order (one conflict-free ds_read_b128 per
 // operand).  The same trick runs the backward data chain (dA2 -> dA1 -> dX) with transposed weights.
-// Only the weight gradients, which sum over SAMPLES, need a transpose: dZ^T and H^T tiles are staged
-// once per 128-sample workgroup step as [feature][sample] bf16 images in LDS, and each of the four
-// waves owns a 16-row slice of every dW (no cross-wave reduction).  One f32 slab per workgroup goes to
+// Only the weight gradients, which sum over SAMPLES, need a transpose.  dZ and H tiles are staged once per
+// 128-sample workgroup step as [sample][feature] bf16 images in LDS -- a lane stores the packed registers it
+// already holds for the MFMA B operand, 8 bytes (4 consecutive features of its sample) at a time -- and the
+// operands of dW = dZ^T (x) H^T (feature on the lane, 8 consecutive SAMPLES in the registers) are read back with
+// gfx950's transposing LDS read, ds_read_b64_tr_b16 (cdna_hip_programming.md T10): no per-element conversions or
+// 2-byte stores.  Each of the four waves owns a 16-row slice of every dW (no cross-wave reduction).  One f32 slab per workgroup goes to
 // HBM and k_mlp_reduce_slabs (mlp.hip) sums the slabs in a fixed order: deterministic gradients.
 //
 // Lane maps (cdna_hip_programming.md §3): A[i = l&15][k = 8 (l>>4) + jj], B[k = 8 (l>>4) + jj][j = l&15],
@@ -33,7 +36,9 @@ constexpr int F_W2T = 18;   // [mt 0..3][s 0..1]  backward dA1:      W2[phi][16m
 constexpr int F_W1T = 26;   // [mt 0..1][s 0..1]  backward dX:       W1[phi][16mt+c]
 constexpr int F_FWD = 14, F_ALL = 30;
 
-constexpr int LD_S = 136;   // bf16 elements per row of a [feature][128 samples] staging image (+8 pad)
+constexpr int RS = 68;      // bf16 elements per row of a [128 samples][feature] staging image (64 + 4 pad: 136 B,
+                            // a multiple of 8 B as the transposing read requires; 16 lanes' 8-byte stores of one
+                            // column group fall on 16 different bank pairs)
 
 __device__ __forceinline__ int phi_of(int s, int q, int jj) { return 32 * s + 16 * (jj >> 2) + 4 * q + (jj & 3); }
 
@@ -190,20 +195,43 @@ k_mlp_forward_bf16(MlpArgs a, float *__restrict__ sigmas, float *__restrict__ rg
 }
 
 // ------------------------------------------------------------------ backward
-// write a packed B fragment (element jj <-> feature feat_of(jj), this lane's sample column) into a
-// [feature][sample] staging image
-template <typename F>
-__device__ __forceinline__ void stage_frag(__bf16 *img, const bf16x8 &v, int col, F feat_of) {
-#pragma unroll
-    for (int jj = 0; jj < 8; ++jj) img[feat_of(jj) * LD_S + col] = v[jj];
+// store the two packed halves of a B fragment (elements 0..3 <-> features fa..fa+3, elements 4..7 <-> fb..fb+3 of
+// this lane's sample) into row `row` of a [sample][feature] staging image: two 8-byte stores of registers the lane
+// already holds
+__device__ __forceinline__ void stage_pair(__bf16 *img, int row, int fa, int fb, const bf16x8 &v) {
+    const uint4 u = *reinterpret_cast<const uint4 *>(&v);
+    *reinterpret_cast<uint2 *>(img + row * RS + fa) = make_uint2(u.x, u.y);
+    *reinterpret_cast<uint2 *>(img + row * RS + fb) = make_uint2(u.z, u.w);
+}
+__device__ __forceinline__ void stage_lo(__bf16 *img, int row, int fa, const bf16x8 &v) {
+    const uint4 u = *reinterpret_cast<const uint4 *>(&v);
+    *reinterpret_cast<uint2 *>(img + row * RS + fa) = make_uint2(u.x, u.y);
+}
+
+// MFMA operand with the FEATURE f0 + (lane & 15) on the lane and the 8 samples 32k + 8(lane >> 4) + 0..7 in the
+// registers (A[i = feature][k = sample] and B[k = sample][j = feature] alike), read from a [sample][feature] image.
+// ds_read_b64_tr_b16: per group of 16 lanes, lane 4a+b supplies the address of row a, columns 4b..4b+3 of a 4 x 16
+// block, and lane i receives column i of the 4 rows; two of them cover the 8 samples.  EXEC is all ones here.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 ld_tr(const __bf16 *img, int k, int f0, int lane) {
+    typedef s16x4 __attribute__((address_space(3))) *lds_s16x4_p;
+    const int g = lane >> 4, i = lane & 15;
+    const __bf16 *p = img + (32 * k + 8 * g + (i >> 2)) * RS + f0 + 4 * (i & 3);
+    union {
+        struct { s16x4 lo, hi; } h;
+        bf16x8 v;
+    } u;
+    u.h.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)p);
+    u.h.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(p + 4 * RS));
+    return u.v;
 }
 
 __global__ void __launch_bounds__(256, 2)
 k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__restrict__ dsigmas,
                     const float *__restrict__ drgbs, float *__restrict__ dfeat, float *__restrict__ slabs) {
     __shared__ __attribute__((aligned(16))) __bf16 frag[F_ALL * 512];
-    __shared__ __attribute__((aligned(16))) __bf16 imgA[MLP_HID * LD_S];  // H2^T, then H1^T, then X^T
-    __shared__ __attribute__((aligned(16))) __bf16 imgD[MLP_HID * LD_S];  // dZ3^T, then dZ2^T, then dZ1^T
+    __shared__ __attribute__((aligned(16))) __bf16 imgA[128 * RS];  // [sample][feature]: H2, then H1, then X
+    __shared__ __attribute__((aligned(16))) __bf16 imgD[128 * RS];  // [sample][feature]: dZ3, then dZ2, then dZ1
     __shared__ float sB1[MLP_HID], sB2[MLP_HID];
     int64_t M = a.m_host;
     if (a.m_dev) { const int64_t md = *a.m_dev; M = md < M ? md : M; }
@@ -265,16 +293,16 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
         __syncthreads();  // previous step's readers of imgA/imgD are done
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int col = 32 * w + 16 * t + c;
+            const int row = 32 * w + 16 * t + c;  // this lane's sample inside the 128-sample step
 #pragma unroll
-            for (int s = 0; s < 2; ++s) stage_frag(imgA, h2B[s][t], col, [&](int jj) { return phi_of(s, q, jj); });
-            stage_frag(imgD, d3B[t], col, [&](int jj) { return (jj < 4) ? 4 * q + jj : 16 + 4 * q + (jj - 4); });
+            for (int s = 0; s < 2; ++s) stage_pair(imgA, row, 32 * s + 4 * q, 32 * s + 16 + 4 * q, h2B[s][t]);
+            stage_lo(imgD, row, 4 * q, d3B[t]);   // outputs 4q .. 4q+3 (columns 0..15; zero beyond out_dim)
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const bf16x8 dA = *reinterpret_cast<const bf16x8 *>(imgD + c * LD_S + 32 * k + 8 * q);
-            const bf16x8 hB = *reinterpret_cast<const bf16x8 *>(imgA + (16 * w + c) * LD_S + 32 * k + 8 * q);
+            const bf16x8 dA = ld_tr(imgD, k, 0, lane);        // A[i = output][k = sample]
+            const bf16x8 hB = ld_tr(imgA, k, 16 * w, lane);   // B[k = sample][j = hidden 16w + c]
             gW3 = MFMA32(dA, hB, gW3);
             if (w == 0) gB3 = MFMA32(dA, ones, gB3);
         }
@@ -296,22 +324,19 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int col = 32 * w + 16 * t + c;
+            const int row = 32 * w + 16 * t + c;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                stage_frag(imgA, h1B[s][t], col, [&](int jj) { return phi_of(s, q, jj); });
-                stage_frag(imgD, dzB[s][t], col, [&](int jj) { return phi_of(s, q, jj); });
+                stage_pair(imgA, row, 32 * s + 4 * q, 32 * s + 16 + 4 * q, h1B[s][t]);
+                stage_pair(imgD, row, 32 * s + 4 * q, 32 * s + 16 + 4 * q, dzB[s][t]);
             }
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const bf16x8 dA = *reinterpret_cast<const bf16x8 *>(imgD + (16 * w + c) * LD_S + 32 * k + 8 * q);
+            const bf16x8 dA = ld_tr(imgD, k, 16 * w, lane);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const bf16x8 hB = *reinterpret_cast<const bf16x8 *>(imgA + (16 * nt + c) * LD_S + 32 * k + 8 * q);
-                gW2[nt] = MFMA32(dA, hB, gW2[nt]);
-            }
+            for (int nt = 0; nt < 4; ++nt) gW2[nt] = MFMA32(dA, ld_tr(imgA, k, 16 * nt, lane), gW2[nt]);
             gB2 = MFMA32(dA, ones, gB2);
         }
         // ---- dA1 = W2^T dZ2 ; dZ1 = dA1 masked by H1 > 0   (dzB is overwritten by dZ1)
@@ -336,20 +361,17 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int col = 32 * w + 16 * t + c;
-            stage_frag(imgA, xB[t], col, [&](int jj) { return 8 * q + jj; });
+            const int row = 32 * w + 16 * t + c;
+            stage_pair(imgA, row, 8 * q, 8 * q + 4, xB[t]);   // input features 8q .. 8q+7
 #pragma unroll
-            for (int s = 0; s < 2; ++s) stage_frag(imgD, dzB[s][t], col, [&](int jj) { return phi_of(s, q, jj); });
+            for (int s = 0; s < 2; ++s) stage_pair(imgD, row, 32 * s + 4 * q, 32 * s + 16 + 4 * q, dzB[s][t]);
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const bf16x8 dA = *reinterpret_cast<const bf16x8 *>(imgD + (16 * w + c) * LD_S + 32 * k + 8 * q);
+            const bf16x8 dA = ld_tr(imgD, k, 16 * w, lane);
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const bf16x8 xb = *reinterpret_cast<const bf16x8 *>(imgA + (16 * nt + c) * LD_S + 32 * k + 8 * q);
-                gW1[nt] = MFMA32(dA, xb, gW1[nt]);
-            }
+            for (int nt = 0; nt < 2; ++nt) gW1[nt] = MFMA32(dA, ld_tr(imgA, k, 16 * nt, lane), gW1[nt]);
             gB1 = MFMA32(dA, ones, gB1);
         }
         // ---- dX = W1^T dZ1 -> dfeat (level-major f32): lane holds features 16mt + 4q + r of its sample

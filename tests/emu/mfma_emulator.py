@@ -39,3 +39,20 @@ def mfma_16x16x32(a, b, c):
         for r in range(4):
             out[l, r] += D[(l >> 4) * 4 + r, l & 15]
     return out
+
+
+def ds_read_tr16_b64(lds, rows, cols):
+    """gfx950 ds_read_b64_tr_b16 (cdna_hip_programming.md T10).  lds: 2-D array [row][16-bit element];
+    rows/cols: [64] per-lane address (row, first of 4 consecutive columns).  Per group of 16 lanes, lane 4a+b of the
+    group supplies the address of row a, columns 4b..4b+3 of a 4 x 16 block; lane i of the group receives column i
+    of the 4 rows, row a in its element a.  Returns [64, 4]."""
+    out = np.zeros((64, 4))
+    for g in range(4):
+        block = np.zeros((4, 16))
+        for a in range(4):
+            for b in range(4):
+                src = 16 * g + 4 * a + b
+                block[a, 4 * b:4 * b + 4] = lds[rows[src], cols[src]:cols[src] + 4]
+        for i in range(16):
+            out[16 * g + i, :] = block[:, i]
+    return out

@@ -1,9 +1,11 @@
 """CPU replay of the index algebra of the bf16 MFMA MLP (csrc/mlp_bf16.hip): the "sample on the
 lane" formulation Z^T = W X^T in which every layer's accumulator tile is the next MFMA's B operand
-(k order permuted by phi), and the weight gradients that go through [feature][sample] LDS tiles.
+(k order permuted by phi), and the weight gradients that go through [sample][feature] LDS images written
+with the packed fragment halves and read back with the transposing LDS read (ds_read_b64_tr_b16).
 Pure numpy in float64 -- this pins layouts, not rounding."""
 import numpy as np
 
+from tests.emu.mfma_emulator import ds_read_tr16_b64
 from tests.emu.mfma_emulator import mfma_16x16x32 as mfma
 
 IN, HID = 32, 64
@@ -115,32 +117,50 @@ def test_bf16_formulation_forward_backward():
                 for r in range(4):
                     assert abs(a[l, r] - dX[16 * t + C[l], 16 * mt + 4 * Q[l] + r]) < 1e-9
 
-    # ---------------- weight gradients through [feature][sample] LDS tiles (one wave, 32 samples)
-    def to_lds(tiles, rows):
-        lds = np.zeros((rows, S))
-        for mt in range(rows // 16):
-            for t in range(2):
-                for l in range(64):
-                    for r in range(4):
-                        lds[16 * mt + 4 * Q[l] + r, 16 * t + C[l]] = tiles[mt][t][l, r]
-        return lds
+    # ---------------- weight gradients through [sample][feature] LDS images (one wave, 32 samples = one k-step)
+    RS = 68
 
-    ldsH1, ldsH2 = to_lds(h1, 64), to_lds(h2, 64)
-    ldsD1, ldsD2 = to_lds(dz1, 64), to_lds(dz2, 64)
-    ldsX = np.zeros((32, S))
-    for t in range(2):  # X rows come from the B fragments: lane (q,c) holds features 8q..8q+7 of sample 16t+c
+    def stage_pair(img, t, fa_of, fb_of, fragB):
+        """kernel stage_pair: lane (q, c) stores elements 0..3 at features fa..fa+3 and 4..7 at fb..fb+3 of its
+        sample row 16t + c."""
         for l in range(64):
-            for jj in range(8):
-                ldsX[8 * Q[l] + jj, 16 * t + C[l]] = xB[t][l, jj]
-    ldsD3 = np.zeros((16, S))
-    for t in range(2):  # dZ3^T rows straight from the dz3B fragments (rows 4q+jj, jj < 4)
-        for l in range(64):
-            for jj in range(4):
-                ldsD3[4 * Q[l] + jj, 16 * t + C[l]] = dz3B[t][l, jj]
+            row = 16 * t + C[l]
+            img[row, fa_of(Q[l]):fa_of(Q[l]) + 4] = fragB[l, 0:4]
+            if fb_of is not None:
+                img[row, fb_of(Q[l]):fb_of(Q[l]) + 4] = fragB[l, 4:8]
+
+    def image(tiles):
+        img = np.full((S, RS), np.nan)
+        for t in range(2):
+            for s in range(2):
+                stage_pair(img, t, lambda q, s=s: 32 * s + 4 * q, lambda q, s=s: 32 * s + 16 + 4 * q, pack(tiles, s, t))
+        return img
+
+    ldsH1, ldsH2 = image(h1), image(h2)
+    ldsD1, ldsD2 = image(dz1), image(dz2)
+    ldsX = np.full((S, RS), np.nan)
+    for t in range(2):  # lane (q,c) holds input features 8q..8q+7 of sample 16t+c
+        stage_pair(ldsX, t, lambda q: 8 * q, lambda q: 8 * q + 4, xB[t])
+    ldsD3 = np.full((S, RS), np.nan)
+    for t in range(2):  # dZ3: slot (q, jj < 4) <-> output 4q + jj: only the low half is stored
+        stage_pair(ldsD3, t, lambda q: 4 * q, None, dz3B[t])
+
+    def ld_tr(img, k, f0):
+        """kernel ld_tr: feature f0 + (l & 15) on the lane, samples 32k + 8(l >> 4) + 0..7 in the 8 elements."""
+        rows = 32 * k + 8 * Q + (C >> 2)
+        cols = f0 + 4 * (C & 3)
+        lo = ds_read_tr16_b64(img, rows, cols)
+        hi = ds_read_tr16_b64(img, rows + 4, cols)
+        return np.concatenate([lo, hi], axis=1)
 
     def dw(ldsD, ldsA, mt, nt):
-        a = frag(lambda q, c, jj: ldsD[16 * mt + c, 8 * q + jj])      # A[i = row c][k = sample 8q+jj]
-        b = frag(lambda q, c, jj: ldsA[16 * nt + c, 8 * q + jj])      # B[k = sample][col c]
+        a = ld_tr(ldsD, 0, 16 * mt)                                   # A[i = feature row][k = sample 8q+jj]
+        b = ld_tr(ldsA, 0, 16 * nt)                                   # B[k = sample][col = feature]
+        assert not np.isnan(a).any() and not np.isnan(b).any()        # only staged elements are ever read
+        # and the fragments are what the old [feature][sample] formulation asked for
+        for l in range(64):
+            for jj in range(8):
+                assert a[l, jj] == ldsD[8 * Q[l] + jj, 16 * mt + C[l]] and b[l, jj] == ldsA[8 * Q[l] + jj, 16 * nt + C[l]]
         return mfma(a, b, z4)                                         # K = 32 samples in one step
 
     def check(ldsD, ldsA, n_mt, n_nt, want):
@@ -159,7 +179,7 @@ def test_bf16_formulation_forward_backward():
     # bias gradients with a B tile of ones: every column of the result is the row sum
     ones = np.ones((64, 8))
     for mt in range(4):
-        a = frag(lambda q, c, jj, mt=mt: ldsD2[16 * mt + c, 8 * q + jj])
+        a = ld_tr(ldsD2, 0, 16 * mt)
         acc = mfma(a, ones, z4)
         for l in range(64):
             for r in range(4):
