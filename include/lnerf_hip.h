@@ -65,6 +65,8 @@ const char *lnerf_build_info(void);
  *   "scatter_bin_wgs":         persistent workgroups of map 2 (default 768 = 3 per CU).
  *   "scatter_bin_debug":       TIMING-ONLY experiment switch (non-zero values give wrong sums).
  *   "gather_pair_loads":       1 (default) = x-adjacent vertices fetched with one load where adjacent.
+ *   "gather_dedup_max_res":    levels with resolution <= value fetch a cell's 8 vertices once per run of
+ *                              lanes (consecutive samples of a ray) in that cell (default 512; 0 = off).
  *   "mlp_fwd_blocks":          persistent workgroups of the bf16 MLP forward (default 512).
  *   "scatter_split_level":     levels >= value are binned first and reduced on a side stream while the others
  *                              are binned (default 0 = single stream; the split measured slower).

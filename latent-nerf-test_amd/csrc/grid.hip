@@ -74,24 +74,6 @@ template <> struct Feat2<uint16_t> {  // bf16 pairs in one dword
     }
 };
 
-// two consecutive table rows with one load (x-adjacent vertices are adjacent rows on dense levels, and on
-// hashed levels when x is even: row(x+1) = row(x) ^ 1): halves the L1 accesses of those lookups
-template <typename T> struct Pair2;
-template <> struct Pair2<float> {
-    static __device__ __forceinline__ void load(const float *base, uint32_t row, float2 &a, float2 &b) {
-        const float4 v = *reinterpret_cast<const float4 *>(base + (int64_t)row * 2);  // dword-aligned 16-byte load
-        a = make_float2(v.x, v.y);
-        b = make_float2(v.z, v.w);
-    }
-};
-template <> struct Pair2<uint16_t> {
-    static __device__ __forceinline__ void load(const uint16_t *base, uint32_t row, float2 &a, float2 &b) {
-        const uint2 v = *reinterpret_cast<const uint2 *>(base + (int64_t)row * 2);    // two bf16 pairs
-        a = make_float2(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xFFFF0000u));
-        b = make_float2(__uint_as_float(v.y << 16), __uint_as_float(v.y & 0xFFFF0000u));
-    }
-};
-
 struct LevelPos {
     uint32_t gx, gy, gz;
     float fx, fy, fz;
@@ -145,11 +127,80 @@ __device__ __forceinline__ TileMap tile_map(int variant, int L) {
     return t;
 }
 
+// Runs of samples that sit in the same grid cell (lanes = consecutive samples of a ray: on coarse levels long
+// runs share all 8 vertices).  `start` = first lane of this lane's run, `tail` = this lane is the last lane of its
+// run.  Computed once per (wave, level) from the cell coordinates; every lane of the wave must call it.
+struct RunInfo {
+    int start;
+    bool tail;
+};
+__device__ __forceinline__ RunInfo wave_cell_runs(uint32_t gx, uint32_t gy, uint32_t gz, bool valid) {
+    const int lane = lane_id();
+    const int px = lane_prev_i((int)gx, -1), py = lane_prev_i((int)gy, -1), pz = lane_prev_i((int)gz, -1);
+    const int pv = lane_prev_i((int)valid, 0);
+    const bool head = (lane == 0) || px != (int)gx || py != (int)gy || pz != (int)gz || !valid || !pv;
+    const unsigned long long H = __ballot(head);  // bit 0 is always set
+    RunInfo r;
+    r.start = 63 - __clzll((long long)(H & (~0ull >> (63 - lane))));
+    r.tail = (lane == 63) || ((H >> (lane + 1)) & 1ull);
+    return r;
+}
+
+// the vertex values of one cell as raw dwords: 8 (bf16 pairs) or 16 (f32 pairs).  load_pair fetches two consecutive
+// table rows with one load (x-adjacent vertices are adjacent rows on dense levels, and on hashed levels when x is
+// even: row(x+1) = row(x) ^ 1): half the cache accesses of those lookups
+template <typename TT> struct CellRaw;
+template <> struct CellRaw<uint16_t> {
+    uint32_t d[8];
+    __device__ __forceinline__ void load_pair(const uint16_t *lt, uint32_t row, int c) {  // rows row, row+1 -> c, c+1
+        const uint2 v = *reinterpret_cast<const uint2 *>(lt + (int64_t)row * 2);
+        d[c] = v.x; d[c + 1] = v.y;
+    }
+    __device__ __forceinline__ void load_one(const uint16_t *lt, uint32_t row, int c) {
+        d[c] = reinterpret_cast<const uint32_t *>(lt)[row];
+    }
+    __device__ __forceinline__ void swap_pair(int c) { const uint32_t t = d[c]; d[c] = d[c + 1]; d[c + 1] = t; }
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[i] = 0u;
+    }
+    __device__ __forceinline__ void take_from_lane(int src) {  // every lane reads lane `src`'s cell
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)d[i]);
+    }
+    __device__ __forceinline__ float2 get(int c) const {
+        return make_float2(__uint_as_float(d[c] << 16), __uint_as_float(d[c] & 0xFFFF0000u));
+    }
+};
+template <> struct CellRaw<float> {
+    float2 d[8];
+    __device__ __forceinline__ void load_pair(const float *lt, uint32_t row, int c) {
+        const float4 v = *reinterpret_cast<const float4 *>(lt + (int64_t)row * 2);  // dword-aligned 16-byte load
+        d[c] = make_float2(v.x, v.y); d[c + 1] = make_float2(v.z, v.w);
+    }
+    __device__ __forceinline__ void load_one(const float *lt, uint32_t row, int c) {
+        d[c] = reinterpret_cast<const float2 *>(lt)[row];
+    }
+    __device__ __forceinline__ void swap_pair(int c) { const float2 t = d[c]; d[c] = d[c + 1]; d[c + 1] = t; }
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[i] = make_float2(0.f, 0.f);
+    }
+    __device__ __forceinline__ void take_from_lane(int src) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            d[i].x = __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(d[i].x)));
+            d[i].y = __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(d[i].y)));
+        }
+    }
+    __device__ __forceinline__ float2 get(int c) const { return d[c]; }
+};
+
 template <typename TT, typename TO>
 __global__ void __launch_bounds__(256)
 k_grid_forward(const float *__restrict__ xyzs, float bound, const TT *__restrict__ table, GridMeta meta, int64_t m_host,
                const int32_t *__restrict__ m_dev, int64_t level_stride, TO *__restrict__ feat, int variant,
-               int pair_loads) {
+               int pair_loads, int dedup_max_res) {
     int64_t M = m_host;
     if (m_dev) { const int64_t md = *m_dev; M = md < M ? md : M; }
     const TileMap tm = tile_map(variant, meta.num_levels);
@@ -160,49 +211,61 @@ k_grid_forward(const float *__restrict__ xyzs, float bound, const TT *__restrict
     const uint32_t off = (uint32_t)meta.offsets[l];
     const uint32_t hsize = (uint32_t)(meta.offsets[l + 1] - meta.offsets[l]);
     const TT *lt = table + (int64_t)off * 2;
+    const bool dense = (uint64_t)(res + 1) * (res + 1) * (res + 1) <= (uint64_t)hsize;  // wave-uniform
+    const bool pow2 = (hsize & (hsize - 1u)) == 0u;
+    // Coarse levels: the 64 lanes of a wave are consecutive samples of a ray and sit in a handful of cells.  The
+    // kernel is bound by the L1's miss path (one cache access per lane gather): only the first lane of
+    // each run of equal cells fetches the 8 vertices, the others take them from it through the LDS crossbar.
+    const bool dedup = (int)res <= dedup_max_res;  // wave-uniform
+    const int lane = lane_id();
     for (int64_t tile = tm.tile0; tile * 256 < M; tile += tm.tstep) {
         const int64_t m = tile * 256 + threadIdx.x;
-        if (m >= M) continue;
-        const LevelPos p = level_pos(xyzs, m, bound, scale);
-        // issue the 8 gathers first, blend afterwards (keeps 8 loads in flight per lane)
-        float2 v[8];
-        float w[8];
+        const bool valid = m < M;  // (no early exit: the run logic below needs every lane of the wave)
+        LevelPos p;
+        p.gx = p.gy = p.gz = 0u; p.fx = p.fy = p.fz = 0.f;
+        if (valid) p = level_pos(xyzs, m, bound, scale);
         uint32_t rows[8];
         corner_rows(p.gx, p.gy, p.gz, res, hsize, rows);
-        const bool dense = (uint64_t)(res + 1) * (res + 1) * (res + 1) <= (uint64_t)hsize;  // wave-uniform
-        const bool pow2 = (hsize & (hsize - 1u)) == 0u;
-        if (pair_loads && dense) {
-#pragma unroll
-            for (int c = 0; c < 8; c += 2) Pair2<TT>::load(lt, rows[c], v[c], v[c + 1]);  // rows[c+1] == rows[c] + 1
-        } else if (pair_loads && pow2 && !(p.gx & 1u)) {
-            // hashed, x even: the two x-neighbours are the two halves of one aligned pair
-#pragma unroll
-            for (int c = 0; c < 8; c += 2) {
-                float2 lo, hi;
-                Pair2<TT>::load(lt, rows[c] & ~1u, lo, hi);
-                const bool odd = rows[c] & 1u;
-                v[c] = odd ? hi : lo;
-                v[c + 1] = odd ? lo : hi;
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) v[c] = Feat2<TT>::load(lt, rows[c]);
+        bool fetch = valid;
+        int src = lane;
+        if (dedup) {
+            const RunInfo ri = wave_cell_runs(p.gx, p.gy, p.gz, valid);
+            src = ri.start;
+            fetch = valid && ri.start == lane;
         }
+        // issue the gathers first, blend afterwards (keeps up to 8 loads in flight per lane)
+        CellRaw<TT> cell;
+        cell.zero();
+        if (fetch) {
+            if (pair_loads && dense) {
+#pragma unroll
+                for (int c = 0; c < 8; c += 2) cell.load_pair(lt, rows[c], c);  // rows[c+1] == rows[c] + 1
+            } else if (pair_loads && pow2 && !(p.gx & 1u)) {
+                // hashed, x even: the two x-neighbours are the two halves of one aligned pair
+#pragma unroll
+                for (int c = 0; c < 8; c += 2) {
+                    cell.load_pair(lt, rows[c] & ~1u, c);
+                    if (rows[c] & 1u) cell.swap_pair(c);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) cell.load_one(lt, rows[c], c);
+            }
+        }
+        if (dedup) cell.take_from_lane(src);
+        float a0 = 0.f, a1 = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const uint32_t bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
             const float wx = bx ? p.fx : 1.0f - p.fx;
             const float wy = by ? p.fy : 1.0f - p.fy;
             const float wz = bz ? p.fz : 1.0f - p.fz;
-            w[c] = (wx * wy) * wz;
+            const float w = (wx * wy) * wz;
+            const float2 v = cell.get(c);
+            a0 = fmaf(w, v.x, a0);
+            a1 = fmaf(w, v.y, a1);
         }
-        float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            a0 = fmaf(w[c], v[c].x, a0);
-            a1 = fmaf(w[c], v[c].y, a1);
-        }
-        Feat2<TO>::store(feat, (int64_t)l * level_stride + m, a0, a1);
+        if (valid) Feat2<TO>::store(feat, (int64_t)l * level_stride + m, a0, a1);
     }
 }
 
@@ -315,24 +378,6 @@ struct BucketMeta {
     int fstart[LNERF_MAX_LEVELS];        // sliced levels: first bucket index in the finishing pass's grid
 };
 
-// Runs of samples that sit in the same grid cell (lanes = consecutive samples of a ray: on coarse
-// levels long runs share all 8 vertices).  `start` = first lane of this lane's run, `tail` = this lane is
-// the last lane of its run.  Computed once per (wave, level) from the cell coordinates.
-struct RunInfo {
-    int start;
-    bool tail;
-};
-__device__ __forceinline__ RunInfo wave_cell_runs(uint32_t gx, uint32_t gy, uint32_t gz, bool valid) {
-    const int lane = lane_id();
-    const int px = lane_prev_i((int)gx, -1), py = lane_prev_i((int)gy, -1), pz = lane_prev_i((int)gz, -1);
-    const int pv = lane_prev_i((int)valid, 0);
-    const bool head = (lane == 0) || px != (int)gx || py != (int)gy || pz != (int)gz || !valid || !pv;
-    const unsigned long long H = __ballot(head);  // bit 0 is always set
-    RunInfo r;
-    r.start = 63 - __clzll((long long)(H & (~0ull >> (63 - lane))));
-    r.tail = (lane == 63) || ((H >> (lane + 1)) & 1ull);
-    return r;
-}
 // sum of v over this lane's run, valid on the run's tail lane: difference of wave prefix sums
 __device__ __forceinline__ float run_sum(float v, const RunInfo &r) {
     const float P = wave_inclusive_sum(v);
@@ -865,6 +910,8 @@ extern int g_mlp_fwd_blocks;  // mlp.hip
 static int g_compact_max_res = 512;
 // gather: fetch x-adjacent vertices with one load where they are adjacent rows
 static int g_gather_pairs = 1;
+// gather: levels with resolution <= this fetch a cell's vertices once per run of lanes in that cell (0 = off)
+static int g_gather_dedup_res = 512;
 // workgroup -> (level, tile) map of the binning pass: 0 = level on blockIdx.y, 1 = XCD-aware, 2 = persistent
 // workgroups striding over the (tile, level) list with the level rotated per round
 static int g_bin_map = 2;
@@ -1022,7 +1069,7 @@ int lnerf_grid_encode_forward(const float *xyzs, float bound, const void *table,
     hipStream_t s = as_stream(stream);
 #define LAUNCH_FWD(TT, TO)                                                                                         \
     hipLaunchKernelGGL((k_grid_forward<TT, TO>), grid, dim3(256), 0, s, xyzs, bound, (const TT *)table, meta, m_host, \
-                       m_dev, level_stride, (TO *)feat, variant, g_gather_pairs)
+                       m_dev, level_stride, (TO *)feat, variant, g_gather_pairs, g_gather_dedup_res)
     if (table_dtype == LNERF_F32 && feat_dtype == LNERF_F32) LAUNCH_FWD(float, float);
     else if (table_dtype == LNERF_F32) LAUNCH_FWD(float, uint16_t);
     else if (feat_dtype == LNERF_F32) LAUNCH_FWD(uint16_t, float);
@@ -1047,6 +1094,11 @@ int lnerf_set_tuning(const char *key, int value) {
     if (strcmp(key, "scatter_bin_wgs") == 0) {
         LNERF_REQUIRE(value >= 1 && value <= 65535, "set_tuning: scatter_bin_wgs out of range");
         g_bin_wgs = value;
+        return LNERF_OK;
+    }
+    if (strcmp(key, "gather_dedup_max_res") == 0) {
+        LNERF_REQUIRE(value >= 0, "set_tuning: gather_dedup_max_res must be >= 0");
+        g_gather_dedup_res = value;
         return LNERF_OK;
     }
     if (strcmp(key, "gather_pair_loads") == 0) {

@@ -63,20 +63,19 @@ def main():
         f32o = torch.empty(16, cap, 2, device=dev)
         bf16o = torch.empty(16, cap, 2, device=dev, dtype=torch.bfloat16)
         fns = {}
-        for pl in (0, 1):
-            def mk(tab, out, pl=pl):
+        for dd in (0, 64, 128, 256, 512):
+            def mk(tab, out, dd=dd):
                 def f():
-                    B.call("lnerf_set_tuning", b"gather_pair_loads", pl)
+                    B.call("lnerf_set_tuning", b"gather_dedup_max_res", dd)
                     E.grid_encode_forward(xyzs, 1.0, tab, levels, cap, m_dev, cap, out, variant=0)
                 return f
-            fns["f32tab_f32out_pairs%d" % pl] = mk(table, f32o)
-            fns["f32tab_bf16out_pairs%d" % pl] = mk(table, bf16o)
-            fns["bf16tab_bf16out_pairs%d" % pl] = mk(table_bf, bf16o)
+            fns["f32tab_bf16out_dedup%d" % dd] = mk(table, bf16o)
+            fns["bf16tab_bf16out_dedup%d" % dd] = mk(table_bf, bf16o)
         t = timed(fns)
         res["gather_ms(median,min)"] = t
         bps = lambda k: (1024 if k.startswith("f32tab") else 512) + 12 + (128 if "f32out" in k else 64)
         res["gather_GBps_algorithmic"] = {k: round(M * bps(k) / (v[0] * 1e-3) / 1e9, 1) for k, v in t.items()}
-        B.call("lnerf_set_tuning", b"gather_pair_loads", 1)
+        B.call("lnerf_set_tuning", b"gather_dedup_max_res", 512)
 
     if "scatter" in which:
         # a REAL dfeat (from a render + backward of the bench step), so that zero gradients appear where they do
