@@ -13,6 +13,7 @@
 #include "common.h"
 #include "adam_shared.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 namespace lnerf {
@@ -1130,6 +1131,10 @@ int lnerf_set_tuning(const char *key, int value) {
         return LNERF_OK;
     }
     if (strcmp(key, "scatter_bin_debug") == 0) {
+        // non-zero values produce WRONG sums (timing-only experiments of tools/microbench.py): refuse them unless
+        // the process opted in
+        LNERF_REQUIRE(value == 0 || getenv("LNERF_TIMING_EXPERIMENTS") != nullptr,
+                      "set_tuning: scatter_bin_debug is a timing-only switch (set LNERF_TIMING_EXPERIMENTS=1 to use it)");
         g_bin_dbg = value;
         return LNERF_OK;
     }
