@@ -271,6 +271,7 @@ def main():
             log("hipGraph capture failed (%s: %s); running eager launches" % (type(e).__name__, e))
             torch.cuda.synchronize()
             gstep = None
+    emb0 = net.encoder.embeddings.detach().clone()
     for i in range(args.warmup):
         (gstep if (gstep is not None and i % 2) else step)()
     torch.cuda.synchronize()
@@ -297,6 +298,12 @@ def main():
     elapsed = float(t.item())
     if rank == 0:
         log("timed region: %.3f s for %d steps" % (elapsed, args.steps))
+    # outside the timed region: the run must have trained, not diverged (fail loudly rather than report a number)
+    emb = net.encoder.embeddings.detach()
+    if not bool(torch.isfinite(emb).all()) or not all(bool(torch.isfinite(p.detach()).all()) for p in net.parameters()):
+        raise SystemExit("bench: non-finite parameters after the timed steps")
+    if float((emb - emb0).abs().max()) == 0.0:
+        raise SystemExit("bench: the hash table did not change during the timed steps (optimiser not applied?)")
 
     breakdown = None
     if args.breakdown and rank == 0:
