@@ -114,16 +114,19 @@ def make_step(net, pose, intr, bg, grad, opt, world, transport=torch.float32, pe
         out["image"].backward(gradient=grad)
         return out
 
+    def allreduce():
+        sync.allreduce(copy_back=False)  # no-op at world size 1; bf16 sums stay in the wire buffer
+
     def opt_step():
-        opt.step(grad_scale=1.0 / world)
+        opt.step(grad_scale=1.0 / world, grads=sync.reduced() if world > 1 else None)
 
     def step():
         out = fwd_bwd()
-        sync.allreduce()                 # no-op at world size 1
+        allreduce()
         opt_step()
         return out
 
-    return step, fwd_bwd, opt_step, sync.allreduce
+    return step, fwd_bwd, opt_step, allreduce
 
 
 class KernelTimer:

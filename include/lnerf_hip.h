@@ -258,10 +258,11 @@ int lnerf_texture_map_backward(const float *uv, const int32_t *face_idx, const f
 /* ---- optimiser step used by the bench/trainer (Adam, src/latent_paint/training/trainer.py:93-95:
  * betas (0.9, 0.99), eps 1e-15).  g is multiplied by grad_scale (1/world_size) first; if
  * zero_grad != 0 the gradient is cleared in the same pass; if shadow_bf16 != NULL the bf16
- * copy read by the gather is refreshed in the same pass. */
-int lnerf_adam_step(float *p, float *g, float *m, float *v, void *shadow_bf16, int64_t n, float lr, float beta1,
-                    float beta2, float eps, int step, const int32_t *step_dev, float grad_scale, int zero_grad,
-                    lnerf_stream_t stream);
+ * copy read by the gather is refreshed in the same pass.  grad_dtype: LNERF_F32, or LNERF_BF16 to
+ * consume the bf16 wire buffer of the data-parallel all-reduce directly. */
+int lnerf_adam_step(float *p, void *g, int grad_dtype, float *m, float *v, void *shadow_bf16, int64_t n, float lr,
+                    float beta1, float beta2, float eps, int step, const int32_t *step_dev, float grad_scale,
+                    int zero_grad, lnerf_stream_t stream);
 /* `step_dev` (may be NULL): device-side step counter read by the kernels instead of the host `step`, so a
  * captured hipGraph of the whole optimisation step can be replayed; lnerf_adam_tick() increments it. */
 int lnerf_adam_tick(int32_t *step_dev, lnerf_stream_t stream);

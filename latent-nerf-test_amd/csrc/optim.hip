@@ -6,13 +6,35 @@
 
 namespace lnerf {
 
+// gradient element type: f32, or bf16 (the wire format of the data-parallel all-reduce: no cast back to f32)
+template <typename TG> struct Grad4;
+template <> struct Grad4<float> {
+    static __device__ __forceinline__ float4 load(const float *g, int64_t i) { return reinterpret_cast<const float4 *>(g)[i]; }
+    static __device__ __forceinline__ void zero(float *g, int64_t i) { reinterpret_cast<float4 *>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    static __device__ __forceinline__ float load1(const float *g, int64_t t) { return g[t]; }
+    static __device__ __forceinline__ void zero1(float *g, int64_t t) { g[t] = 0.f; }
+};
+template <> struct Grad4<uint16_t> {
+    static __device__ __forceinline__ float4 load(const uint16_t *g, int64_t i) {
+        const uint2 v = reinterpret_cast<const uint2 *>(g)[i];
+        return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xFFFF0000u), __uint_as_float(v.y << 16),
+                           __uint_as_float(v.y & 0xFFFF0000u));
+    }
+    static __device__ __forceinline__ void zero(uint16_t *g, int64_t i) { reinterpret_cast<uint2 *>(g)[i] = make_uint2(0u, 0u); }
+    static __device__ __forceinline__ float load1(const uint16_t *g, int64_t t) { return bf16_to_f32(g[t]); }
+    static __device__ __forceinline__ void zero1(uint16_t *g, int64_t t) { g[t] = 0; }
+};
+
+template <typename TG>
 __global__ void __launch_bounds__(256)
-k_adam(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+k_adam(float *__restrict__ p, TG *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
        uint16_t *__restrict__ shadow, int64_t n, AdamArgs a) {
     adam_bias(a);
+    const int zero_grad = a.zero_grad;
+    a.zero_grad = 0;  // (adam_one works on a register copy of g; the buffer is cleared below)
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        float4 P = reinterpret_cast<float4 *>(p)[i], G = reinterpret_cast<float4 *>(g)[i];
+        float4 P = reinterpret_cast<float4 *>(p)[i], G = Grad4<TG>::load(g, i);
         float4 Mv = reinterpret_cast<float4 *>(m)[i], V = reinterpret_cast<float4 *>(v)[i];
         adam_one(P.x, G.x, Mv.x, V.x, a);
         adam_one(P.y, G.y, Mv.y, V.y, a);
@@ -21,7 +43,7 @@ k_adam(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, floa
         reinterpret_cast<float4 *>(p)[i] = P;
         reinterpret_cast<float4 *>(m)[i] = Mv;
         reinterpret_cast<float4 *>(v)[i] = V;
-        if (a.zero_grad) reinterpret_cast<float4 *>(g)[i] = G;
+        if (zero_grad) Grad4<TG>::zero(g, i);
         if (shadow) {
             uint2 s;
             s.x = (uint32_t)f32_to_bf16(P.x) | ((uint32_t)f32_to_bf16(P.y) << 16);
@@ -32,10 +54,10 @@ k_adam(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, floa
     // tail (n % 4 elements)
     const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x == 0 && t < n) {
-        float P = p[t], G = g[t], Mv = m[t], V = v[t];
+        float P = p[t], G = Grad4<TG>::load1(g, t), Mv = m[t], V = v[t];
         adam_one(P, G, Mv, V, a);
         p[t] = P; m[t] = Mv; v[t] = V;
-        if (a.zero_grad) g[t] = G;
+        if (zero_grad) Grad4<TG>::zero1(g, t);
         if (shadow) shadow[t] = f32_to_bf16(P);
     }
 }
@@ -89,12 +111,13 @@ int lnerf_adam_tick(int32_t *step_dev, lnerf_stream_t stream) {
     return LNERF_OK;
 }
 
-int lnerf_adam_step(float *p, float *g, float *m, float *v, void *shadow_bf16, int64_t n, float lr, float beta1,
-                    float beta2, float eps, int step, const int32_t *step_dev, float grad_scale, int zero_grad,
-                    lnerf_stream_t stream) {
+int lnerf_adam_step(float *p, void *g, int grad_dtype, float *m, float *v, void *shadow_bf16, int64_t n, float lr,
+                    float beta1, float beta2, float eps, int step, const int32_t *step_dev, float grad_scale,
+                    int zero_grad, lnerf_stream_t stream) {
     LNERF_REQUIRE(n >= 0, "adam_step: negative n");
     LNERF_REQUIRE(step_dev || step >= 1, "adam_step: step must be >= 1 (got %d)", step);
     LNERF_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "adam_step: betas must be in [0,1)");
+    LNERF_REQUIRE(grad_dtype == LNERF_F32 || grad_dtype == LNERF_BF16, "adam_step: bad gradient dtype tag");
     if (n == 0) return LNERF_OK;
     LNERF_REQUIRE(p && g && m && v, "adam_step: null pointer");
     LNERF_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
@@ -110,8 +133,12 @@ int lnerf_adam_step(float *p, float *g, float *m, float *v, void *shadow_bf16, i
     int64_t blocks = div_up(div_up(n, 4), 256);
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, g, m, v,
-                       (uint16_t *)shadow_bf16, n, a);
+    if (grad_dtype == LNERF_BF16)
+        hipLaunchKernelGGL(k_adam<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, (uint16_t *)g, m,
+                           v, (uint16_t *)shadow_bf16, n, a);
+    else
+        hipLaunchKernelGGL(k_adam<float>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, (float *)g, m, v,
+                           (uint16_t *)shadow_bf16, n, a);
     LNERF_CHECK_LAUNCH("adam_step");
     return LNERF_OK;
 }

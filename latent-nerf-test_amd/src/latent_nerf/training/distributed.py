@@ -69,8 +69,15 @@ class GradSync:
             self._wire[id(p)] = buf
         return buf
 
-    def allreduce(self):
-        """After this call every `.grad` holds the SUM over ranks (scale by 1/world in the optimiser)."""
+    def reduced(self):
+        """{parameter: tensor holding the reduced gradient} of the big buckets after allreduce(copy_back=False): the
+        bf16 wire buffers (FusedAdam.step(grads=...) reads them directly), else the `.grad` tensors themselves."""
+        return {p: self._wire.get(id(p), p.grad) if self.transport != torch.float32 and self.world > 1 else p.grad
+                for p in self.big}
+
+    def allreduce(self, copy_back=True):
+        """After this call every `.grad` holds the SUM over ranks (scale by 1/world in the optimiser).  With the bf16
+        transport and copy_back=False the sums of the big buckets stay in the wire buffers (see reduced())."""
         if self.world == 1:
             return
         pending = []
@@ -98,5 +105,5 @@ class GradSync:
                 o += p.numel()
         for h, wire, p in pending:
             h.wait()
-            if wire is not None:
+            if wire is not None and copy_back:
                 p.grad.copy_(wire)  # bf16 -> f32

@@ -70,7 +70,9 @@ class FusedAdam:
         if self.fused is not None and (self.fused.armed or self.fused.applied):
             raise RuntimeError("FusedAdam.zero_grad(): a fused table update is pending or already applied this step")
 
-    def step(self, grad_scale=None, set_to_none=True):
+    def step(self, grad_scale=None, set_to_none=True, grads=None):
+        """grads: optional {parameter: gradient tensor} overriding `.grad` for the big tensors -- f32, or the bf16
+        wire buffer of GradSync (`GradSync.reduced()`), which the Adam kernel then reads directly."""
         if grad_scale is None:
             grad_scale = self.grad_scale
         elif self.fused is not None and float(grad_scale) != float(self.grad_scale):
@@ -87,11 +89,15 @@ class FusedAdam:
                                        % (self.fused.applied, self.fused.armed, p.grad is not None))
                 self.fused.applied = 0
                 continue
-            if p.grad is None:
+            g = p.grad if grads is None else grads.get(p, p.grad)
+            if g is None:
                 continue
+            if g.dtype not in (torch.float32, torch.bfloat16) or g.numel() != p.numel() or not g.is_contiguous():
+                raise ValueError("FusedAdam: gradient must be a contiguous f32 or bf16 tensor of the parameter's size")
             shadow = enc.shadow() if (enc is not None and p is enc.embeddings) else None
-            _b.call("lnerf_adam_step", _p(p.data), _p(p.grad), _p(m), _p(v), _p(shadow), p.numel(), lr, b1, b2,
-                    self.eps, self.step_no, _p(self.step_dev), float(grad_scale), 0, _stream())
+            _b.call("lnerf_adam_step", _p(p.data), _p(g), _b.F32 if g.dtype == torch.float32 else _b.BF16, _p(m), _p(v),
+                    _p(shadow), p.numel(), lr, b1, b2, self.eps, self.step_no, _p(self.step_dev), float(grad_scale), 0,
+                    _stream())
         if self.small:
             for k, (p, m, v, lr) in enumerate(self.small):
                 if p.grad is None:

@@ -58,7 +58,7 @@ def test_argument_validation_fails_loudly(built_lib):
     rc = lib.lnerf_grid_encode_forward(P(16), 1.0, P(16), 0, 2, 4, offs, sc, rs, 8, None, 8, P(16), 0, 0, None)
     assert rc == -1 and b"level_dim" in lib.lnerf_last_error()
     with pytest.raises(B.LnerfError):
-        B.call("lnerf_adam_step", P(16), P(16), P(16), P(16), None, 8, 1e-3, 0.9, 0.99, 1e-15, 0, None, 1.0, 1, None)
+        B.call("lnerf_adam_step", P(16), P(16), B.F32, P(16), P(16), None, 8, 1e-3, 0.9, 0.99, 1e-15, 0, None, 1.0, 1, None)
 
 
 def test_ops_refuse_cpu_tensors(built_lib):

@@ -34,7 +34,22 @@ def _worker(rank, world, port, out, transport="f32"):
             p.grad = torch.randn(p.shape, generator=g)
         local = [table.grad.clone()] + [p.grad.clone() for p in small]
         sync = D.GradSync([table], small, transport=torch.bfloat16 if transport == "bf16" else torch.float32)
+        # first without the copy back: the bf16 sums stay in the wire buffer (what FusedAdam.step(grads=...) reads),
+        # the f32 transport reduces in place either way
+        keep = table.grad.clone()
+        sync.allreduce(copy_back=False)
+        red = sync.reduced()[table]
+        if transport == "bf16":
+            assert red.dtype == torch.bfloat16 and torch.equal(table.grad, keep)   # .grad untouched
+            wire_sum = red.float().clone()
+        else:
+            assert red is table.grad
+        table.grad = keep.clone()
+        for p, l in zip(small, local[1:]):
+            p.grad = l.clone()
         sync.allreduce()
+        if transport == "bf16":
+            assert torch.equal(table.grad, wire_sum)   # the copy back delivers exactly the wire buffer
         # gather every rank's local gradients to check the sum on rank 0
         gathered = [None] * world
         dist.all_gather_object(gathered, [t.numpy() for t in local])

@@ -475,11 +475,22 @@ def test_adam_step_matches_torch(dev):
         ref.grad = g.clone() * 0.5
         opt.step()
         gd = g.to(dev)
-        B.call("lnerf_adam_step", _p(p), _p(gd), _p(m), _p(v), _p(shadow), n, 1e-2, 0.9, 0.99, 1e-15, step, None, 0.5, 1,
-               _stream())
+        B.call("lnerf_adam_step", _p(p), _p(gd), B.F32, _p(m), _p(v), _p(shadow), n, 1e-2, 0.9, 0.99, 1e-15, step, None,
+               0.5, 1, _stream())
         assert float(gd.abs().max()) == 0.0  # gradient cleared in the same pass
     _close(p, ref, 1e-5, 1e-6, "adam params")
     assert torch.equal(shadow.cpu(), p.cpu().to(torch.bfloat16))
+    # bf16 gradients (the wire buffer of the data-parallel all-reduce) == the same gradients widened to f32, bit for bit
+    pa, ma, va = p.clone(), m.clone(), v.clone()
+    pb, mb, vb = p.clone(), m.clone(), v.clone()
+    gb = torch.randn(n, device=dev).to(torch.bfloat16)
+    gf = gb.float()
+    B.call("lnerf_adam_step", _p(pa), _p(gf), B.F32, _p(ma), _p(va), None, n, 1e-2, 0.9, 0.99, 1e-15, 4, None, 0.125, 0,
+           _stream())
+    B.call("lnerf_adam_step", _p(pb), _p(gb), B.BF16, _p(mb), _p(vb), None, n, 1e-2, 0.9, 0.99, 1e-15, 4, None, 0.125, 1,
+           _stream())
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    assert float(gb.float().abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("capturable", [False, True])
