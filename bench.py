@@ -106,6 +106,7 @@ def make_step(net, pose, intr, bg, grad, opt, world, transport=torch.float32, pe
     from src.latent_nerf.training.distributed import GradSync
     small = [p for p in net.parameters() if p is not net.encoder.embeddings]
     sync = GradSync([net.encoder.embeddings], small, transport=transport)
+    sync.attach_sink(net.encoder)        # N > 1 with bf16 on the wire: backward writes the wire buffer directly
 
     def fwd_bwd():
         rays_o, rays_d = rm.get_rays(pose, intr, H, W)
@@ -259,8 +260,9 @@ def main():
     opt = FusedAdam(net.get_params(LR if args.lr is None else args.lr), betas=(0.9, 0.99), eps=1e-15, encoder=net.encoder, capturable=True,
                     fuse_table_update=fuse)
     opt.grad_scale = 1.0 / world
-    scatter_call = "lnerf_grid_encode_backward_adam" if fuse else "lnerf_grid_encode_backward"
     tr = args.precision if args.grad_transport == "auto" else args.grad_transport
+    scatter_call = ("lnerf_grid_encode_backward_adam" if fuse else
+                    "lnerf_grid_encode_backward_bf16" if (world > 1 and tr == "bf16") else "lnerf_grid_encode_backward")
     step, fwd_bwd, opt_step, sync = make_step(net, pose, intr, bg, grad, opt, world,
                                               torch.bfloat16 if tr == "bf16" else torch.float32, bool(args.perturb))
 
@@ -313,6 +315,12 @@ def main():
     emb = net.encoder.embeddings.detach()
     if not bool(torch.isfinite(emb).all()) or not all(bool(torch.isfinite(p.detach()).all()) for p in net.parameters()):
         raise SystemExit("bench: non-finite parameters after the timed steps")
+    if world > 1:  # data parallel: every rank applied the same update, the replicas must still be bit-identical
+        chk = torch.stack([emb.double().sum(), emb.double().abs().sum(), net.w2.detach().double().sum()])
+        allc = [torch.empty_like(chk) for _ in range(world)]
+        dist.all_gather(allc, chk)
+        if not all(torch.equal(allc[0], c) for c in allc):
+            raise SystemExit("bench: the replicas diverged (rank checksums differ)")
     if float((emb - emb0).abs().max()) == 0.0 and (args.lr is None or args.lr != 0.0):
         raise SystemExit("bench: the hash table did not change during the timed steps (optimiser not applied?)")
 
@@ -341,7 +349,7 @@ def main():
         g_ms = timer.mean_ms("lnerf_grid_encode_forward")
         s_ms = timer.mean_ms(scatter_call)
         achieved = M * bytes_per_sample / (g_ms * 1e-3) / 1e9
-        scatter = M * 1164 / (s_ms * 1e-3) / 1e9
+        scatter = M * 1164 / (s_ms * 1e-3) / 1e9 if s_ms > 0 else None
         traffic = None   # HBM-side bytes per launch of the gather from the committed PMC passes (profiles/)
         pmc = os.path.join(ROOT, "profiles", "pmc_gather_latest.json")
         if os.path.exists(pmc):
@@ -373,7 +381,8 @@ def main():
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "bytes_per_sample": bytes_per_sample, "samples_per_launch": M, "kernel_ms": g_ms},
             "scatter": {"kernel": scatter_call.replace("lnerf_", "") + " (H6: two-pass bucketed scatter"
-                                  + (" + fused Adam step of the table)" if fuse else ")"),
+                                  + (" + fused Adam step of the table)" if fuse else
+                                     ", gradient written in the bf16 wire format)" if scatter_call.endswith("bf16") else ")"),
                         "algorithmic_GBps": scatter, "kernel_ms": s_ms},
         }
         if breakdown:

@@ -158,6 +158,16 @@ int lnerf_grid_encode_backward(const float *xyzs, float bound, const void *dfeat
                                const int32_t *res_host, int64_t m_host, const int32_t *m_dev, int64_t level_stride,
                                float *dtable, int variant, void *workspace, size_t workspace_bytes,
                                lnerf_stream_t stream);
+/* Backward of the hash grid with the gradient WRITTEN (not accumulated) as bf16 pairs, the wire format of
+ * the data-parallel all-reduce: `grad_bf16` ([rows, 2] bf16) needs no zero fill and every row is written
+ * exactly once by the kernel that finishes its sum -- no read-modify-write of an f32 table gradient and no
+ * cast afterwards.  variant 2 or 3.  `dtable_zero` (f32 [rows, 2]) only carries the records of overflowing
+ * buckets; it must be ZERO on entry and is zero again on return. */
+int lnerf_grid_encode_backward_bf16(const float *xyzs, float bound, const void *dfeat, int dfeat_dtype, int num_levels,
+                                    int level_dim, const int32_t *offsets_host, const float *scales_host,
+                                    const int32_t *res_host, int64_t m_host, const int32_t *m_dev,
+                                    int64_t level_stride, float *dtable_zero, int variant, void *workspace,
+                                    size_t workspace_bytes, void *grad_bf16, lnerf_stream_t stream);
 /* Backward of the hash grid fused with the table's optimiser step (single-GPU training: no gradient
  * exchange sits between the two).  Same scatter as above (variant 2 or 3), but the kernel that
  * finishes a row's sum (pass 2, or the finishing kernel of the sliced coarse levels) applies

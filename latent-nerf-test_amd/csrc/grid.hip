@@ -688,8 +688,10 @@ constexpr int REDUCE_SLICE_RECS = 16384;
 // through HBM (42 -> 26 bytes per table entry and step).
 struct FusedUpdate {
     float *p, *m, *v;
-    uint16_t *shadow;  // optional bf16 copy of p, refreshed in the same pass
+    uint16_t *shadow;    // optional bf16 copy of p, refreshed in the same pass
     AdamArgs a;
+    uint16_t *grad_out;  // when set: no Adam step -- every row's finished sum is WRITTEN as bf16 here instead (the wire
+                         // format of the data-parallel all-reduce: no zero fill, no read-modify-write, no cast)
 };
 
 // power-of-two scale of a level's fixed-point sums: largest |value| < 2^(e-126) -> scale 2^(170-e) puts it below
@@ -795,6 +797,15 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
                 reinterpret_cast<float2 *>(dst)[r] = make_float2(0.f, 0.f);
             }
         };
+        if (fu.grad_out) {  // gradient output in the wire format: one bf16 pair per row
+            uint32_t *go = reinterpret_cast<uint32_t *>(fu.grad_out) + R0;
+            for (int r = tid; r < rows; r += RT) {
+                float g0, g1;
+                grad_of(r, g0, g1);
+                go[r] = (uint32_t)f32_to_bf16(g0) | ((uint32_t)f32_to_bf16(g1) << 16);
+            }
+            return;
+        }
         // usual case (full bucket, even first row): two rows per lane and access (16 B).  (Fetching the lane's
         // parameters and moments ahead of the record stream was measured 35 us SLOWER.)
         constexpr int NQ = (BK_ROWS / 2 + RT - 1) / RT;  // row pairs per lane
@@ -885,6 +896,10 @@ k_scatter_finish(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
             g0 = d.x + g0;
             g1 = d.y + g1;
             *d2 = make_float2(0.f, 0.f);
+        }
+        if (fu.grad_out) {
+            reinterpret_cast<uint32_t *>(fu.grad_out)[R] = (uint32_t)f32_to_bf16(g0) | ((uint32_t)f32_to_bf16(g1) << 16);
+            return;
         }
         AdamArgs a = fu.a;
         adam_bias(a);
@@ -1302,6 +1317,22 @@ int lnerf_grid_encode_backward(const float *xyzs, float bound, const void *dfeat
                             m_host, m_dev, level_stride, dtable, variant, workspace, workspace_bytes, stream, nullptr);
 }
 
+int lnerf_grid_encode_backward_bf16(const float *xyzs, float bound, const void *dfeat, int dfeat_dtype, int num_levels,
+                                    int level_dim, const int32_t *offsets_host, const float *scales_host,
+                                    const int32_t *res_host, int64_t m_host, const int32_t *m_dev,
+                                    int64_t level_stride, float *dtable_zero, int variant, void *workspace,
+                                    size_t workspace_bytes, void *grad_bf16, lnerf_stream_t stream) {
+    LNERF_REQUIRE(grad_bf16 && dtable_zero, "grid_encode_backward_bf16: null output");
+    LNERF_REQUIRE((((uintptr_t)grad_bf16 | (uintptr_t)dtable_zero) & 15) == 0,
+                  "grid_encode_backward_bf16: buffers must be 16-byte aligned");
+    FusedUpdate fu;
+    memset(&fu, 0, sizeof(fu));
+    adam_host_args(fu.a, 0.f, 0.5f, 0.5f, 1.f, 1, nullptr, 1.f, 0);  // (unused in this mode)
+    fu.grad_out = (uint16_t *)grad_bf16;
+    return scatter_backward(xyzs, bound, dfeat, dfeat_dtype, num_levels, level_dim, offsets_host, scales_host, res_host,
+                            m_host, m_dev, level_stride, dtable_zero, variant, workspace, workspace_bytes, stream, &fu);
+}
+
 int lnerf_grid_encode_backward_adam(const float *xyzs, float bound, const void *dfeat, int dfeat_dtype, int num_levels,
                                     int level_dim, const int32_t *offsets_host, const float *scales_host,
                                     const int32_t *res_host, int64_t m_host, const int32_t *m_dev,
@@ -1318,6 +1349,7 @@ int lnerf_grid_encode_backward_adam(const float *xyzs, float bound, const void *
     LNERF_REQUIRE(!shadow_bf16 || ((uintptr_t)shadow_bf16 & 7) == 0, "grid_encode_backward_adam: shadow must be 8-byte aligned");
     FusedUpdate fu;
     fu.p = table; fu.m = exp_avg; fu.v = exp_avg_sq; fu.shadow = (uint16_t *)shadow_bf16;
+    fu.grad_out = nullptr;
     adam_host_args(fu.a, lr, beta1, beta2, eps, step, step_dev, grad_scale, 0);
     return scatter_backward(xyzs, bound, dfeat, dfeat_dtype, num_levels, level_dim, offsets_host, scales_host, res_host,
                             m_host, m_dev, level_stride, dtable_zero, variant, workspace, workspace_bytes, stream, &fu);

@@ -137,6 +137,30 @@ def grid_encode_backward_adam(xyzs, bound, dfeat, encoder, m_host, m_dev, level_
     fu.applied += 1
 
 
+class GradSink:
+    """Set on a GridEncoder (`encoder.grad_sink`) by GradSync.attach_sink(): the backward pass WRITES the table
+    gradient as bf16 into `wire` (lnerf_grid_encode_backward_bf16) -- the buffer the data-parallel all-reduce sends --
+    instead of accumulating an f32 `.grad`: no zero fill, no read-modify-write, no cast.  One backward per step."""
+
+    def __init__(self, table):
+        self.wire = torch.zeros(table.shape, device=table.device, dtype=torch.bfloat16)
+        self.zero = torch.zeros(table.shape, device=table.device, dtype=torch.float32)  # overflow records only
+        self.written = 0
+
+
+def grid_encode_backward_bf16(xyzs, bound, dfeat, encoder, m_host, m_dev, level_stride, variant):
+    sink = encoder.grad_sink
+    levels = encoder.levels
+    if variant < 2:
+        raise _b.LnerfError("the bf16 gradient output needs the bucketed scatter (variant 2 or 3)")
+    wst = scatter_workspace(levels, m_host, xyzs.device)
+    _b.call("lnerf_grid_encode_backward_bf16", _chk(xyzs, "xyzs"), float(bound), _chk(dfeat, "dfeat"), _b.F32,
+            levels.num_levels, levels.level_dim, levels.c_offsets, levels.c_scales, levels.c_res, int(m_host),
+            _chk(m_dev, "m_dev", torch.int32, allow_none=True), int(level_stride), _p(sink.zero), int(variant), _p(wst),
+            wst.numel(), _p(sink.wire), _stream())
+    sink.written += 1
+
+
 class _GridEncode(torch.autograd.Function):
     """feat = encode(xyzs; table).  `table` is the f32 master parameter (gradient target);
     `shadow` an optional bf16 copy that the gather actually reads."""
@@ -165,6 +189,10 @@ class _GridEncode(torch.autograd.Function):
             grid_encode_backward_adam(xyzs, bound, dfeat, enc, m_host, m_dev if ctx.has_mdev else None, level_stride,
                                       variant)
             return (None,) * 12
+        if enc is not None and enc.grad_sink is not None:
+            grid_encode_backward_bf16(xyzs, bound, dfeat, enc, m_host, m_dev if ctx.has_mdev else None, level_stride,
+                                      variant)
+            return (None,) * 12
         dtable = torch.zeros(shape, device=dev, dtype=torch.float32)
         grid_encode_backward(xyzs, bound, dfeat, levels, m_host, m_dev if ctx.has_mdev else None, level_stride,
                              dtable, variant)
@@ -189,6 +217,7 @@ class GridEncoder(nn.Module):
         self._shadow = None
         self._shadow_version = -1
         self.fused_update = None  # FusedTableUpdate, installed by FusedAdam(fuse_table_update=True)
+        self.grad_sink = None     # GradSink, installed by GradSync.attach_sink() (data parallel, bf16 on the wire)
 
     def reset_parameters(self):
         self.embeddings.data.uniform_(-1e-4, 1e-4)

@@ -110,6 +110,9 @@ class _HashMLPField(torch.autograd.Function):
         if encoder.fused_update is not None and encoder.fused_update.take():  # armed: the scatter applies the table's Adam step
             E.grid_encode_backward_adam(xyzs, bound, dfeat, encoder, m_host, m_dev, level_stride, encoder.scatter_variant)
             dtable = None
+        elif encoder.grad_sink is not None:  # data parallel: the gradient goes straight into the bf16 wire buffer
+            E.grid_encode_backward_bf16(xyzs, bound, dfeat, encoder, m_host, m_dev, level_stride, encoder.scatter_variant)
+            dtable = None
         else:
             dtable = torch.zeros(tshape, device=dev, dtype=torch.float32)
             E.grid_encode_backward(xyzs, bound, dfeat, encoder.levels, m_host, m_dev, level_stride, dtable,

@@ -54,6 +54,7 @@ class GradSync:
         self.transport = transport
         self._flat = None
         self._wire = {}
+        self._sinks = {}
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
     def _flat_buffer(self):
@@ -69,6 +70,22 @@ class GradSync:
             self._wire[id(p)] = buf
         return buf
 
+    def attach_sink(self, encoder):
+        """bf16 transport, more than one rank: let the encoder's backward write the table gradient straight into the
+        wire buffer this object all-reduces (GradSink): the table then has no `.grad`, use reduced() for the sums.
+        No-op otherwise.  One backward per step."""
+        if self.world == 1 or self.transport == torch.float32:
+            return None
+        from ..models.encoding import GradSink
+        p = encoder.embeddings
+        if not any(p is q for q in self.big):
+            raise ValueError("attach_sink: encoder.embeddings is not one of the big buckets")
+        sink = GradSink(p.data)
+        self._wire[id(p)] = sink.wire
+        self._sinks[id(p)] = sink
+        encoder.grad_sink = sink
+        return sink
+
     def reduced(self):
         """{parameter: tensor holding the reduced gradient} of the big buckets after allreduce(copy_back=False): the
         bf16 wire buffers (FusedAdam.step(grads=...) reads them directly), else the `.grad` tensors themselves."""
@@ -82,6 +99,14 @@ class GradSync:
             return
         pending = []
         for p in self.big:
+            sink = self._sinks.get(id(p))
+            if sink is not None:  # the backward pass wrote this rank's gradient into the wire buffer itself
+                # (no host-side count of backward passes here: a replayed hipGraph writes the buffer without
+                # running any Python)
+                if copy_back:
+                    raise RuntimeError("GradSync: a sinked gradient has no f32 `.grad` to copy back into")
+                pending.append((dist.all_reduce(sink.wire, group=self.group, async_op=True), None, None))
+                continue
             if p.grad is None:
                 raise RuntimeError("GradSync: a bucketed parameter has no gradient on this rank")
             if self.transport == torch.float32:

@@ -538,3 +538,34 @@ def test_occupancy_helpers(dev):
     scratch = torch.zeros(2, device=dev)
     B.call("lnerf_occ_mean", _p(gg), gg.numel(), _p(mean), _p(scratch), _stream())
     assert abs(float(mean) - float(ref_g.clamp(min=0).mean())) < 1e-4
+
+
+def test_scatter_bf16_gradient_output_matches_f32_path(dev):
+    """lnerf_grid_encode_backward_bf16 (gradient WRITTEN in the all-reduce's wire format) == the f32 scatter followed
+    by a round-to-nearest cast, bit for bit; a second call overwrites (no accumulation) and the overflow scratch is
+    left zero."""
+    from src.latent_nerf.models import encoding as E
+    enc = E.GridEncoder(scatter_variant=3).to(dev)
+    levels = enc.levels
+    M = 150000
+    g = torch.Generator().manual_seed(4)
+    x = ((torch.rand(M, 3, generator=g) * 2 - 1) * 0.999).to(dev)
+    dfeat = torch.randn(16, M, 2, generator=g).to(dev)
+    m_dev = torch.tensor([M], dtype=torch.int32, device=dev)
+    ref = torch.zeros(levels.n_rows, 2, device=dev)
+    E.grid_encode_backward(x, 1.0, dfeat, levels, M, m_dev, M, ref, variant=3)
+    enc.grad_sink = E.GradSink(enc.embeddings.data)
+    enc.grad_sink.wire.fill_(7.0)                      # stale content must be overwritten everywhere
+    for _ in range(2):
+        E.grid_encode_backward_bf16(x, 1.0, dfeat, enc, M, m_dev, M, 3)
+    assert torch.equal(enc.grad_sink.wire, ref.to(torch.bfloat16))
+    assert float(enc.grad_sink.zero.abs().max()) == 0.0
+    # clustered points: buckets overflow into the f32 scratch, which the finishing kernels consume and clear
+    xc = (torch.tensor([[0.1234, -0.3456, 0.4567]]) + torch.rand(6000, 3, generator=g) * 1e-5).to(dev)
+    dc = torch.randn(16, 6000, 2, generator=g).to(dev)
+    refc = torch.zeros(levels.n_rows, 2, device=dev)
+    E.grid_encode_backward(xc, 1.0, dc, levels, 6000, None, 6000, refc, variant=3)
+    E.grid_encode_backward_bf16(xc, 1.0, dc, enc, 6000, None, 6000, 3)
+    got = enc.grad_sink.wire.float()
+    assert float((got - refc).abs().max()) <= 2e-2 * float(refc.abs().max())   # overflow path: atomics order + bf16
+    assert float(enc.grad_sink.zero.abs().max()) == 0.0
