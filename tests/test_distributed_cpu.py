@@ -61,6 +61,35 @@ def _worker(rank, world, port, out, transport="f32"):
                     assert torch.equal(p.grad, p.grad.to(torch.bfloat16).float())
                 else:
                     assert torch.allclose(p.grad, ref, atol=1e-6)
+        if transport == "bf16":
+            # gradient sink: the backward pass writes this rank's table gradient straight into the wire buffer
+            # (GridEncoder.grad_sink / lnerf_grid_encode_backward_bf16); emulated here by filling the buffer by hand
+            class _Enc:
+                pass
+            enc = _Enc()
+            enc.embeddings = table
+            enc.grad_sink = None
+            sync2 = D.GradSync([table], small, transport=torch.bfloat16)
+            sink = sync2.attach_sink(enc)
+            assert enc.grad_sink is sink and sink.wire.dtype == torch.bfloat16 and float(sink.zero.abs().max()) == 0.0
+            sink.wire.copy_(local[0])
+            for p, l in zip(small, local[1:]):
+                p.grad = l.clone()
+            keep_grad = table.grad
+            table.grad = None                      # a sinked table has no .grad
+            sync2.allreduce(copy_back=False)
+            assert sync2.reduced()[table] is sink.wire
+            got = [torch.empty_like(sink.wire) for _ in range(world)]
+            dist.all_gather(got, sink.wire)
+            assert all(torch.equal(got[0], w) for w in got)                      # same sums on every rank
+            ref16 = sum(torch.from_numpy(gathered[r][0]).to(torch.bfloat16).float() for r in range(world))
+            assert torch.allclose(sink.wire.float(), ref16, rtol=2e-2, atol=2e-2)
+            try:
+                sync2.allreduce(copy_back=True)
+                raise AssertionError("copy_back into a sinked gradient must be refused")
+            except RuntimeError:
+                pass
+            table.grad = keep_grad
         # identical optimiser step on every rank -> replicas stay bit-identical
         opt = torch.optim.Adam([table] + small, lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
         for p in [table] + small:
