@@ -101,6 +101,50 @@ def main():
         t = timed(fns, rounds=10)
         res["scatter_ms(median,min)"] = t
 
+    if "update" in which:
+        # the three ways to get from dfeat to an updated table (real dfeat of the bench step, random-init state):
+        # fused (N = 1), bf16 gradient sink + Adam reading bf16 (N > 1, bf16 wire), f32 gradient + Adam (N > 1, f32)
+        import src.latent_nerf.models.encoding as Emod
+        from src.latent_nerf.training.optimizer import FusedAdam
+        from src.latent_nerf.raymarching.raymarching import _p, _stream
+        store = {}
+        orig = Emod.grid_encode_backward
+
+        def grab(xyzs_, bound_, dfeat_, *a, **k):
+            store["dfeat"] = dfeat_.clone()
+            return orig(xyzs_, bound_, dfeat_, *a, **k)
+        Emod.grid_encode_backward = grab
+        out2 = net.render(rays_o, rays_d, bg_color=bg, perturb=False)
+        out2["image"].backward(gradient=grad)
+        Emod.grid_encode_backward = orig
+        dfeat = store["dfeat"]
+        enc = net.encoder
+        emb = enc.embeddings
+        opt = FusedAdam([{"params": [emb], "lr": 1e-7}], encoder=enc, fuse_table_update=True)
+        m, v = opt.big[0][1], opt.big[0][2]
+        sink = Emod.GradSink(emb.data)
+        zero = torch.zeros_like(emb.data)
+
+        def fused():
+            opt.fused.armed = False
+            Emod.grid_encode_backward_adam(xyzs, 1.0, dfeat, enc, cap, m_dev, cap, 3)
+
+        def sink_path():
+            enc.grad_sink = sink
+            Emod.grid_encode_backward_bf16(xyzs, 1.0, dfeat, enc, cap, m_dev, cap, 3)
+            enc.grad_sink = None
+            B.call("lnerf_adam_step", _p(emb.data), _p(sink.wire), B.BF16, _p(m), _p(v), None, emb.numel(), 1e-7, 0.9, 0.99,
+                   1e-15, 1, None, 1.0, 0, _stream())
+
+        def f32_path():
+            zero.zero_()
+            Emod.grid_encode_backward(xyzs, 1.0, dfeat, levels, cap, m_dev, cap, zero, variant=3)
+            B.call("lnerf_adam_step", _p(emb.data), _p(zero), B.F32, _p(m), _p(v), None, emb.numel(), 1e-7, 0.9, 0.99,
+                   1e-15, 1, None, 1.0, 0, _stream())
+        res["table_update_ms(median,min)"] = timed({"fused_backward_adam": fused, "bf16_sink_then_adam": sink_path,
+                                                    "f32_grad_then_adam": f32_path}, rounds=10)
+        enc.fused_update = None
+
     if "scatter_levels" in which:
         # one launch pair per level (num_levels = 1 slices of the level table): per-level cost under rocprofv3
         import ctypes
