@@ -76,6 +76,29 @@ def test_bf16_training_step_runs(dev, tmp_path):
     assert bool(torch.isfinite(tr.nerf.w1).all())
 
 
+def test_multi_view_steps_accumulate_and_match_unfused_single_view(dev, tmp_path):
+    """Two views per step: the table update cannot be fused into one backward pass, gradients accumulate over the
+    views and the ordinary Adam kernel applies them.  And with one view per step the fused table update (default) and
+    the ordinary path give the same table, bit for bit (same seeds, same poses)."""
+    from src.latent_nerf.training.trainer import Trainer
+    cfg = _cfg(tmp_path, **{"optim.views_per_step": 2, "optim.iters": 6, "log.save_interval": 1000, "log.exp_name": "v2"})
+    tr = Trainer(cfg, device=dev)
+    assert tr.optimizer.fused is None
+    before = tr.nerf.encoder.embeddings.detach().clone()
+    tr.train()
+    assert tr.train_step == 6 and bool(torch.isfinite(tr.nerf.encoder.embeddings).all())
+    assert float((tr.nerf.encoder.embeddings.detach() - before).abs().max()) > 0
+    tabs = []
+    for fuse in (True, False):
+        c = _cfg(tmp_path, **{"optim.iters": 5, "log.save_interval": 1000, "log.exp_name": "f%d" % fuse,
+                              "optim.fuse_table_update": fuse})
+        t = Trainer(c, device=dev)
+        assert (t.optimizer.fused is not None) == fuse
+        t.train()
+        tabs.append(t.nerf.encoder.embeddings.detach().clone())
+    assert torch.equal(tabs[0], tabs[1])
+
+
 def test_mesh_winding_distance_and_shape_guidance(dev, tmp_path):
     """csrc/mesh.hip against the float64 oracle on a synthetic closed mesh (5120-face icosphere, the size of
     the reference's shapes/teddy.obj), occupancy seeding from the mesh, and the shape loss driving sigma."""
