@@ -63,6 +63,8 @@ const char *lnerf_build_info(void);
  *                              blockIdx.y, 1 = XCD-aware, 2 (default) = persistent workgroups that
  *                              stride over the (tile, level) list and prefetch the next item's inputs.
  *   "scatter_bin_wgs":         persistent workgroups of map 2 (default 768 = 3 per CU).
+ *   "scatter_bin_spt":         samples per thread of the binning pass with 8-byte records, 1 (default) or 2
+ *                              (1024-sample items: half the per-item costs per sample, measured slower).
  *   "scatter_bin_debug":       TIMING-ONLY experiment switch (non-zero values give wrong sums; refused
  *                              unless the environment variable LNERF_TIMING_EXPERIMENTS is set).
  *   "gather_pair_loads":       1 (default) = x-adjacent vertices fetched with one load where adjacent.

@@ -412,26 +412,30 @@ __device__ unsigned long long g_bin_stamps[16];
 #define BIN_STAMP_FLUSH() do { } while (0)
 #endif
 
-template <typename TG, int BIN_T, typename REC>
-__global__ void __launch_bounds__(BIN_T, BIN_T == 512 ? 6 : (BIN_T == 1024 ? 4 : 3))
+template <typename TG, int BIN_T, typename REC, int SPT>
+__global__ void __launch_bounds__(BIN_T, SPT == 2 ? 4 : (BIN_T == 512 ? 6 : (BIN_T == 1024 ? 4 : 3)))
 k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict__ dfeat, GridMeta meta, BucketMeta bm,
               int64_t m_host, const int32_t *__restrict__ m_dev, int64_t level_stride, int32_t *__restrict__ cursor,
               unsigned int *__restrict__ gmax, REC *__restrict__ recs, float *__restrict__ dtable, int variant,
               int skip_zero, int level_lo, int dbg) {
+    // SPT samples per thread: an item is IT = BIN_T * SPT consecutive samples of one level.  SPT = 2 halves the
+    // per-item costs (barriers, reservations and their latency, count scan) per sample and doubles the span a bucket
+    // gets from one reservation, at twice the LDS stage and register state.
+    constexpr int IT = BIN_T * SPT;
     __shared__ int s_cnt[2][BK_MAX_PER_LEVEL];  // records of this tile per bucket (double-buffered per item)
     __shared__ int s_base[BK_MAX_PER_LEVEL];  // first slot reserved in the bucket's global region
     __shared__ int s_off[BK_MAX_PER_LEVEL];   // first slot of the bucket in the LDS stage
     __shared__ unsigned int s_max[2];         // bit pattern of the tile's largest |value|
     __shared__ int s_dest[BK_MAX_PER_LEVEL];  // global slot of the bucket's first staged record, minus its stage offset
     __shared__ int s_ovf[2];                  // some bucket of this tile ran past its region
-    __shared__ REC s_stage[BIN_T * 8];        // the tile's records, grouped by bucket (48 KiB, 32 KiB packed)
-    __shared__ uint8_t s_bkt[REC::kPacked ? BIN_T * 8 : 4];  // packed records do not name their bucket: kept beside
+    __shared__ REC s_stage[IT * 8];           // the tile's records, grouped by bucket (48 KiB, 32 KiB packed, x SPT)
+    __shared__ uint8_t s_bkt[REC::kPacked ? IT * 8 : 4];  // packed records do not name their bucket: kept beside
     int64_t M = m_host;
     if (m_dev) { const int64_t md = *m_dev; M = md < M ? md : M; }
     const int L = meta.num_levels;
     const int tid = threadIdx.x, lane = tid & 63;
     // Work items = (level, tile) pairs.  variant 2 (default): a PERSISTENT 1-D grid of G workgroups (G a multiple
-    // of L, ~3 per CU = what the LDS stage admits); workgroup w takes items w, w+G, w+2G, ... of the tile-major list
+    // of L, as many per CU as the LDS stage admits); workgroup w takes items w, w+G, w+2G, ... of the tile-major list
     // and rotates the level by one per round, so every workgroup sees every level (balanced) and the 16 levels'
     // bucket cursors are hit evenly.  variants 0/1: the (level, tile) maps of the gather.
     TileMap tm;
@@ -447,21 +451,26 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
             lv = tm.level + level_lo;  // level_lo != 0 only with the blockIdx.y map (a launch over a level range)
             if (!tm.ok || lv >= L) return false;
         }
-        return tl * BIN_T < M;
+        return tl * IT < M;
     };
     // inputs of the NEXT item are fetched while the current one is ranked and staged (the pass waits on memory
     // round trips, not on arithmetic: rocprofv3 shows 64 % of the wave cycles parked)
-    float2 n_gg = make_float2(0.f, 0.f);
-    float n_x = 0.f, n_y = 0.f, n_z = 0.f;
+    float2 n_gg[SPT];
+    float n_x[SPT], n_y[SPT], n_z[SPT];
     auto fetch = [&](int lv, int64_t tl) {
-        const int64_t mm = tl * BIN_T + tid;
-        n_gg = make_float2(0.f, 0.f);
-        n_x = n_y = n_z = 0.f;
-        if (mm < M) {
-            n_gg = Feat2<TG>::load(dfeat + ((int64_t)lv * level_stride + mm) * 2, 0);
-            n_x = xyzs[mm * 3]; n_y = xyzs[mm * 3 + 1]; n_z = xyzs[mm * 3 + 2];
+#pragma unroll
+        for (int u = 0; u < SPT; ++u) {
+            const int64_t mm = tl * IT + u * BIN_T + tid;
+            n_gg[u] = make_float2(0.f, 0.f);
+            n_x[u] = n_y[u] = n_z[u] = 0.f;
+            if (mm < M) {
+                n_gg[u] = Feat2<TG>::load(dfeat + ((int64_t)lv * level_stride + mm) * 2, 0);
+                n_x[u] = xyzs[mm * 3]; n_y[u] = xyzs[mm * 3 + 1]; n_z[u] = xyzs[mm * 3 + 2];
+            }
         }
     };
+#pragma unroll
+    for (int u = 0; u < SPT; ++u) { n_gg[u] = make_float2(0.f, 0.f); n_x[u] = n_y[u] = n_z[u] = 0.f; }
     int l = 0;
     int64_t tile = 0;
     bool have = locate(0, l, tile);
@@ -485,8 +494,6 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
         REC *lrec = recs + bm.rstart[l];
         float *lt = dtable + (int64_t)off * 2;
         BIN_STAMP(0);
-        const int64_t m = tile * BIN_T + tid;
-        const bool valid = m < M;
         int l_next = 0;
         int64_t tile_next = 0;
         const bool have_next = locate(k + 1, l_next, tile_next);
@@ -494,52 +501,63 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
         // (T < T_thresh) get dsigma = drgb = 0 from the compositing backward, hence dfeat = 0 exactly: a run (or
         // sample) whose gradients are all zero appends nothing, and a wavefront of 64 such samples skips its
         // index arithmetic altogether.  The values themselves are computed later, behind the reservations.
-        const float2 gg = n_gg;
-        const bool nzg = valid && (gg.x != 0.f || gg.y != 0.f);
-        const unsigned long long nzmask = __ballot(nzg);
-        const bool wave_live = !skip_zero || nzmask != 0ull;
-        LevelPos p;
-        p.gx = p.gy = p.gz = 0; p.fx = p.fy = p.fz = 0.f;
-        RunInfo ri;
-        ri.start = lane; ri.tail = true;
-        uint32_t row[8];
-        int rank[8];
-        uint32_t emit = 0;  // bit c: this lane appends a record for corner c
-        if (wave_live) {
-            if (valid) p = level_pos_xyz(n_x, n_y, n_z, bound, scale);
-            corner_rows(p.gx, p.gy, p.gz, res, hsize, row);
-            if (compact) {  // wave-uniform branch
-                ri = wave_cell_runs(p.gx, p.gy, p.gz, valid);
-                const unsigned long long seg = (nzmask >> ri.start) & ((2ull << (lane - ri.start)) - 1ull);
-                emit = (valid && ri.tail && (!skip_zero || seg != 0ull)) ? 0xFFu : 0u;
-            } else {
-                emit = (valid && (!skip_zero || nzg)) ? 0xFFu : 0u;
-            }
-        } else {
+        float2 gg[SPT];
+        LevelPos p[SPT];
+        RunInfo ri[SPT];
+        uint32_t row[SPT][8];
+        int rank[SPT][8];
+        uint32_t emit[SPT];  // bit c: this lane appends a record for corner c
+        bool wave_live[SPT];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) row[c] = 0u;
+        for (int u = 0; u < SPT; ++u) {
+            const int64_t m = tile * IT + u * BIN_T + tid;
+            const bool valid = m < M;
+            gg[u] = n_gg[u];
+            const bool nzg = valid && (gg[u].x != 0.f || gg[u].y != 0.f);
+            const unsigned long long nzmask = __ballot(nzg);
+            wave_live[u] = !skip_zero || nzmask != 0ull;
+            p[u].gx = p[u].gy = p[u].gz = 0; p[u].fx = p[u].fy = p[u].fz = 0.f;
+            ri[u].start = lane; ri[u].tail = true;
+            emit[u] = 0;
+            if (wave_live[u]) {
+                if (valid) p[u] = level_pos_xyz(n_x[u], n_y[u], n_z[u], bound, scale);
+                corner_rows(p[u].gx, p[u].gy, p[u].gz, res, hsize, row[u]);
+                if (compact) {  // wave-uniform branch
+                    ri[u] = wave_cell_runs(p[u].gx, p[u].gy, p[u].gz, valid);
+                    const unsigned long long seg = (nzmask >> ri[u].start) & ((2ull << (lane - ri[u].start)) - 1ull);
+                    emit[u] = (valid && ri[u].tail && (!skip_zero || seg != 0ull)) ? 0xFFu : 0u;
+                } else {
+                    emit[u] = (valid && (!skip_zero || nzg)) ? 0xFFu : 0u;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) row[u][c] = 0u;
+            }
         }
         BIN_STAMP(1);
         // ---- B: rank every record inside its bucket (tile-local)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const bool e = (emit >> c) & 1u;
-            const int b = (int)(row[c] >> BK_SHIFT);
-            rank[c] = 0;
-            if (few_buckets) {  // all lanes of a wave mostly target one or two buckets
-                unsigned long long todo = __ballot(e);
-                while (todo) {
-                    const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
-                    const int bl = __builtin_amdgcn_readlane(b, leader);
-                    const unsigned long long mm = __ballot(e && b == bl);
-                    int base = 0;
-                    if (lane == leader) base = atomicAdd(&s_cnt[cur][bl], __popcll(mm));
-                    base = __builtin_amdgcn_readlane(base, leader);
-                    if (e && b == bl) rank[c] = base + mbcnt(mm);
-                    todo &= ~mm;
+        for (int u = 0; u < SPT; ++u) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const bool e = (emit[u] >> c) & 1u;
+                const int b = (int)(row[u][c] >> BK_SHIFT);
+                rank[u][c] = 0;
+                if (few_buckets) {  // all lanes of a wave mostly target one or two buckets
+                    unsigned long long todo = __ballot(e);
+                    while (todo) {
+                        const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+                        const int bl = __builtin_amdgcn_readlane(b, leader);
+                        const unsigned long long mm = __ballot(e && b == bl);
+                        int base = 0;
+                        if (lane == leader) base = atomicAdd(&s_cnt[cur][bl], __popcll(mm));
+                        base = __builtin_amdgcn_readlane(base, leader);
+                        if (e && b == bl) rank[u][c] = base + mbcnt(mm);
+                        todo &= ~mm;
+                    }
+                } else if (e) {
+                    rank[u][c] = atomicAdd(&s_cnt[cur][b], 1);
                 }
-            } else if (e) {
-                rank[c] = atomicAdd(&s_cnt[cur][b], 1);
             }
         }
         BIN_STAMP(2);
@@ -563,34 +581,37 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
         }
         if (have_next) fetch(l_next, tile_next);
         // ---- D: the values w * g (run sums on coarse levels) and the tile's largest |value|
-        float v0[8], v1[8];
-        if (wave_live) {
+        float v0[SPT][8], v1[SPT][8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const uint32_t bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
-                const float wx = bx ? p.fx : 1.0f - p.fx;
-                const float wy = by ? p.fy : 1.0f - p.fy;
-                const float wz = bz ? p.fz : 1.0f - p.fz;
-                const float w = (wx * wy) * wz;
-                v0[c] = w * gg.x;
-                v1[c] = w * gg.y;
-            }
-            if (compact) {
+        for (int u = 0; u < SPT; ++u) {
+            if (wave_live[u]) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    v0[c] = run_sum(v0[c], ri);
-                    v1[c] = run_sum(v1[c], ri);
+                    const uint32_t bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
+                    const float wx = bx ? p[u].fx : 1.0f - p[u].fx;
+                    const float wy = by ? p[u].fy : 1.0f - p[u].fy;
+                    const float wz = bz ? p[u].fz : 1.0f - p[u].fz;
+                    const float w = (wx * wy) * wz;
+                    v0[u][c] = w * gg[u].x;
+                    v1[u][c] = w * gg[u].y;
                 }
+                if (compact) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        v0[u][c] = run_sum(v0[u][c], ri[u]);
+                        v1[u][c] = run_sum(v1[u][c], ri[u]);
+                    }
+                }
+                float mx = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if ((emit[u] >> c) & 1u) mx = fmaxf(mx, fmaxf(fabsf(v0[u][c]), fabsf(v1[u][c])));
+                mx = wave_max_nonneg(mx);  // DPP wave max, one LDS atomic per wave (+floats order as uints)
+                if (lane == 0 && mx > 0.f) atomicMax(&s_max[cur], __float_as_uint(mx));
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { v0[u][c] = 0.f; v1[u][c] = 0.f; }
             }
-            float mx = 0.f;
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-                if ((emit >> c) & 1u) mx = fmaxf(mx, fmaxf(fabsf(v0[c]), fabsf(v1[c])));
-            mx = wave_max_nonneg(mx);  // DPP wave max, one LDS atomic per wave (+floats order as uints)
-            if (lane == 0 && mx > 0.f) atomicMax(&s_max[cur], __float_as_uint(mx));
-        } else {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) { v0[c] = 0.f; v1[c] = 0.f; }
         }
         BIN_STAMP(4);
         // ---- E: exclusive scan of the bucket counts.  EVERY wave computes it (4 buckets per lane, one DPP scan) and
@@ -616,12 +637,15 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
         }
         // ---- F: group the records by bucket in LDS
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            if ((emit >> c) & 1u) {
-                const int b = (int)(row[c] >> BK_SHIFT);
-                const int slot = s_off[b] + rank[c];
-                s_stage[slot] = REC::make(row[c], v0[c], v1[c]);
-                if (REC::kPacked) s_bkt[slot] = (uint8_t)b;
+        for (int u = 0; u < SPT; ++u) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if ((emit[u] >> c) & 1u) {
+                    const int b = (int)(row[u][c] >> BK_SHIFT);
+                    const int slot = s_off[b] + rank[u][c];
+                    s_stage[slot] = REC::make(row[u][c], v0[u][c], v1[u][c]);
+                    if (REC::kPacked) s_bkt[slot] = (uint8_t)b;
+                }
             }
         }
         BIN_STAMP(5);
@@ -640,7 +664,9 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
         if (tid == BIN_T - 1 && s_max[cur] != 0u) atomicMax(&gmax[l], s_max[cur]);  // one value per LEVEL
         // the prefetched inputs are pinned in registers here, so that the next item starts without waiting for the
         // stores below to be acknowledged (one in-order memory counter covers loads and stores)
-        asm volatile("" : "+v"(n_gg.x), "+v"(n_gg.y), "+v"(n_x), "+v"(n_y), "+v"(n_z));
+#pragma unroll
+        for (int u = 0; u < SPT; ++u)
+            asm volatile("" : "+v"(n_gg[u].x), "+v"(n_gg[u].y), "+v"(n_x[u]), "+v"(n_y[u]), "+v"(n_z[u]));
         // ---- G: copy out: consecutive lanes -> consecutive slots of (mostly) the same bucket: coalesced
         auto bucket_of = [&](const REC &r, int i) -> int {
             if constexpr (REC::kPacked) return (int)s_bkt[i];
@@ -933,6 +959,8 @@ static int g_gather_dedup_res = 512;
 static int g_bin_map = 2;
 // persistent workgroups of map 2 (3 per CU fit the 52 KiB LDS stage: 768 on 256 CUs)
 static int g_bin_wgs = 768;
+// samples per thread of the binning pass with the 8-byte records (1 or 2)
+static int g_bin_spt = 1;
 // samples per binning tile (256 or 512)
 static int g_bin_tile = 512;
 // drop contributions that are exactly zero (samples behind a ray's termination point)
@@ -1107,6 +1135,11 @@ int lnerf_set_tuning(const char *key, int value) {
         g_bin_map = value;
         return LNERF_OK;
     }
+    if (strcmp(key, "scatter_bin_spt") == 0) {
+        LNERF_REQUIRE(value == 1 || value == 2, "set_tuning: scatter_bin_spt must be 1 or 2");
+        g_bin_spt = value;
+        return LNERF_OK;
+    }
     if (strcmp(key, "scatter_bin_wgs") == 0) {
         LNERF_REQUIRE(value >= 1 && value <= 65535, "set_tuning: scatter_bin_wgs out of range");
         g_bin_wgs = value;
@@ -1233,25 +1266,28 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
     ScatterAux *aux = split ? scatter_aux(s) : nullptr;
     if (!aux) split = 0;
     const int BIN_T = packed ? 512 : g_bin_tile;
+    const int SPT = (packed && g_bin_spt == 2) ? 2 : 1;  // samples per thread (two only with the 8-byte records: LDS)
     auto launch_bin = [&](int l0, int l1) {
         dim3 g;
         if (g_bin_map == 2) {  // persistent: G workgroups, G a multiple of the level count
-            int64_t G = (int64_t)(g_bin_wgs / num_levels) * num_levels;
-            const int64_t items = div_up(m_host, BIN_T) * num_levels;
+            const int wgs = SPT == 2 ? (g_bin_wgs * 2) / 3 : g_bin_wgs;  // 2 instead of 3 workgroups per CU
+            int64_t G = (int64_t)(wgs / num_levels) * num_levels;
+            const int64_t items = div_up(m_host, (int64_t)BIN_T * SPT) * num_levels;
             if (G > items) G = items;
             if (G < num_levels) G = num_levels;
             g = dim3((unsigned)G, 1, 1);
         } else {
-            launch_dims(g_bin_map, g_bin_map == 0 ? (l1 - l0) : num_levels, div_up(m_host * 256, BIN_T), g);
+            launch_dims(g_bin_map, g_bin_map == 0 ? (l1 - l0) : num_levels, div_up(m_host * 256, (int64_t)BIN_T * SPT), g);
         }
-#define LAUNCH_BIN(T, REC)                                                                                          \
-    hipLaunchKernelGGL((k_scatter_bin<float, T, REC>), g, dim3(T), 0, s, xyzs, bound, (const float *)dfeat, meta, bm, \
-                       m_host, m_dev, level_stride, cursor, gmax, (REC *)rec, dtable, g_bin_map,                    \
+#define LAUNCH_BIN(T, REC, S)                                                                                          \
+    hipLaunchKernelGGL((k_scatter_bin<float, T, REC, S>), g, dim3(T), 0, s, xyzs, bound, (const float *)dfeat, meta, bm, \
+                       m_host, m_dev, level_stride, cursor, gmax, (REC *)rec, dtable, g_bin_map,                       \
                        g_skip_zero, l0, g_bin_dbg)
-        if (packed) LAUNCH_BIN(512, Rec8);
-        else if (BIN_T == 256) LAUNCH_BIN(256, Rec12);
-        else if (BIN_T == 1024) LAUNCH_BIN(1024, Rec12);
-        else LAUNCH_BIN(512, Rec12);
+        if (packed && SPT == 2) LAUNCH_BIN(512, Rec8, 2);
+        else if (packed) LAUNCH_BIN(512, Rec8, 1);
+        else if (BIN_T == 256) LAUNCH_BIN(256, Rec12, 1);
+        else if (BIN_T == 1024) LAUNCH_BIN(1024, Rec12, 1);
+        else LAUNCH_BIN(512, Rec12, 1);
 #undef LAUNCH_BIN
     };
     FusedUpdate fu0;

@@ -94,11 +94,13 @@ def main():
         res["dfeat_zero_fraction"] = float((dfeat[:, :M, :] == 0).all(-1).float().mean())
         dtable = torch.zeros_like(table)
         fns = {}
-        for var in (2, 3):
-            def f(var=var):
-                E.grid_encode_backward(xyzs, 1.0, dfeat, levels, cap, m_dev, cap, dtable, variant=var)
-            fns["variant%d" % var] = f
+        for spt in (1, 2):
+            def f(spt=spt):
+                B.call("lnerf_set_tuning", b"scatter_bin_spt", spt)
+                E.grid_encode_backward(xyzs, 1.0, dfeat, levels, cap, m_dev, cap, dtable, variant=3)
+            fns["variant3_spt%d" % spt] = f
         t = timed(fns, rounds=10)
+        B.call("lnerf_set_tuning", b"scatter_bin_spt", 1)
         res["scatter_ms(median,min)"] = t
 
     if "update" in which:
