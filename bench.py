@@ -293,8 +293,12 @@ def main():
     barrier()
     t0 = time.perf_counter()
     n_probe = 0
+    # eager probe steps: every --probe-every-th step; a run shorter than that still gets one (its last step), so that
+    # the roofline object can always be measured live, whatever --steps the caller picks
+    pe = max(1, args.probe_every)
+    probes = {i for i in range(args.steps) if i % pe == pe - 1} or {args.steps - 1}
     for i in range(args.steps):
-        if gstep is None or (i % args.probe_every) == args.probe_every - 1:
+        if gstep is None or i in probes:
             B.set_profile_hook(timer.hook)   # eager step: the gather is bracketed by HIP events on its stream
             out = step()
             B.set_profile_hook(None)
