@@ -253,7 +253,9 @@ int lnerf_mesh_distance(const float *points, int64_t n, const float *triangles, 
  * background) and perspective-correct barycentrics [H*W,3];  interpolate_attributes: per-face-vertex
  * attributes [F,3,D] -> [H*W,D] (differentiable w.r.t. the attributes);  texture_map: tex [C,R,R] sampled at
  * uv [H*W,2] with grid_sample(align_corners=False, padding 'border') semantics on (u, 1-v), mode 0 nearest /
- * 1 bilinear; pixels with face_idx < 0 give 0.  The backward entry points ACCUMULATE (+=). */
+ * 1 bilinear / 2 bicubic (A = -0.75, every tap clamped to the border) = `guide.texture_interpolation_mode` of
+ * src/latent_paint/configs/train_config.py:42-43; pixels with face_idx < 0 give 0.  The backward entry points
+ * ACCUMULATE (+=). */
 int lnerf_raster_prepare(const float *verts, int n_verts, const int32_t *faces, int n_faces, const float *cam_host,
                          float *face_z, float *face_xy, lnerf_stream_t stream);
 int lnerf_rasterize(int H, int W, const float *face_z, const float *face_xy, int n_faces, int32_t *face_idx,

@@ -115,15 +115,28 @@ k_interp_attr_bwd(const int32_t *__restrict__ face_idx, const float *__restrict_
     atomicAdd(&a[2 * D + d], bary[p * 3 + 2] * g);
 }
 
-// texture lookup: tex [C,R,R]; uv [P,2]; mode 0 nearest, 1 bilinear; grid_sample(align_corners=False, border)
-__device__ __forceinline__ void tex_coords(float u, float v, int R, float &x, float &y) {
+// texture lookup: tex [C,R,R]; uv [P,2]; mode 0 nearest, 1 bilinear, 2 bicubic; grid_sample(align_corners=False, border)
+// on (u, 1 - v) after clamping uv to [0, 1] (the semantics of kal.render.mesh.texture_mapping, the op the reference
+// calls at src/latent_paint/models/render.py:64 with mode = guide.texture_interpolation_mode)
+__device__ __forceinline__ void tex_coords(float u, float v, int R, bool clip, float &x, float &y) {
     u = clampf(u, 0.f, 1.f);
     v = clampf(v, 0.f, 1.f);
     const float gx = u * 2.0f - 1.0f, gy = -(v * 2.0f - 1.0f);
     x = ((gx + 1.0f) * (float)R - 1.0f) * 0.5f;
     y = ((gy + 1.0f) * (float)R - 1.0f) * 0.5f;
-    x = clampf(x, 0.f, (float)(R - 1));   // padding_mode = 'border'
-    y = clampf(y, 0.f, (float)(R - 1));
+    if (clip) {  // padding_mode = 'border' (nearest / bilinear clip the position, bicubic clips every tap instead)
+        x = clampf(x, 0.f, (float)(R - 1));
+        y = clampf(y, 0.f, (float)(R - 1));
+    }
+}
+// cubic convolution weights of the 4 taps around a position with fractional part t (A = -0.75, as grid_sample)
+__device__ __forceinline__ void cubic_weights(float t, float w[4]) {
+    const float A = -0.75f;
+    const float a = t + 1.0f, b = 1.0f - t, c = b + 1.0f;
+    w[0] = ((A * a - 5.0f * A) * a + 8.0f * A) * a - 4.0f * A;
+    w[1] = ((A + 2.0f) * t - (A + 3.0f)) * t * t + 1.0f;
+    w[2] = ((A + 2.0f) * b - (A + 3.0f)) * b * b + 1.0f;
+    w[3] = ((A * c - 5.0f * A) * c + 8.0f * A) * c - 4.0f * A;
 }
 template <bool BWD>
 __global__ void __launch_bounds__(256)
@@ -138,13 +151,13 @@ k_texture_map(const float *__restrict__ uv, const int32_t *__restrict__ face_idx
         return;
     }
     float x, y;
-    tex_coords(uv[p * 2], uv[p * 2 + 1], R, x, y);
+    tex_coords(uv[p * 2], uv[p * 2 + 1], R, mode != 2, x, y);
     float *tc = tex + (int64_t)c * R * R;
     if (mode == 0) {
         const int xi = (int)rintf(x), yi = (int)rintf(y);
         if (BWD) atomicAdd(&tc[yi * R + xi], out_or_dout[t]);
         else out_or_dout[t] = tc[yi * R + xi];
-    } else {
+    } else if (mode == 1) {
         const float xf = floorf(x), yf = floorf(y);
         const int x0 = (int)xf, y0 = (int)yf, x1 = min(x0 + 1, R - 1), y1 = min(y0 + 1, R - 1);
         const float ax = x - xf, ay = y - yf;
@@ -155,6 +168,32 @@ k_texture_map(const float *__restrict__ uv, const int32_t *__restrict__ face_idx
             atomicAdd(&tc[y1 * R + x0], w10 * g); atomicAdd(&tc[y1 * R + x1], w11 * g);
         } else {
             out_or_dout[t] = w00 * tc[y0 * R + x0] + w01 * tc[y0 * R + x1] + w10 * tc[y1 * R + x0] + w11 * tc[y1 * R + x1];
+        }
+    } else {
+        const float xf = floorf(x), yf = floorf(y);
+        const int xb = (int)xf - 1, yb = (int)yf - 1;
+        float wx[4], wy[4];
+        cubic_weights(x - xf, wx);
+        cubic_weights(y - yf, wy);
+        if (BWD) {
+            const float g = out_or_dout[t];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int yi = min(max(yb + i, 0), R - 1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) atomicAdd(&tc[yi * R + min(max(xb + j, 0), R - 1)], (wy[i] * wx[j]) * g);
+            }
+        } else {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int yi = min(max(yb + i, 0), R - 1);
+                float row = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) row = fmaf(wx[j], tc[yi * R + min(max(xb + j, 0), R - 1)], row);
+                acc = fmaf(wy[i], row, acc);
+            }
+            out_or_dout[t] = acc;
         }
     }
 }
@@ -212,7 +251,7 @@ int lnerf_interpolate_attributes_backward(const int32_t *face_idx, const float *
 
 int lnerf_texture_map_forward(const float *uv, const int32_t *face_idx, const float *texture, int n_pixels, int C,
                               int R, int mode, float *out, lnerf_stream_t stream) {
-    LNERF_REQUIRE(n_pixels > 0 && C >= 1 && R >= 1 && (mode == 0 || mode == 1), "texture_map_forward: bad arguments");
+    LNERF_REQUIRE(n_pixels > 0 && C >= 1 && R >= 1 && mode >= 0 && mode <= 2, "texture_map_forward: bad arguments");
     LNERF_REQUIRE(uv && texture && out, "texture_map_forward: null pointer");
     hipLaunchKernelGGL(k_texture_map<false>, dim3((unsigned)div_up((int64_t)n_pixels * C, 256)), dim3(256), 0,
                        as_stream(stream), uv, face_idx, const_cast<float *>(texture), n_pixels, C, R, mode, out);
@@ -222,7 +261,7 @@ int lnerf_texture_map_forward(const float *uv, const int32_t *face_idx, const fl
 
 int lnerf_texture_map_backward(const float *uv, const int32_t *face_idx, const float *dout, int n_pixels, int C, int R,
                                int mode, float *dtexture, lnerf_stream_t stream) {
-    LNERF_REQUIRE(n_pixels > 0 && C >= 1 && R >= 1 && (mode == 0 || mode == 1), "texture_map_backward: bad arguments");
+    LNERF_REQUIRE(n_pixels > 0 && C >= 1 && R >= 1 && mode >= 0 && mode <= 2, "texture_map_backward: bad arguments");
     LNERF_REQUIRE(uv && dout && dtexture, "texture_map_backward: null pointer");
     hipLaunchKernelGGL(k_texture_map<true>, dim3((unsigned)div_up((int64_t)n_pixels * C, 256)), dim3(256), 0,
                        as_stream(stream), uv, face_idx, dtexture, n_pixels, C, R, mode, const_cast<float *>(dout));

@@ -46,10 +46,11 @@ class RenderConfig:
     # occupancy grid resolution
     grid_size: int = 128
     # ---- MI355X knobs
-    # "f32": exact-f32 MFMA MLP (parity path), "bf16": bf16 MFMA, f32 accumulate
-    mlp_precision: str = "f32"
-    # "f32": gather reads the master table, "bf16": gather reads a bf16 shadow (half the bytes)
-    table_dtype: str = "f32"
+    # "f32": exact-f32 MFMA MLP (parity path), "bf16": bf16 MFMA, f32 accumulate.  "auto" (default): decided
+    # by the owner -- TrainConfig picks "bf16" when optim.fp16 else "f32"; a bare RenderConfig means "f32"
+    mlp_precision: str = "auto"
+    # "f32": gather reads the master table, "bf16": gather reads a bf16 shadow (half the bytes); "auto" as above
+    table_dtype: str = "auto"
     # workgroup -> (level, tile) mapping of the gather/scatter: 0 = level on grid.y (measured 1.8x faster), 1 = XCD-pinned levels
     gather_variant: int = 0
     # hash-grid backward: 0/1 = global float atomics, 2 = two-pass bucketed scatter (LDS reduction, exact f32
@@ -59,5 +60,14 @@ class RenderConfig:
     # jitter of the march start (perturb=True): seed of the in-kernel counter-based generator
     # (lnerf_march_rays_train `noise_counter`: graph-capturable, no host RNG state); None = torch.rand(N) per call
     noise_seed: Optional[int] = 0x5EED
-    # sample buffer capacity per view (0 = rays * min(max_steps, 256))
+    # sample buffer capacity per view.  0 = automatic: rays * min(max_steps, 256) until the renderer has seen
+    # `update_extra_interval` training marches, then 2 x the running mean sample count (rounded up to 64 Ki; rays
+    # that do not fit are dropped by the march's scan pass and counted, never written out of bounds)
     max_samples: int = 0
+
+    def precision(self, name: str) -> str:
+        """Resolved value of `mlp_precision` / `table_dtype` ("auto" on a bare RenderConfig = the f32 parity path)."""
+        v = getattr(self, name)
+        if v not in ("auto", "f32", "bf16"):
+            raise ValueError("render.%s must be 'auto', 'f32' or 'bf16' (got %r)" % (name, v))
+        return "f32" if v == "auto" else v

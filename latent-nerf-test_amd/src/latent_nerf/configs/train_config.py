@@ -8,15 +8,11 @@ advertise for the absent package (demo_configs/latent_nerf/lego_man.yaml:1-10, R
 guide.shape_path, guide.mesh_scale, guide.proximal_surface, optim.lambda_shape, optim.seed, optim.iters).
 pyrallis is not installed here, so `load_config()` implements the same two input forms on top of
 argparse + yaml; when pyrallis is importable the dataclasses work with `pyrallis.wrap()` unchanged."""
-import argparse
-import dataclasses
 from dataclasses import dataclass, field
 from pathlib import Path
-from typing import Optional, Tuple, get_type_hints
+from typing import Optional
 
-import yaml
-
-from ..models.nerf_utils import NeRFType
+from ... import config_cli as _cli
 from .render_config import RenderConfig
 
 
@@ -84,69 +80,30 @@ class TrainConfig:
     def __post_init__(self):
         if self.log.eval_only and (self.optim.ckpt is None and not self.optim.resume):
             self.optim.resume = True  # same rule as src/latent_paint/configs/train_config.py:94-97
-        if self.optim.fp16:
-            self.render.mlp_precision = "bf16"
-            self.render.table_dtype = "bf16"
+        # Precision follows optim.fp16 ONLY where the user left render.mlp_precision / render.table_dtype on "auto":
+        # the set of such fields is fixed the first time (and edited by note_explicit), so that re-running this after
+        # `--optim.fp16 false` or after an explicit `--render.mlp_precision f32` gives the f32 parity path.
+        if not hasattr(self, "_auto_precision"):
+            self._auto_precision = {n for n in ("mlp_precision", "table_dtype") if getattr(self.render, n) == "auto"}
+        for n in self._auto_precision:
+            setattr(self.render, n, "bf16" if self.optim.fp16 else "f32")
+        for n in ("mlp_precision", "table_dtype"):
+            self.render.precision(n)  # validates
 
-
-def _coerce(value, typ):
-    if typ is bool:
-        return value if isinstance(value, bool) else str(value).lower() in ("1", "true", "yes", "y")
-    if typ is NeRFType:
-        return value if isinstance(value, NeRFType) else NeRFType(str(value))
-    if typ is Path:
-        return Path(value)
-    origin = getattr(typ, "__origin__", None)
-    if origin is tuple:
-        if isinstance(value, str):
-            value = [v for v in value.replace("(", "").replace(")", "").split(",") if v.strip()]
-        return tuple(float(v) for v in value)
-    if typ in (int, float, str):
-        return typ(value)
-    args = getattr(typ, "__args__", ())
-    if type(None) in args:  # Optional[X]
-        if value is None or str(value).lower() in ("none", "null"):
-            return None
-        return _coerce(value, [a for a in args if a is not type(None)][0])
-    return value
+    def note_explicit(self, key, value):
+        """config_cli.apply_overrides tells us which fields the user set."""
+        section, _, name = key.partition(".")
+        if section == "render" and name in ("mlp_precision", "table_dtype"):
+            if not hasattr(self, "_auto_precision"):
+                self._auto_precision = set()
+            (self._auto_precision.add if value == "auto" else self._auto_precision.discard)(name)
 
 
 def apply_overrides(cfg: TrainConfig, flat: dict) -> TrainConfig:
     """flat: {'log.exp_name': 'x', 'render.nerf_type': 'latent', ...}"""
-    for key, value in flat.items():
-        section, _, name = key.partition(".")
-        sub = getattr(cfg, section, None)
-        if sub is None or not dataclasses.is_dataclass(sub) or name not in {f.name for f in dataclasses.fields(sub)}:
-            raise KeyError("unknown config field %r" % key)
-        setattr(sub, name, _coerce(value, get_type_hints(type(sub))[name]))
-    cfg.__post_init__()
-    return cfg
+    return _cli.apply_overrides(cfg, flat)
 
 
 def load_config(argv=None) -> TrainConfig:
     """`--config_path file.yaml` and/or dotted flags `--section.field value`."""
-    ap = argparse.ArgumentParser(add_help=True)
-    ap.add_argument("--config_path", default=None)
-    args, rest = ap.parse_known_args(argv)
-    flat = {}
-    if args.config_path:
-        doc = yaml.safe_load(open(args.config_path)) or {}
-        for section, body in doc.items():
-            for name, value in (body or {}).items():
-                flat["%s.%s" % (section, name)] = value
-    i = 0
-    while i < len(rest):
-        tok = rest[i]
-        if not tok.startswith("--"):
-            raise SystemExit("unexpected argument %r" % tok)
-        if "=" in tok:
-            k, v = tok[2:].split("=", 1)
-            i += 1
-        else:
-            k = tok[2:]
-            if i + 1 >= len(rest):
-                raise SystemExit("flag %r needs a value" % tok)
-            v = rest[i + 1]
-            i += 2
-        flat[k] = v
-    return apply_overrides(TrainConfig(), flat)
+    return _cli.load_config(TrainConfig, argv)

@@ -128,12 +128,12 @@ class NeRFNetwork(NeRFRenderer):
             raise ValueError("the fused HIP MLP is built for 32 -> 64 -> 64 -> 1+C")
         self.img_dims = 3 + 1 if self.latent_mode else 3
         self.blob_scale, self.blob_std = blob_scale, blob_std
-        self.precision = cfg.mlp_precision
-        table_dtype = torch.bfloat16 if cfg.table_dtype == "bf16" else torch.float32
+        self.precision = cfg.precision("mlp_precision")
+        table_dtype = torch.bfloat16 if cfg.precision("table_dtype") == "bf16" else torch.float32
         self.encoder = GridEncoder(num_levels, level_dim, base_resolution, 2048 * self.bound, log2_hashmap_size,
                                    table_dtype=table_dtype, variant=cfg.gather_variant,
                                    scatter_variant=(cfg.scatter_variant if cfg.scatter_variant >= 0
-                                                    else (3 if cfg.mlp_precision == "bf16" else 2)))
+                                                    else (3 if self.precision == "bf16" else 2)))
         in_dim, out_dim = self.encoder.out_dim, 1 + self.img_dims
         # nn.Linear default init, kept as bare parameters: the fused kernel takes all six at once
         self.w1 = nn.Parameter(torch.empty(hidden_dim, in_dim))

@@ -16,6 +16,26 @@ from ..raymarching import raymarching as rm
 from ..raymarching.raymarching import _p, _stream
 
 
+def _sample_pdf(bins, weights, n_samples, stratified):
+    """Inverse-transform sampling of `n_samples` positions per ray from the piecewise-constant density that `weights`
+    [N, B-1] puts on the intervals between `bins` [N, B] (hierarchical sampling of NeRF)."""
+    w = weights + 1e-5
+    cdf = torch.cumsum(w / w.sum(-1, keepdim=True), -1)
+    cdf = torch.cat([torch.zeros_like(cdf[:, :1]), cdf], -1)                     # [N, B]
+    if stratified:
+        u = torch.linspace(0.5 / n_samples, 1.0 - 0.5 / n_samples, n_samples, device=bins.device)
+        u = u[None].expand(bins.shape[0], n_samples).contiguous()
+    else:
+        u = torch.rand(bins.shape[0], n_samples, device=bins.device)
+    hi = torch.searchsorted(cdf, u, right=True).clamp(max=cdf.shape[-1] - 1)
+    lo = (hi - 1).clamp(min=0)
+    c0, c1 = torch.gather(cdf, 1, lo), torch.gather(cdf, 1, hi)
+    b0, b1 = torch.gather(bins, 1, lo), torch.gather(bins, 1, hi)
+    span = c1 - c0
+    t = (u - c0) / torch.where(span < 1e-5, torch.ones_like(span), span)
+    return b0 + t * (b1 - b0)
+
+
 class NeRFRenderer(nn.Module):
     def __init__(self, cfg, latent_mode: bool = True):
         super().__init__()
@@ -40,6 +60,9 @@ class NeRFRenderer(nn.Module):
         self.iter_density = 0
         self.local_step = 0
         self._march = None
+        self._march_key = None
+        self._budget = None       # ((N, max_steps), capacity) derived from observed marches
+        self.mean_count = 0
         self._noise_counter = None
         self._occ_scratch = None
 
@@ -78,9 +101,37 @@ class NeRFRenderer(nn.Module):
         return bg.reshape(N, C).contiguous()
 
     def _capacity(self, N, max_steps):
+        """Sample-buffer capacity of a training march of N rays.  `cfg.max_samples` if set; else the worst case
+        N * min(max_steps, 256) until update_sample_budget() has seen real marches of this shape, then the budget it
+        derived from them (every capacity-sized buffer, the scatter workspace included, shrinks with it)."""
+        worst = max(N * min(int(max_steps), 256), 64)
         if self.cfg.max_samples > 0:
             return int(self.cfg.max_samples)
-        return max(N * min(int(max_steps), 256), 64)
+        if self._budget is not None and self._budget[0] == (N, int(max_steps)):
+            return min(worst, self._budget[1])
+        return worst
+
+    def update_sample_budget(self):
+        """Called where the training loop synchronises anyway (the occupancy refresh, every `update_extra_interval`
+        steps): reads the last march's device counters [M, live rays, dropped rays] back ONCE and re-derives the
+        capacity for marches of that shape: 2 x M rounded up to 128 Ki samples, changed only when the march came
+        within 2/3 of the current capacity (or dropped rays: back to the worst case) or fell below a quarter of
+        it.  The upstream renderer sizes its buffers from a running `mean_count` the same way, but reads the
+        counter back every step."""
+        m = self._march
+        if m is None or self.cfg.max_samples > 0:
+            return None
+        M, _, dropped = [int(v) for v in m.counter[:3].tolist()]
+        N = m.rays.shape[0]
+        key = self._march_key
+        cap = m.capacity
+        self.mean_count = M if self.mean_count == 0 else int(0.9 * self.mean_count + 0.1 * M)
+        want = -(-max(2 * M, 1) // 131072) * 131072
+        if dropped > 0:
+            self._budget = None                      # back to the worst case for the next marches
+        elif 3 * M > 2 * cap or 4 * M < cap or self._budget is None or self._budget[0] != key:
+            self._budget = (key, want)
+        return self._budget
 
     def _noise_state(self, dev):
         """(seed, device counter) of the march's counter-based jitter generator (cfg.noise_seed; None = torch.rand)."""
@@ -115,6 +166,7 @@ class NeRFRenderer(nn.Module):
                                         max_steps=max_steps, capacity=cap, out=self._march,
                                         noises=kwargs.get("noises"), noise_state=self._noise_state(rays_o.device))
             self._march = march
+            self._march_key = (N, int(max_steps))
             self.local_step += 1
             m_dev = march.counter[0:1]
             sigmas, rgbs = self.field(march.xyzs, cap, m_dev, cap)
@@ -162,11 +214,10 @@ class NeRFRenderer(nn.Module):
         return cached[1]
 
     def run(self, rays_o, rays_d, num_steps=128, upsample_steps=0, bg_color=None, perturb=False, **kwargs):
-        """Uniform-sampling renderer (`cuda_ray=False`): num_steps samples in [near, far] per ray,
-        evaluated with the same HIP gather/MLP kernels and composited with the same HIP kernels
-        (every ray simply owns a fixed span of num_steps samples)."""
-        if upsample_steps > 0:
-            raise NotImplementedError("importance resampling (upsample_steps > 0) is not built")
+        """Uniform-sampling renderer (`cuda_ray=False`): num_steps samples in [near, far] per ray, optionally refined
+        by `upsample_steps` importance samples drawn from the coarse pass's weights (inverse-CDF sampling between
+        the mid-points of the coarse samples, stratified when not training), evaluated with the same HIP gather/MLP
+        kernels and composited with the same HIP kernels (every ray owns a fixed span of samples)."""
         prefix = rays_o.shape[:-1]
         rays_o = rays_o.contiguous().view(-1, 3).float()
         rays_d = rays_d.contiguous().view(-1, 3).float()
@@ -181,14 +232,31 @@ class NeRFRenderer(nn.Module):
         sample_dist = (far - near) / num_steps
         if perturb:
             z = z + (torch.rand_like(z) - 0.5) * sample_dist[:, None]
-        xyzs = (rays_o[:, None, :] + rays_d[:, None, :] * z[..., None]).clamp(-self.bound, self.bound)
-        dt = torch.cat([z[:, 1:] - z[:, :-1], sample_dist[:, None]], dim=1)
-        dt = dt * hit[:, None]
-        deltas = torch.stack([dt, z], -1).reshape(-1, 2).contiguous()
-        rays = torch.stack([torch.arange(N, device=dev), torch.arange(N, device=dev) * num_steps,
-                            torch.full((N,), num_steps, device=dev)], -1).to(torch.int32)
-        flat = xyzs.reshape(-1, 3).contiguous()
+
+        def positions(zv):
+            return (rays_o[:, None, :] + rays_d[:, None, :] * zv[..., None]).clamp(-self.bound, self.bound)
+
+        def spacing(zv):
+            return torch.cat([zv[:, 1:] - zv[:, :-1], sample_dist[:, None]], dim=1) * hit[:, None]
+
+        if upsample_steps > 0:
+            with torch.no_grad():
+                flat = positions(z).reshape(-1, 3).contiguous()
+                sigma_c, _ = self.field(flat, flat.shape[0])
+                dt = spacing(z)
+                alpha = 1.0 - torch.exp(-dt * (self.density_scale * sigma_c).view(N, num_steps))
+                trans = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-15], dim=1), dim=1)
+                weights = alpha * trans[:, :-1]
+                mids = z[:, :-1] + 0.5 * dt[:, :-1]
+                z_fine = _sample_pdf(mids, weights[:, 1:-1], upsample_steps, stratified=not self.training)
+                z = torch.sort(torch.cat([z, z_fine], dim=1), dim=1)[0]
+        S = z.shape[1]
+        deltas = torch.stack([spacing(z), z], -1).reshape(-1, 2).contiguous()
+        ar = torch.arange(N, device=dev)
+        rays = torch.stack([ar, ar * S, torch.full((N,), S, device=dev)], -1).to(torch.int32)
+        flat = positions(z).reshape(-1, 3).contiguous()
         sigmas, rgbs = self.field(flat, flat.shape[0])
+        sigmas = self.density_scale * sigmas if self.density_scale != 1.0 else sigmas
         bg = self._bg_tensor(bg_color, rays_d, N, C)
         weights_sum, depth, image = rm.composite_rays_train(sigmas, rgbs, deltas, rays, 0.0, bg)
         return {"image": image.view(*prefix, C), "depth": depth.view(*prefix),
@@ -201,6 +269,8 @@ class NeRFRenderer(nn.Module):
         occupied cells), decayed-max into the grid, recompute the mean and repack the bitfield."""
         if not self.cuda_ray:
             return
+        if self.training:
+            self.update_sample_budget()
         dev = self.density_grid.device
         G, G3 = self.grid_size, self.grid_size ** 3
         chunk = 1 << 20
@@ -241,6 +311,9 @@ class NeRFRenderer(nn.Module):
     def render(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):
         """rays_o, rays_d [B,N,3] -> dict with 'image' [B,N,C], 'depth' [B,N], 'weights_sum' [B,N]."""
         _run = self.run_cuda if self.cuda_ray else self.run
+        if not self.cuda_ray:   # the uniform sampler takes its sample counts from the config (render.num_steps / upsample_steps)
+            kwargs.setdefault("num_steps", self.cfg.num_steps)
+            kwargs.setdefault("upsample_steps", self.cfg.upsample_steps)
         B, N = rays_o.shape[:2]
         if staged and not self.cuda_ray:
             dev = rays_o.device

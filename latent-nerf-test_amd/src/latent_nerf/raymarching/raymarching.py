@@ -143,6 +143,11 @@ def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars,
             noises = torch.rand(N, device=dev, dtype=torch.float32)
     if out is not None and out.capacity == capacity and out.rays.shape[0] == N:
         xyzs, dirs, deltas, rays, counter = out.xyzs, out.dirs, out.deltas, out.rays, out.counter
+        # The kernels write through raw pointers, which autograd cannot see: tell it that these buffers change, so
+        # that a backward pass of an EARLIER render that saved them fails loudly ("modified by an inplace operation")
+        # instead of silently using this march's samples.  Host-side bookkeeping only, no launch.
+        for t in (xyzs, dirs, deltas, rays, counter):
+            torch.autograd.graph.increment_version(t)
     else:
         xyzs = torch.empty(capacity, 3, device=dev, dtype=torch.float32)
         dirs = torch.empty(capacity, 3, device=dev, dtype=torch.float32)

@@ -21,6 +21,10 @@ class Guidance:
         """latents [B,4,H,W] -> gradient w.r.t. latents, same shape (no autograd through it)."""
         raise NotImplementedError()
 
+    def decode_latents(self, latents):
+        """latents [B,4,h,w] -> RGB [B,3,8h,8w] in [0,1] (evaluation renders, mesh export)."""
+        raise NotImplementedError()
+
 
 class SyntheticGuidance(Guidance):
     """Deterministic target-seeking gradient: for view bucket d (0..5) the target latent image is a fixed
@@ -42,6 +46,17 @@ class SyntheticGuidance(Guidance):
 
     def get_text_embeds(self, prompt):
         return torch.zeros(2, 77, 768, device=self.device)
+
+    @torch.no_grad()
+    def decode_latents(self, latents):
+        """[B,4,h,w] latents -> [B,3,8h,8w] RGB in [0,1]: stand-in for the VAE decoder (src/stable_diffusion.py
+        decode_latents: 8x up-sampling decoder, output (x/2 + 0.5).clamp(0,1)) built from the linear latent->RGB
+        estimate of src/latent_paint/models/textured_mesh.py:34-40 and a bilinear 8x resize."""
+        m = torch.tensor([[0.298, 0.207, 0.208], [0.187, 0.286, 0.173], [-0.158, 0.189, 0.264],
+                          [-0.184, -0.271, -0.473]], device=latents.device, dtype=latents.dtype)
+        rgb = torch.einsum("bchw,cr->brhw", latents, m)
+        rgb = torch.nn.functional.interpolate(rgb, scale_factor=8, mode="bilinear", align_corners=False)
+        return (rgb / 2 + 0.5).clamp(0, 1)
 
     @torch.no_grad()
     def train_step(self, text_z, latents, dirs=None):

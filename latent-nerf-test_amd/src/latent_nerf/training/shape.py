@@ -130,8 +130,20 @@ class MeshOccupancy:
 
 
 class ShapeLoss:
-    """Cross-entropy between the NeRF's occupancy 1 - exp(-delta sigma) and the mesh occupancy clamp(w, 0, 1),
-    down-weighted near the surface by 1 - exp(-d^2 / (2 proximal_surface^2))."""
+    """Shape prior on the NeRF occupancy.  PARITY UNPINNED: the reference ships no shape loss (src/latent_nerf is absent,
+    README.md:140-142 only documents the knobs `guide.proximal_surface` and `optim.lambda_shape`); the form below is the
+    upstream one as recalled in SURVEY.md Appendix A, chosen deliberately so that the advertised default
+    `lambda_shape = 5e-6` (demo_configs/latent_nerf/lego_man.yaml) has the effect it was tuned for:
+
+        nerf_occ  = clamp(1 - exp(-delta sigma), 0, 1.1),  delta = 0.2
+        indicator = [winding number > 0.5]
+        CE(p = nerf_occ, q = indicator)  = -(p log clamp(q) + (1 - p) log clamp(1 - q)),  clamp to [0.01, 0.99]
+        loss = SUM over the samples of  CE x (1 - exp(-d^2 / (2 proximal_surface^2)))
+
+    i.e. the cross-entropy takes the NeRF occupancy as its FIRST argument (linear in nerf_occ: a constant pull
+    of log(0.99/0.01) per sample towards the indicator, the indicator itself is not optimised), it is SUMMED over the
+    M ~ 1e5..4e5 samples of the view (not averaged), and samples near the surface are down-weighted by their
+    distance d to the mesh."""
 
     def __init__(self, occ: MeshOccupancy, proximal_surface=0.3, delta=0.2):
         self.occ, self.proximal_surface, self.delta = occ, proximal_surface, delta
@@ -142,11 +154,11 @@ class ShapeLoss:
         valid = torch.ones(n, dtype=torch.bool, device=xyzs.device) if counter is None else \
             torch.arange(n, device=xyzs.device) < counter[0]
         x = torch.where(valid[:, None], xyzs, torch.zeros_like(xyzs))
-        target = self.occ.winding_at(x).clamp(0.0, 1.0)
-        d = self.occ.distance_at(x)
-        weight = 1.0 - torch.exp(-(d * d) / (2.0 * self.proximal_surface ** 2))
+        inside = (self.occ.winding_at(x) > 0.5).float()
         sig = torch.where(valid, sigmas, torch.zeros_like(sigmas))  # never read the uninitialised tail
-        nerf_occ = (1.0 - torch.exp(-self.delta * sig)).clamp(1e-5, 1.0 - 1e-5)
-        ce = -(target * torch.log(nerf_occ) + (1.0 - target) * torch.log(1.0 - nerf_occ))
-        denom = valid.sum().clamp(min=1).float()
-        return (torch.where(valid, ce * weight, torch.zeros_like(ce))).sum() / denom
+        nerf_occ = (1.0 - torch.exp(-self.delta * sig)).clamp(0.0, 1.1)
+        ce = -(nerf_occ * torch.log(inside.clamp(0.01, 0.99)) + (1.0 - nerf_occ) * torch.log((1.0 - inside).clamp(0.01, 0.99)))
+        if self.proximal_surface > 0:
+            d = self.occ.distance_at(x)
+            ce = ce * (1.0 - torch.exp(-(d * d) / (2.0 * self.proximal_surface ** 2)))
+        return torch.where(valid, ce, torch.zeros_like(ce)).sum()

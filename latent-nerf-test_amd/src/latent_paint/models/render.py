@@ -8,7 +8,7 @@ import torch
 from ...latent_nerf.raymarching import backend as _b
 from ...latent_nerf.raymarching.raymarching import _chk, _p, _stream
 
-_MODES = {"nearest": 0, "bilinear": 1}
+_MODES = {"nearest": 0, "bilinear": 1, "bicubic": 2}
 
 
 class _InterpAttr(torch.autograd.Function):
@@ -57,8 +57,6 @@ class _TextureMap(torch.autograd.Function):
 class Renderer:
     def __init__(self, device, dim=(224, 224), interpolation_mode="nearest"):
         assert interpolation_mode in ["nearest", "bilinear", "bicubic"], "no interpolation mode %s" % interpolation_mode
-        if interpolation_mode == "bicubic":
-            raise NotImplementedError("bicubic texture lookup is not built (nearest / bilinear are)")
         self.device = device
         self.interpolation_mode = interpolation_mode
         self.fov = math.pi / 3                         # kal.render.camera.generate_perspective_projection(np.pi / 3)

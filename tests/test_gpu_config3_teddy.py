@@ -1,0 +1,147 @@
+"""BASELINE config 3 on its own workload: sketch-guided latent-NeRF on the reference's shapes/teddy.obj (committed as data
+under tests/golden/shapes/), 128^3 occupancy grid, 64 x 64 render: the mesh kernels (csrc/mesh.hip) against the float64
+oracle on a point subset, the occupancy seeded from the mesh winding number, the march through that bitfield against the
+oracle march (bit-exact), and the shape loss at the reference's advertised default weight
+(`optim.lambda_shape` of demo_configs/latent_nerf/lego_man.yaml; parity unpinned: the loss itself is absent from the
+reference, see src/latent_nerf/training/shape.py)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mesh_oracle as MO
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "shapes")
+TEDDY = os.path.join(SHAPES, "teddy.obj")
+
+
+@pytest.fixture(scope="module")
+def dev(built_lib):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def teddy(dev):
+    from src.latent_nerf.training import shape as S
+    verts, faces = S.load_obj(TEDDY)
+    assert verts.shape == (2892, 3) and faces.shape == (5760, 3)
+    verts = S.normalize_mesh(verts, target_scale=0.7, dy=0.0)      # guide.mesh_scale default
+    occ = S.MeshOccupancy(verts, faces, dev, bound=1.0, resolution=128)
+    return verts, faces, occ
+
+
+def test_teddy_winding_and_distance_grids_match_float64_oracle(dev, teddy):
+    from src.latent_nerf.training import shape as S
+    verts, faces, occ = teddy
+    R = 128
+    assert occ.winding.shape == (1, 1, R, R, R) and occ.dist.shape == (1, 1, R, R, R)
+    tris = verts[faces].numpy()
+    g = torch.Generator().manual_seed(0)
+    # a subset of the 128^3 voxel centres the grids were evaluated at (z, y, x order) ...
+    cells = torch.randint(0, R, (300, 3), generator=g)
+    centres = ((cells.float() + 0.5) / R * 2 - 1)[:, [2, 1, 0]]                     # -> (x, y, z)
+    w = occ.winding[0, 0][cells[:, 0], cells[:, 1], cells[:, 2]].cpu().numpy()
+    d = occ.dist[0, 0][cells[:, 0], cells[:, 1], cells[:, 2]].cpu().numpy()
+    w_ref = MO.winding_number(centres.numpy(), tris)
+    d_ref = MO.distance(centres.numpy(), tris)
+    assert np.abs(w - w_ref).max() < 3e-3           # f32 sum of 5760 solid angles vs float64
+    assert np.abs(d - d_ref).max() < 2e-5
+    # ... and free points, biased towards the surface (vertices + small offsets)
+    near = verts[torch.randint(0, verts.shape[0], (200,), generator=g)] + 0.02 * torch.randn(200, 3, generator=g)
+    w2 = S.mesh_winding_number(near.to(dev), torch.from_numpy(tris).to(dev)).cpu().numpy()
+    d2 = S.mesh_distance(near.to(dev), torch.from_numpy(tris).to(dev)).cpu().numpy()
+    assert np.abs(w2 - MO.winding_number(near.numpy(), tris)).max() < 3e-3
+    assert np.abs(d2 - MO.distance(near.numpy(), tris)).max() < 2e-5
+    # the teddy is a closed surface up to small gaps: the winding number is ~0 outside and ~1 deep inside
+    frac_inside = float((occ.winding > 0.5).float().mean())
+    assert 0.01 < frac_inside < 0.12
+    far = occ.winding[0, 0, :4].abs().max()           # a slab at the boundary of the cube
+    assert float(far) < 0.02
+
+
+def test_teddy_occupancy_seed_and_march_match_oracle(dev, teddy):
+    """`MeshOccupancy.init_density_grid` = 'mesh winding-number occupancy in march' (BASELINE config 3): the bitfield
+    equals packbits(winding > 0.5) of the oracle on a cell subset, and the 64 x 64 march through it is bit-exact."""
+    from src.latent_nerf.configs.render_config import RenderConfig
+    from src.latent_nerf.models.network_grid import NeRFNetwork
+    from src.latent_nerf.raymarching import raymarching as rm
+    verts, faces, occ = teddy
+    G, HW = 128, 64
+    net = NeRFNetwork(RenderConfig(grid_size=G, train_h=HW, train_w=HW), log2_hashmap_size=14).to(dev)
+    bits = occ.init_density_grid(net).cpu()
+    grid = net.density_grid[0].cpu()
+    assert set(grid.unique().tolist()) == {0.0, 2.0 * net.density_thresh}
+    n_set = int(sum(bin(b).count("1") for b in bits.tolist()))
+    assert n_set == int((grid > 0).sum()) and 0.01 < n_set / G ** 3 < 0.12
+    # oracle: winding number (float64) at the centres of a subset of Morton-ordered cells
+    g = torch.Generator().manual_seed(1)
+    idx = torch.randint(0, G ** 3, (400,), generator=g)
+    xyz = O.occupancy_cell_points(idx, 0, G, 1.0, None)
+    w_ref = MO.winding_number(xyz.numpy(), verts[faces].numpy())
+    clear = np.abs(w_ref - 0.5) > 5e-3                              # cells within f32 rounding of the threshold may flip
+    got = (grid[idx] > 0).numpy()
+    assert (got[clear] == (w_ref[clear] > 0.5)).all() and clear.sum() > 380
+    byte, bit = idx // 8, idx % 8
+    assert torch.equal(((bits[byte] >> bit.to(torch.uint8)) & 1).bool(), grid[idx] > 0)
+    # march (64 x 64 rays, fixed pose, jitter on) through the teddy bitfield: HIP == oracle, bit for bit
+    f = HW / (2 * math.tan(math.radians(55) / 2))
+    ro, rd = O.get_rays(O.pose_from_angles(math.radians(70), math.radians(40), 1.3), f, f, HW / 2, HW / 2, HW, HW)
+    ro, rd = ro[0], rd[0]
+    nears, fars = O.near_far_from_aabb(ro, rd, [-1.0] * 3 + [1.0] * 3, 0.1)
+    noises = torch.rand(ro.shape[0], generator=g)
+    xyzs, dirs, deltas, rays, M = O.march_rays_train(ro, rd, nears, fars, bits, 1.0, 1, G, 1024, 0.0, noises)
+    res = rm.march_rays_train(ro.to(dev), rd.to(dev), 1.0, bits.to(dev), 1, G, nears.to(dev), fars.to(dev),
+                              dt_gamma=0.0, max_steps=1024, capacity=ro.shape[0] * 256, noises=noises.to(dev))
+    assert int(res.counter[0]) == M and M > 20000
+    assert torch.equal(res.rays.cpu(), rays)
+    assert torch.equal(res.xyzs[:M].cpu(), xyzs) and torch.equal(res.deltas[:M].cpu(), deltas)
+    # every sample sits in a cell the mesh marks as inside
+    w_at = occ.winding_at(res.xyzs[:M])
+    assert float((w_at > 0.2).float().mean()) > 0.97
+
+
+def test_teddy_trainer_default_shape_weight_moves_density_towards_the_mesh(dev, tmp_path):
+    """The reference's lego_man.yaml (shape_path = shapes/teddy.obj, default lambda_shape) through the trainer: with the
+    SDS gradient silenced, a few steps at the DEFAULT lambda_shape = 5e-6 raise the NeRF occupancy inside the mesh (the
+    summed form gives the advertised default the weight it was tuned for; a per-sample mean is ~1e5 times weaker
+    against the SDS term)."""
+    from src.latent_nerf.configs.train_config import TrainConfig, apply_overrides
+    from src.latent_nerf.training.guidance import SyntheticGuidance
+    from src.latent_nerf.training.trainer import Trainer
+
+    class Silent(SyntheticGuidance):
+        def train_step(self, text_z, latents, dirs=None):
+            return torch.zeros_like(latents)
+
+    cfg = apply_overrides(TrainConfig(), {
+        "log.exp_name": "lego_man", "log.exp_root": str(tmp_path), "guide.text": "a lego man",
+        "guide.shape_path": TEDDY, "optim.seed": 10, "optim.iters": 24, "optim.fp16": False,
+        "optim.lambda_sparsity": 0.0, "log.save_interval": 1000, "log.eval_size": 1, "render.eval_h": 64,
+        "render.eval_w": 64})
+    assert cfg.optim.lambda_shape == 5e-6 and cfg.render.grid_size == 128 and cfg.render.train_h == 64
+    tr = Trainer(cfg, device=dev, guidance=Silent(dev, channels=4, size=64, seed=0))
+    assert tr.mesh_occ.triangles.shape == (5760, 3, 3)
+    # fixed probe points (the sampled set itself changes as the occupancy grid is refreshed during training)
+    g = torch.Generator().manual_seed(5)
+    probe = ((torch.rand(20000, 3, generator=g) * 2 - 1) * 0.8).to(dev)
+    inside = tr.mesh_occ.winding_at(probe) > 0.5
+    assert int(inside.sum()) > 300
+
+    def probe_loss():
+        with torch.no_grad():
+            sig = tr.nerf.density(probe)["sigma"]
+            return float(tr.shape_loss(probe, sig)), float((1 - torch.exp(-0.2 * sig))[inside].mean())
+
+    l0, occ0 = probe_loss()
+    tr.train()
+    l1, occ1 = probe_loss()
+    assert tr.train_step == 24
+    assert occ1 > occ0 + 0.02, (occ0, occ1)        # the NeRF occupancy inside the teddy rises
+    assert l0 > 0 and l1 > 0 and math.isfinite(l1)

@@ -2,6 +2,7 @@
 interpolation / texture mapping against the PyTorch oracle (oracle/raster_oracle.py), and the
 TexturedMeshModel.render() contract of src/latent_paint/models/textured_mesh.py:181-220."""
 import math
+import os
 
 import pytest
 import torch
@@ -83,12 +84,29 @@ def test_raster_kernels_match_oracle(dev, mode):
     assert abs(float(cols.grad.sum()) - 4 * H * W) < 1e-2 * 4 * H * W   # barycentric weights sum to 1 per pixel/channel
 
 
-def test_textured_mesh_model_render_contract(dev):
-    from src.latent_paint.models.mesh import Mesh
+SHAPES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "shapes")
+
+
+def _paint_cfg(tmp_path, shape="blub.obj", **over):
+    from src.latent_paint.configs.train_config import TrainConfig, apply_overrides
+    flat = {"log.exp_name": "paint", "log.exp_root": str(tmp_path), "guide.text": "a goldfish",
+            "guide.shape_path": os.path.join(SHAPES, shape)}
+    flat.update(over)
+    return apply_overrides(TrainConfig(), flat).validate()
+
+
+def test_textured_mesh_model_built_like_the_reference_trainer(dev, tmp_path):
+    """Constructed exactly as src/latent_paint/training/trainer.py:59-60 does (cfg first, keyword rest) on the
+    reference's own mesh (demo_configs/latent_paint/goldfish.yaml: shapes/blub.obj), then the render() contract of
+    src/latent_paint/models/textured_mesh.py:181-220."""
     from src.latent_paint.models.textured_mesh import TexturedMeshModel
-    v, vt, f = _uv_sphere(16, 32)
-    mesh = Mesh(vertices=v, faces=f, vt=vt, ft=f.clone(), device=dev)
-    model = TexturedMeshModel(mesh=mesh, render_grid_size=64, texture_resolution=128, device=dev)
+    cfg = _paint_cfg(tmp_path)
+    model = TexturedMeshModel(cfg, device=dev, render_grid_size=cfg.render.train_grid_size, latent_mode=True,
+                              texture_resolution=cfg.guide.texture_resolution).to(dev)
+    assert model.mesh.faces.shape == (14208, 3) and model.face_attributes.shape == (1, 14208, 3, 2)
+    assert model.env_sphere.faces.shape == (5120, 3)
+    assert set(model.state_dict()) == {"background_sphere_colors", "texture_img", "texture_img_rgb_finetune"}
+    assert abs(float(model.mesh.vertices.norm(dim=1).max()) - 0.6) < 0.26   # scaled to 0.6, then lifted by dy = 0.25
     out = model.render(math.radians(60.0), math.radians(30.0), 1.25)
     assert set(out) == {"image", "mask", "background", "foreground"}
     assert out["image"].shape == (1, 4, 64, 64) and out["mask"].shape == (1, 1, 64, 64)
@@ -98,5 +116,129 @@ def test_textured_mesh_model_render_contract(dev):
     assert [p.shape for p in model.get_params()] == [model.background_sphere_colors.shape, model.texture_img.shape]
     # composite: background where the mask is 0, texture where it is 1
     m = out["mask"]
+    assert 0.05 < float(m.mean()) < 0.9
     assert float(((out["image"] - out["background"]) * (1 - m)).abs().max()) == 0.0
     assert float(((out["image"] - out["foreground"]) * m).abs().max()) == 0.0
+    # a render size other than 64 is resampled to the 64 x 64 latent grid (bicubic), test renders are not
+    big = TexturedMeshModel(cfg, device=dev, render_grid_size=96, latent_mode=True, texture_resolution=64)
+    assert big.render(1.0, 0.5, 1.3)["image"].shape == (1, 4, 64, 64)
+    test = big.render(1.0, 0.5, 1.3, decode_func=lambda t: t[:, :3].sigmoid(), test=True, dims=(80, 80))
+    assert test["image"].shape == (1, 3, 80, 80) and set(test) == {"image", "texture_map", "mask"}
+    assert float(test["image"][0, :, 0, 0].min()) == 1.0          # white background
+    with pytest.raises(ValueError):
+        big.render(1.0, 0.5, 1.3, test=True)
+    # RGB fine-tuning backbone: 3 channels, trains the RGB texture
+    rgb = TexturedMeshModel(cfg, device=dev, render_grid_size=64, latent_mode=False, texture_resolution=64)
+    assert rgb.render(1.0, 0.5, 1.3)["image"].shape == (1, 3, 64, 64)
+    assert rgb.get_params()[1] is rgb.texture_img_rgb_finetune
+
+
+@pytest.mark.parametrize("mode", ["nearest", "bilinear", "bicubic"])
+def test_config5_blub_512_texture_matches_oracle(dev, tmp_path, mode):
+    """BASELINE config 5 on its own workload: shapes/blub.obj (14 208 faces), 64 x 64 render, 512 x 512 4-channel
+    latent texture; image and d(texture) against oracle/raster_oracle.py (parity unpinned at the kaolin boundary)."""
+    from src.latent_paint.models.textured_mesh import TexturedMeshModel
+    torch.manual_seed(3)
+    cfg = _paint_cfg(tmp_path, **{"guide.texture_resolution": 512, "guide.texture_interpolation_mode": mode})
+    model = TexturedMeshModel(cfg, device=dev, render_grid_size=64, latent_mode=True, texture_resolution=512)
+    assert model.texture_img.shape == (1, 4, 512, 512)
+    theta, phi, radius = math.radians(70.0), math.radians(200.0), 1.3
+    out = model.render(theta, phi, radius)
+    g = torch.randn_like(out["image"])
+    out["image"].backward(gradient=g)
+    # ---- oracle on the same inputs
+    H = W = 64
+    verts, faces = model.mesh.vertices.cpu(), model.mesh.faces.cpu()
+    rot, pos = RO.camera_from_view(theta, phi, radius, model.dy)
+    fz, fxy = RO.prepare_vertices(verts, faces, rot, pos)
+    idx_ref, bary_ref = RO.rasterize(H, W, fz, fxy)
+    got_idx, got_bary, _, _ = model.renderer._rasterize(model.mesh.vertices, model.mesh.faces, theta, phi, radius,
+                                                        model.dy, (W, H))
+    same = got_idx.cpu().long() == idx_ref
+    assert float(same.float().mean()) > 0.99 and int((idx_ref >= 0).sum()) > 400
+    ok = same & (idx_ref >= 0)
+    assert float((got_bary.cpu()[ok] - bary_ref[ok]).abs().max()) < 2e-3
+    tex_ref = model.texture_img.detach().cpu().clone().requires_grad_()
+    uv_ref = RO.interpolate(idx_ref, bary_ref, model.face_attributes[0].cpu())
+    fg_ref = RO.texture_mapping(uv_ref, tex_ref, mode) * (idx_ref >= 0)[:, None]          # [P,4]
+    fg = out["foreground"][0].permute(1, 2, 0).reshape(-1, 4).detach().cpu()
+    diff = (fg[ok] - fg_ref[ok].detach()).abs().max(-1)[0]
+    if mode == "nearest":   # same texel unless the uv sits within rounding distance of a texel edge
+        assert float((diff < 1e-6).float().mean()) > 0.97
+    else:                   # uv differs by ~1e-6 between the f32 pipelines: x 512 texels x |d tex| ~ 1
+        assert float(diff.max()) < (2e-2 if mode == "bilinear" else 4e-2) and float(diff.mean()) < 1e-3
+    # d(texture): the oracle's autograd through ITS foreground, upstream gradient restricted to agreeing pixels
+    gm = (g[0].permute(1, 2, 0).reshape(-1, 4).cpu() * ok[:, None])
+    fg_ref.backward(gm)
+    model.texture_img.grad = None
+    out2 = model.render(theta, phi, radius)
+    keep = ok.reshape(1, 1, H, W).to(dev)
+    out2["image"].backward(gradient=g * keep * out2["mask"])
+    got = model.texture_img.grad.cpu()
+    want = tex_ref.grad
+    assert abs(float(got.sum()) - float(want.sum())) < 1e-3 * float(want.abs().sum()) + 1e-4
+    if mode == "nearest":
+        assert float(((got - want).abs() < 1e-5).float().mean()) > 0.9995
+    else:
+        assert float((got - want).abs().max()) < 5e-2 * float(want.abs().max())
+        assert float((got - want).abs().sum()) < 2e-2 * float(want.abs().sum())
+
+
+def test_latent_paint_trainer_steps_checkpoints_and_exports(dev, tmp_path):
+    """scripts/train_latent_paint.py's trainer on blub.obj: the SDS-style gradient really updates the texture (the
+    reference's own trainer never calls backward), checkpoints follow the reference schema
+    (src/latent_paint/training/trainer.py:288-310), full_eval writes the circle renders and the mesh export."""
+    from src.latent_paint.training.trainer import Trainer
+    over = {"optim.iters": 12, "log.save_interval": 6, "log.eval_size": 2, "log.full_eval_size": 3,
+            "render.eval_grid_size": 96, "guide.texture_resolution": 64, "guide.texture_interpolation_mode": "bilinear"}
+    tr = Trainer(_paint_cfg(tmp_path, **over), device=dev)
+    tex0 = tr.mesh_model.texture_img.detach().clone()
+    sky0 = tr.mesh_model.background_sphere_colors.detach().clone()
+
+    def err():
+        data = tr.dataloaders["val"]._data.collate([0])
+        pred = tr.mesh_model.render(data["theta"], data["phi"], data["radius"])["image"]
+        return float((pred - tr.diffusion.targets[int(data["dir"][0])][None]).pow(2).mean())
+
+    e0 = err()
+    tr.train()
+    assert tr.train_step == 12
+    assert float((tr.mesh_model.texture_img.detach() - tex0).abs().max()) > 1e-3
+    assert float((tr.mesh_model.background_sphere_colors.detach() - sky0).abs().max()) > 1e-3
+    assert err() < e0
+    ck = sorted(tr.ckpt_path.glob("*.pth"))
+    assert [c.name for c in ck] == ["step_000006.pth", "step_000012.pth"]
+    state = torch.load(ck[-1], map_location="cpu", weights_only=True)
+    assert set(state) == {"train_step", "checkpoints", "model", "optimizer"} and state["train_step"] == 12
+    assert set(state["model"]) == {"background_sphere_colors", "texture_img", "texture_img_rgb_finetune"}
+    files = {p.name for p in tr.final_renders_path.iterdir()}
+    assert "step_00012_texture.png" in files and any(n.startswith("step_00012_rgb.") for n in files)
+    assert {p.name for p in (tr.exp_path / "mesh").iterdir()} == {"albedo.png", "mesh.obj", "mesh.mtl"}
+    # the exported OBJ reads back with the same topology and UV indices
+    from src.latent_paint.models.mesh import Mesh
+    back = Mesh(str(tr.exp_path / "mesh" / "mesh.obj"))
+    assert torch.equal(back.faces, tr.mesh_model.mesh.faces.cpu()) and torch.equal(back.ft, tr.mesh_model.ft.cpu())
+    assert float((back.vertices - tr.mesh_model.mesh.vertices.cpu()).abs().max()) < 1e-6
+    # resume continues at train_step + 1 with the same weights; eval_only implies resume (train_config.py:94-97)
+    tr2 = Trainer(_paint_cfg(tmp_path, **dict(over, **{"log.eval_only": True})), device=dev)
+    assert tr2.train_step == 13 and torch.equal(tr2.mesh_model.texture_img, tr.mesh_model.texture_img)
+    # RGB fine-tuning backbone starts from the decoded latent texture of the checkpoint (:248-262)
+    tr3 = Trainer(_paint_cfg(tmp_path, **dict(over, **{"render.backbone": "texture-rgb-mesh", "optim.ckpt": str(ck[-1])})),
+                  device=dev)
+    want = tr3._rgb_texture_from_latents(tr.mesh_model.texture_img.detach())
+    assert torch.allclose(tr3.mesh_model.texture_img_rgb_finetune.detach(), want)
+
+
+def test_mesh_without_uvs_gets_an_atlas_and_caches_it(dev, tmp_path):
+    """teddy.obj has UVs on a third of its faces only: the reference then takes the cached atlas or
+    unwraps (textured_mesh.py:81-109).  Without xatlas the built-in per-triangle atlas is generated and cached."""
+    from src.latent_paint.models.textured_mesh import TexturedMeshModel
+    cfg = _paint_cfg(tmp_path, shape="teddy.obj")
+    m = TexturedMeshModel(cfg, device=dev, render_grid_size=64, texture_resolution=128)
+    assert m.ft.shape == (5760, 3) and int(m.ft.min()) == 0 and float(m.vt.min()) >= 0 and float(m.vt.max()) <= 1
+    assert (cfg.log.exp_dir / "vt.pth").exists() and (cfg.log.exp_dir / "ft.pth").exists()
+    m2 = TexturedMeshModel(cfg, device=dev, render_grid_size=64, texture_resolution=128)   # second time: from the cache
+    assert torch.equal(m2.vt, m.vt) and torch.equal(m2.ft, m.ft)
+    out = m.render(math.radians(80.0), 0.3, 1.4)
+    out["image"].backward(gradient=torch.ones_like(out["image"]))
+    assert float(out["mask"].mean()) > 0.05 and float(m.texture_img.grad.abs().sum()) > 0

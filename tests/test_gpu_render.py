@@ -341,3 +341,85 @@ def test_empty_frame_trains_without_samples(dev, fuse):
     torch.cuda.synchronize()
     assert torch.equal(net.encoder.embeddings.detach(), before) and torch.equal(net.w1.detach(), w_before)
     assert bool(torch.isfinite(net.encoder.shadow().float()).all())
+
+
+def test_stale_backward_after_a_second_render_fails_loudly(dev):
+    """The march reuses its sample buffers from render to render and the kernels write them through raw pointers;
+    a backward pass of an EARLIER render must not silently use the later render's samples: autograd's version check
+    fires because the reuse bumps the buffers' versions (raymarching.march_rays_train)."""
+    net, cfg, lv, table, params, grid = _make(dev, 32, 16, 12, 16)
+    net.train()
+    ro, rd = _rays(16)
+    ro2, rd2 = _rays(16, 80.0, 90.0, 1.4)
+    first = net.render(ro.to(dev), rd.to(dev), bg_color=1.0, perturb=False)
+    second = net.render(ro2.to(dev), rd2.to(dev), bg_color=1.0, perturb=False)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        first["image"].sum().backward()
+    second["image"].sum().backward()          # the latest render is still valid
+    assert float(net.encoder.embeddings.grad.abs().sum()) > 0
+
+
+def test_importance_resampling_refines_the_uniform_render(dev):
+    """`upsample_steps` (render.upsample_steps / run(upsample_steps=...)): 24 uniform + 24 importance samples land
+    closer to a 512-sample reference render than 48 uniform samples do on rays that cross the density blob, the
+    sample positions stay sorted, and gradients flow through the refined render."""
+    G, HW = 32, 16
+    net, cfg, lv, table, params, grid = _make(dev, G, HW, 12, 16, seed=9, cuda_ray=False, table_std=1e-4)
+    net.eval()
+    ro, rd = _rays(HW)
+    ro, rd = ro.to(dev), rd.to(dev)
+    with torch.no_grad():
+        fine = net.render(ro, rd, bg_color=1.0, num_steps=512)["weights_sum"][0]
+        coarse = net.render(ro, rd, bg_color=1.0, num_steps=48)["weights_sum"][0]
+        refined = net.render(ro, rd, bg_color=1.0, num_steps=24, upsample_steps=24)["weights_sum"][0]
+    hit = fine > 0.05
+    assert int(hit.sum()) > 20
+    e_coarse = float((coarse - fine)[hit].abs().mean())
+    e_refined = float((refined - fine)[hit].abs().mean())
+    assert e_refined < e_coarse, (e_refined, e_coarse)
+    # the config field drives the default of render()
+    cfg.upsample_steps, cfg.num_steps = 24, 24
+    with torch.no_grad():
+        again = net.render(ro, rd, bg_color=1.0)["weights_sum"][0]
+    assert torch.equal(again, refined)                       # stratified (deterministic) when not training
+    net.train()
+    out = net.render(ro, rd, bg_color=1.0, perturb=True)
+    out["image"].sum().backward()
+    assert float(net.encoder.embeddings.grad.abs().sum()) > 0 and bool(torch.isfinite(out["image"]).all())
+    from src.latent_nerf.models.renderer import _sample_pdf
+    bins = torch.linspace(0, 1, 9, device=dev)[None].repeat(3, 1)
+    w = torch.tensor([[0, 0, 0, 1, 1, 0, 0, 0.0], [1, 0, 0, 0, 0, 0, 0, 0], [1, 1, 1, 1, 1, 1, 1, 1]], device=dev)
+    z = _sample_pdf(bins, w, 64, stratified=True)
+    assert bool((z[:, 1:] >= z[:, :-1]).all())
+    assert float(((z[0] > 0.375) & (z[0] < 0.625)).float().mean()) > 0.95    # mass sits in the two middle bins
+    assert float((z[1] < 0.125).float().mean()) > 0.95
+    assert float((z[2] - torch.linspace(0.5 / 64, 1 - 0.5 / 64, 64, device=dev)).abs().max()) < 1e-5   # uniform -> identity
+
+
+def test_sample_budget_follows_the_observed_march(dev):
+    """Capacity of the sample buffers: worst case (rays x 256) until the first occupancy refresh has read the march
+    counters back, then 2 x M rounded to 128 Ki -- and rays that do not fit a too-small budget are dropped and counted,
+    never written out of bounds."""
+    net, cfg, lv, table, params, grid = _make(dev, 64, 32, 14, 16, seed=1)
+    net.train()
+    ro, rd = _rays(32)
+    ro, rd = ro.to(dev), rd.to(dev)
+    out = net.render(ro, rd, bg_color=1.0, perturb=False)
+    N = 32 * 32
+    assert out["xyzs"].shape[0] == N * 256
+    M = int(out["counter"][0])
+    img0 = out["image"].detach().clone()
+    net.update_extra_state()                                  # the sync point: budget derived here
+    assert net._budget == ((N, 1024), -(-2 * M // 131072) * 131072) and net.mean_count == M
+    net.density_grid.copy_(grid.to(dev))                      # put the test scene back (the refresh re-estimated it)
+    net.density_bitfield.copy_(O.packbits(grid.reshape(-1), 0.01).to(dev))
+    out = net.render(ro, rd, bg_color=1.0, perturb=False)
+    assert out["xyzs"].shape[0] == net._budget[1] < N * 256 and int(out["counter"][0]) == M
+    assert torch.equal(out["image"], img0)
+    # an explicit (too small) budget: later rays are dropped and counted
+    cfg.max_samples = (M // 2 // 64) * 64
+    out = net.render(ro, rd, bg_color=1.0, perturb=False)
+    c = out["counter"].cpu()
+    assert int(c[0]) <= cfg.max_samples and int(c[2]) > 0 and out["xyzs"].shape[0] == cfg.max_samples
+    out["image"].sum().backward()
+    assert bool(torch.isfinite(net.encoder.embeddings.grad).all())

@@ -55,3 +55,26 @@ def test_synthetic_guidance_contract():
 def test_sparsity_loss_prefers_binary_opacity():
     assert sparsity_loss(torch.tensor([0.0, 1.0, 1.0, 0.0])) < 1e-3
     assert abs(float(sparsity_loss(torch.tensor([0.5, 0.5]))) - 1.0) < 1e-6
+
+
+def test_precision_follows_fp16_only_where_left_on_auto():
+    """`optim.fp16` picks bf16 for the table shadow and the MLP unless the user set `render.mlp_precision` /
+    `render.table_dtype` explicitly -- whatever the order of the flags (the f32 parity path must be reachable)."""
+    from src.latent_nerf.configs.render_config import RenderConfig
+    assert (TrainConfig().render.mlp_precision, TrainConfig().render.table_dtype) == ("bf16", "bf16")
+    c = load_config(["--optim.fp16", "false"])
+    assert (c.optim.fp16, c.render.mlp_precision, c.render.table_dtype) == (False, "f32", "f32")
+    for argv in (["--render.mlp_precision", "f32", "--render.table_dtype", "f32"],
+                 ["--render.table_dtype", "f32", "--optim.fp16", "true", "--render.mlp_precision", "f32"]):
+        c = load_config(argv)
+        assert (c.optim.fp16, c.render.mlp_precision, c.render.table_dtype) == (True, "f32", "f32")
+    c = load_config(["--optim.fp16", "true", "--render.mlp_precision", "f32"])
+    assert (c.render.mlp_precision, c.render.table_dtype) == ("f32", "bf16")
+    c = load_config(["--optim.fp16", "false", "--render.mlp_precision", "bf16"])
+    assert (c.render.mlp_precision, c.render.table_dtype) == ("bf16", "f32")
+    c = apply_overrides(load_config(["--optim.fp16", "false"]), {"optim.fp16": True})   # re-resolved after a later change
+    assert (c.render.mlp_precision, c.render.table_dtype) == ("bf16", "bf16")
+    r = RenderConfig()                        # a bare RenderConfig means the f32 parity path
+    assert r.mlp_precision == "auto" and r.precision("mlp_precision") == "f32" and r.precision("table_dtype") == "f32"
+    with pytest.raises(ValueError):
+        load_config(["--render.mlp_precision", "fp8"])
