@@ -57,25 +57,16 @@ const char *lnerf_last_error(void);
 const char *lnerf_build_info(void);
 
 /* Performance knobs (never change results beyond float summation order).  Keys:
- *   "scatter_compact_max_res": levels with resolution <= value merge per-wavefront runs of equal
- *                              rows before binning (default 512).
- *   "scatter_bin_map":         workgroup->(level,tile) map of the binning pass, 0 = level on
- *                              blockIdx.y, 1 = XCD-aware, 2 (default) = persistent workgroups that
- *                              stride over the (tile, level) list and prefetch the next item's inputs.
- *   "scatter_bin_wgs":         persistent workgroups of map 2 (default 768 = 3 per CU).
- *   "scatter_bin_spt":         samples per thread of the binning pass with 8-byte records, 1 (default) or 2
- *                              (1024-sample items: half the per-item costs per sample, measured slower).
- *   "scatter_bin_debug":       TIMING-ONLY experiment switch (non-zero values give wrong sums; refused
- *                              unless the environment variable LNERF_TIMING_EXPERIMENTS is set).
+ *   "scatter_compact_max_res": levels with resolution <= value merge per-wavefront runs of samples in one cell
+ *                              before binning (default 512).
+ *   "scatter_bin_per_cu":      persistent workgroups of the binning pass per CU: 2 (default, what its LDS admits) or 1.
+ *   "scatter_bin_wgs":         persistent workgroups of the binning pass (default 0 = 256 x scatter_bin_per_cu).
+ *   "scatter_skip_zero":       1 (default) = contributions that are exactly zero are not binned.
+ *   "scatter_reduce_threads":  threads per workgroup of the reduce pass, 512 or 1024 (default 1024).
  *   "gather_pair_loads":       1 (default) = x-adjacent vertices fetched with one load where adjacent.
  *   "gather_dedup_max_res":    levels with resolution <= value fetch a cell's 8 vertices once per run of
  *                              lanes (consecutive samples of a ray) in that cell (default 512; 0 = off).
  *   "mlp_fwd_blocks":          persistent workgroups of the bf16 MLP forward (default 512).
- *   "scatter_split_level":     levels >= value are binned first and reduced on a side stream while the others
- *                              are binned (default 0 = single stream; the split measured slower).
- *   "scatter_skip_zero":       1 (default) = contributions that are exactly zero are not binned.
- *   "scatter_bin_tile":        samples per binning tile, 256 or 512 (default 512).
- *   "scatter_reduce_threads":  threads per workgroup of the reduce pass, 512 or 1024 (default 1024).
  */
 int lnerf_set_tuning(const char *key, int value);
 

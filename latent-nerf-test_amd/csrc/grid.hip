@@ -314,10 +314,10 @@ k_grid_backward_atomic(const float *__restrict__ xyzs, float bound, const TG *__
 // (MI355X_MICROARCH.md "Global float atomics"): 55 M vertex updates per frame cost ~10 ms that
 // way.  Instead every level's table is cut into buckets of BK_ROWS consecutive rows (64 KiB of
 // f32x2 accumulators = one LDS tile):
-//   pass 1 (k_scatter_bin)    one thread per (sample, level) computes its 8 (row, w*g) records,
-//                             ranks them inside the workgroup tile with LDS counters, reserves a
-//                             span per touched bucket with ONE returning global atomic, and
-//                             appends the 16-byte records to the bucket's region with plain stores;
+//   pass 1 (k_scatter_bin)    one thread per (sample, level) computes its 8 (row, w*g) records (runs of
+//                             samples in one cell merged first on coarse levels), groups the workgroup's
+//                             records by bucket in LDS, reserves a span per touched bucket with ONE returning
+//                             global atomic, and appends the records to the bucket's region with plain stores;
 //   pass 2 (k_scatter_reduce) one workgroup per (bucket, slice) streams its records (coalesced
 //                             16 B/lane), accumulates them with LDS float atomics and adds the
 //                             64 KiB tile to the gradient table with coalesced stores.
@@ -412,208 +412,331 @@ __device__ unsigned long long g_bin_stamps[16];
 #define BIN_STAMP_FLUSH() do { } while (0)
 #endif
 
-template <typename TG, int BIN_T, typename REC, int SPT>
-__global__ void __launch_bounds__(BIN_T, SPT == 2 ? 4 : (BIN_T == 512 ? 6 : (BIN_T == 1024 ? 4 : 3)))
-k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict__ dfeat, GridMeta meta, BucketMeta bm,
+// ---- pass 1: k_scatter_bin ---------------------------------------------------------------------------------------
+// A work item is BIN_T = 512 consecutive samples of ONE level; PERSISTENT workgroups (3 per CU) stride over the
+// tile-major (tile, level) list, the level rotated by one per round (every workgroup sees every level; the levels'
+// bucket cursors are hit evenly), and fetch the next item's inputs while the current one is processed.  rocprofv3
+// (profiles/r02_pmc_scatter*.json) shows the pass bound by vector-ALU issue -- ~590 VALU instructions per wavefront
+// and item in round 1's form, 73 % of the SIMD cycles -- and by the per-item chain of LDS / global round trips, not by
+// bytes.  Hence, in this form:
+//   * hashed levels (rows of a wavefront spread over all buckets): records ranked with LDS counters, grouped by
+//     bucket in an LDS stage (exact packing from a count scan), ONE returning global atomic per touched bucket
+//     reserves the span, coalesced copy-out; two barriers per item (counters double-buffered);
+//   * dense levels (rows = x + y s + z s^2: a wavefront of consecutive samples touches a handful of buckets): no
+//     stage, no count scan and no workgroup barrier -- every wavefront ranks its records with a private LDS
+//     histogram, reserves its own spans and stores the records directly (consecutive ranks = consecutive slots);
+//   * the level's largest |value| (fixed-point scale of pass 2) is bounded from |g| (weights <= 1, runs <= 64
+//     samples) instead of being measured on the 16 products, one LDS maximum per level and workgroup; records are
+//     packed with bit-field inserts; run sums use fused DPP adds.
+constexpr int BIN_T = 512;                 // threads per workgroup = samples per item
+constexpr int BIN_WAVES = BIN_T / 64;
+// dense levels with this many buckets take the direct path (fewer: every wavefront's reservation would hit the same
+// one or two cursor words -- one word takes ~88 returning atomics per microsecond; more: the per-wave histogram)
+constexpr int BIN_DIRECT_MIN = 8, BIN_DIRECT_NB = 64;
+
+// fast f32 -> 26-bit float (round to nearest even), valid for finite values
+__device__ __forceinline__ uint32_t f26_round(float v) {
+    const uint32_t u = __float_as_uint(v);
+    return u + 0x1Fu + ((u >> 6) & 1u);  // (low 6 bits are dropped by the packing)
+}
+template <typename REC, bool CAREFUL> struct PackRec;
+template <bool CAREFUL> struct PackRec<Rec12, CAREFUL> {
+    static __device__ __forceinline__ Rec12 make(uint32_t row, float a, float b) { return Rec12::make(row, a, b); }
+};
+template <> struct PackRec<Rec8, true> {   // non-finite values present in the wavefront: the reference packing
+    static __device__ __forceinline__ Rec8 make(uint32_t row, float a, float b) { return Rec8::make(row, a, b); }
+};
+template <> struct PackRec<Rec8, false> {  // bits [0,12) row, [12,38) value 0, [38,64) value 1 -- same layout, fewer ops
+    static __device__ __forceinline__ Rec8 make(uint32_t row, float a, float b) {
+        const uint32_t ua = f26_round(a), ub = f26_round(b);
+        Rec8 r;
+        r.lo = ((ua << 6) & 0xFFFFF000u) | (row & 0xFFFu);
+        r.hi = (ua >> 26) | (ub & 0xFFFFFFC0u);
+        return r;
+    }
+};
+
+// maximum over the wave of unsigned values, returned in every lane: one fused DPP max per step (a dependent chain:
+// every DPP read needs the two wait states after the VALU write, which the compiler cannot see inside inline asm)
+__device__ __forceinline__ unsigned int wave_max_u32(unsigned int v) {
+    asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
+    return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// inclusive wave scans of 8 value pairs at once, one fused DPP add per value and step.  The 16 chains are
+// independent, so consecutive DPP reads never hit the VALU-write -> DPP-read hazard inside the block; the leading and
+// trailing s_nop cover the instructions the compiler places around it (inline asm is opaque to its hazard pass).
+__device__ __forceinline__ void wave_inclusive_sum_x16(float (&a)[8], float (&b)[8]) {
+#define LNERF_DPP_STEP(ctrl)                                                                                        \
+    asm volatile("s_nop 1" ::: );                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                 \
+        asm volatile("v_add_f32_dpp %0, %0, %0 " ctrl : "+v"(a[i]));                                                \
+        asm volatile("v_add_f32_dpp %0, %0, %0 " ctrl : "+v"(b[i]));                                                \
+    }
+    LNERF_DPP_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+    LNERF_DPP_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+    LNERF_DPP_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+    LNERF_DPP_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+    LNERF_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+    LNERF_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+    asm volatile("s_nop 1" ::: );
+#undef LNERF_DPP_STEP
+}
+
+// what the binning pass needs to know about a level (read from the kernel arguments in the kernel body only: the
+// lambdas below take it by value, so the argument structs are never copied to scratch)
+struct BinLevel {
+    float scale;
+    uint32_t res, hsize, off;
+    int level, nb, cap, b0;
+    long long rstart;
+    bool compact, direct;
+};
+#define LNERF_BIN_LEVEL(lv)                                                                                          \
+    BinLevel {                                                                                                       \
+        meta.scales[lv], (uint32_t)meta.res[lv], (uint32_t)(meta.offsets[(lv) + 1] - meta.offsets[lv]),              \
+            (uint32_t)meta.offsets[lv], (lv), bm.nb[lv], bm.cap[lv], bm.bstart[lv], bm.rstart[lv], bm.compact[lv] != 0, \
+            (uint64_t)(meta.res[lv] + 1) * (meta.res[lv] + 1) * (meta.res[lv] + 1) <=                                 \
+                    (uint64_t)(meta.offsets[(lv) + 1] - meta.offsets[lv]) &&                                          \
+                bm.nb[lv] >= BIN_DIRECT_MIN && bm.nb[lv] <= BIN_DIRECT_NB                                             \
+    }
+
+template <typename REC>
+__global__ void __launch_bounds__(BIN_T, (sizeof(REC) == 8 ? 6 : 4))
+k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restrict__ dfeat, GridMeta meta, BucketMeta bm,
               int64_t m_host, const int32_t *__restrict__ m_dev, int64_t level_stride, int32_t *__restrict__ cursor,
-              unsigned int *__restrict__ gmax, REC *__restrict__ recs, float *__restrict__ dtable, int variant,
-              int skip_zero, int level_lo, int dbg) {
-    // SPT samples per thread: an item is IT = BIN_T * SPT consecutive samples of one level.  SPT = 2 halves the
-    // per-item costs (barriers, reservations and their latency, count scan) per sample and doubles the span a bucket
-    // gets from one reservation, at twice the LDS stage and register state.
-    constexpr int IT = BIN_T * SPT;
-    __shared__ int s_cnt[2][BK_MAX_PER_LEVEL];  // records of this tile per bucket (double-buffered per item)
-    __shared__ int s_base[BK_MAX_PER_LEVEL];  // first slot reserved in the bucket's global region
-    __shared__ int s_off[BK_MAX_PER_LEVEL];   // first slot of the bucket in the LDS stage
-    __shared__ unsigned int s_max[2];         // bit pattern of the tile's largest |value|
-    __shared__ int s_dest[BK_MAX_PER_LEVEL];  // global slot of the bucket's first staged record, minus its stage offset
-    __shared__ int s_ovf[2];                  // some bucket of this tile ran past its region
-    __shared__ REC s_stage[IT * 8];           // the tile's records, grouped by bucket (48 KiB, 32 KiB packed, x SPT)
-    __shared__ uint8_t s_bkt[REC::kPacked ? IT * 8 : 4];  // packed records do not name their bucket: kept beside
-    int64_t M = m_host;
-    if (m_dev) { const int64_t md = *m_dev; M = md < M ? md : M; }
+              unsigned int *__restrict__ gmax, REC *__restrict__ recs, float *__restrict__ dtable, int skip_zero) {
+    __shared__ int s_cnt[2][BK_MAX_PER_LEVEL];  // records of the item per bucket (two sets: hashed items alternate)
+    __shared__ int s_base[BK_MAX_PER_LEVEL];    // first slot reserved in the bucket's global region
+    __shared__ int s_off[BK_MAX_PER_LEVEL];     // first slot of the bucket in the LDS stage
+    __shared__ int s_dest[BK_MAX_PER_LEVEL];    // global slot of the bucket's first staged record, minus its stage offset
+    __shared__ int s_ovf[2];                    // some bucket of this item ran past its region
+    __shared__ REC s_stage[BIN_T * 8];          // the item's records, grouped by bucket (48 KiB, 32 KiB packed)
+    __shared__ uint8_t s_bkt[REC::kPacked ? BIN_T * 8 : 4];  // packed records do not name their bucket: kept beside
+    __shared__ int s_wave[BIN_WAVES][BIN_DIRECT_NB];          // dense levels: per-wave histogram, then per-wave bases
+    __shared__ unsigned int s_lmax[LNERF_MAX_LEVELS];         // per level: bound of |value| seen by this workgroup
+    int32_t M = (int32_t)m_host;
+    if (m_dev) { const int32_t md = *m_dev; M = md < M ? md : M; }
     const int L = meta.num_levels;
-    const int tid = threadIdx.x, lane = tid & 63;
-    // Work items = (level, tile) pairs.  variant 2 (default): a PERSISTENT 1-D grid of G workgroups (G a multiple
-    // of L, as many per CU as the LDS stage admits); workgroup w takes items w, w+G, w+2G, ... of the tile-major list
-    // and rotates the level by one per round, so every workgroup sees every level (balanced) and the 16 levels'
-    // bucket cursors are hit evenly.  variants 0/1: the (level, tile) maps of the gather.
-    TileMap tm;
-    tm.ok = true; tm.level = 0; tm.tile0 = 0; tm.tstep = 1;
-    if (variant != 2) tm = tile_map(variant, L);
-    const int64_t G = gridDim.x;
-    auto locate = [&](int64_t k, int &lv, int64_t &tl) -> bool {
-        if (variant == 2) {
-            tl = ((int64_t)blockIdx.x + k * G) / L;
-            lv = (int)(((int64_t)blockIdx.x + k) % L);
-        } else {
-            tl = tm.tile0 + k * tm.tstep;
-            lv = tm.level + level_lo;  // level_lo != 0 only with the blockIdx.y map (a launch over a level range)
-            if (!tm.ok || lv >= L) return false;
-        }
-        return tl * IT < M;
-    };
-    // inputs of the NEXT item are fetched while the current one is ranked and staged (the pass waits on memory
-    // round trips, not on arithmetic: rocprofv3 shows 64 % of the wave cycles parked)
-    float2 n_gg[SPT];
-    float n_x[SPT], n_y[SPT], n_z[SPT];
-    auto fetch = [&](int lv, int64_t tl) {
-#pragma unroll
-        for (int u = 0; u < SPT; ++u) {
-            const int64_t mm = tl * IT + u * BIN_T + tid;
-            n_gg[u] = make_float2(0.f, 0.f);
-            n_x[u] = n_y[u] = n_z[u] = 0.f;
-            if (mm < M) {
-                n_gg[u] = Feat2<TG>::load(dfeat + ((int64_t)lv * level_stride + mm) * 2, 0);
-                n_x[u] = xyzs[mm * 3]; n_y[u] = xyzs[mm * 3 + 1]; n_z[u] = xyzs[mm * 3 + 2];
-            }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // item k of this workgroup: tile t0 + k * tstep, level (l0 + k) mod L   (gridDim.x is a multiple of L)
+    const int tstep = gridDim.x / L;
+    const float two_b = 2.0f * bound;
+    const bool pow2_bound = (__float_as_uint(two_b) & 0x007FFFFFu) == 0u;
+    const float inv_two_b = 1.0f / two_b;  // exact when the bound is a power of two (the only case it is used in)
+    for (int i = tid; i < 2 * BK_MAX_PER_LEVEL; i += BIN_T) (&s_cnt[0][0])[i] = 0;
+    if (tid < LNERF_MAX_LEVELS) s_lmax[tid] = 0u;
+    if (tid < 2) s_ovf[tid] = 0;
+    // ---- inputs of an item (5 dwords per lane), fetched while the previous item is processed (the pass waits on
+    // memory round trips, not on bytes)
+    float n_x = 0.f, n_y = 0.f, n_z = 0.f;
+    float2 n_g = make_float2(0.f, 0.f);
+    auto fetch = [&](int lv, int tl) __attribute__((always_inline)) {
+        const int mm = tl * BIN_T + tid;
+        n_x = n_y = n_z = 0.f;
+        n_g = make_float2(0.f, 0.f);
+        if (mm < M) {
+            n_g = reinterpret_cast<const float2 *>(dfeat)[(int64_t)lv * level_stride + mm];
+            n_x = xyzs[(int64_t)mm * 3]; n_y = xyzs[(int64_t)mm * 3 + 1]; n_z = xyzs[(int64_t)mm * 3 + 2];
         }
     };
-#pragma unroll
-    for (int u = 0; u < SPT; ++u) { n_gg[u] = make_float2(0.f, 0.f); n_x[u] = n_y[u] = n_z[u] = 0.f; }
-    int l = 0;
-    int64_t tile = 0;
-    bool have = locate(0, l, tile);
+    // a record that cannot be placed in its bucket's region: finished with global float atomics
+    auto spill = [&](uint32_t level_off, const REC &r, int b) __attribute__((always_inline)) {
+        float *lt = dtable + (int64_t)level_off * 2;
+        const int64_t full_row = ((int64_t)b << BK_SHIFT) | r.row_in_bucket();
+        atomicAdd(lt + full_row * 2, r.a());
+        atomicAdd(lt + full_row * 2 + 1, r.b());
+    };
+    int l = (int)(blockIdx.x % L);
+    int tile = (int)(blockIdx.x / L);
+    bool have = tile * BIN_T < M;
     if (have) fetch(l, tile);
     BIN_STAMP_INIT();
-    for (int i = tid; i < BK_MAX_PER_LEVEL; i += BIN_T) s_cnt[0][i] = 0;
-    if (tid == 0) { s_max[0] = 0u; s_ovf[0] = 0; }
     __syncthreads();
-    for (int64_t k = 0; have; ++k) {
-        // Two barriers per item.  Counters, tile maximum and overflow flag are double-buffered (set k & 1): the set
-        // of the next item is cleared after barrier 1, when every wave has left the previous item, and nobody
-        // touches it before barrier 3 has been passed.
-        const int cur = (int)(k & 1);
-        const float scale = meta.scales[l];
-        const uint32_t res = (uint32_t)meta.res[l];
-        const uint32_t off = (uint32_t)meta.offsets[l];
-        const uint32_t hsize = (uint32_t)(meta.offsets[l + 1] - meta.offsets[l]);
-        const int nb = bm.nb[l], cap = bm.cap[l], b0 = bm.bstart[l];
-        const bool compact = bm.compact[l] != 0;  // wave-uniform: coarse level, merge runs first
-        const bool few_buckets = nb <= 32;        // wave-uniform: rank with ballots instead of per-lane LDS atomics
-        REC *lrec = recs + bm.rstart[l];
-        float *lt = dtable + (int64_t)off * 2;
+    int hk = 0;  // hashed items so far (selects the counter set)
+    while (have) {
+        const BinLevel lv = LNERF_BIN_LEVEL(l);
+        const int nb = lv.nb, cap = lv.cap;
+        REC *lrec = recs + lv.rstart;
+        const int l_next = l + 1 == L ? 0 : l + 1;
+        const int tile_next = tile + tstep;
+        const bool have_next = tile_next * BIN_T < M;
         BIN_STAMP(0);
-        int l_next = 0;
-        int64_t tile_next = 0;
-        const bool have_next = locate(k + 1, l_next, tile_next);
         // ---- A: cell, rows, runs, and WHICH lanes append records.  Samples behind a ray's termination point
         // (T < T_thresh) get dsigma = drgb = 0 from the compositing backward, hence dfeat = 0 exactly: a run (or
         // sample) whose gradients are all zero appends nothing, and a wavefront of 64 such samples skips its
-        // index arithmetic altogether.  The values themselves are computed later, behind the reservations.
-        float2 gg[SPT];
-        LevelPos p[SPT];
-        RunInfo ri[SPT];
-        uint32_t row[SPT][8];
-        int rank[SPT][8];
-        uint32_t emit[SPT];  // bit c: this lane appends a record for corner c
-        bool wave_live[SPT];
-#pragma unroll
-        for (int u = 0; u < SPT; ++u) {
-            const int64_t m = tile * IT + u * BIN_T + tid;
-            const bool valid = m < M;
-            gg[u] = n_gg[u];
-            const bool nzg = valid && (gg[u].x != 0.f || gg[u].y != 0.f);
-            const unsigned long long nzmask = __ballot(nzg);
-            wave_live[u] = !skip_zero || nzmask != 0ull;
-            p[u].gx = p[u].gy = p[u].gz = 0; p[u].fx = p[u].fy = p[u].fz = 0.f;
-            ri[u].start = lane; ri[u].tail = true;
-            emit[u] = 0;
-            if (wave_live[u]) {
-                if (valid) p[u] = level_pos_xyz(n_x[u], n_y[u], n_z[u], bound, scale);
-                corner_rows(p[u].gx, p[u].gy, p[u].gz, res, hsize, row[u]);
-                if (compact) {  // wave-uniform branch
-                    ri[u] = wave_cell_runs(p[u].gx, p[u].gy, p[u].gz, valid);
-                    const unsigned long long seg = (nzmask >> ri[u].start) & ((2ull << (lane - ri[u].start)) - 1ull);
-                    emit[u] = (valid && ri[u].tail && (!skip_zero || seg != 0ull)) ? 0xFFu : 0u;
-                } else {
-                    emit[u] = (valid && (!skip_zero || nzg)) ? 0xFFu : 0u;
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) row[u][c] = 0u;
+        // arithmetic altogether.
+        const int m = tile * BIN_T + tid;
+        const bool valid = m < M;
+        const float2 gg = n_g;
+        const bool nzg = valid && (gg.x != 0.f || gg.y != 0.f);
+        const unsigned long long nzmask = __ballot(nzg);
+        const bool wave_live = !skip_zero || nzmask != 0ull;
+        LevelPos p;
+        p.gx = p.gy = p.gz = 0u; p.fx = p.fy = p.fz = 0.f;
+        RunInfo ri;
+        ri.start = lane; ri.tail = true;
+        uint32_t row[8];
+        bool emit = false;
+        if (wave_live) {
+            if (valid) {
+                float px = n_x + bound, py = n_y + bound, pz = n_z + bound;
+                if (pow2_bound) { px *= inv_two_b; py *= inv_two_b; pz *= inv_two_b; }   // == the division, exactly
+                else { px /= two_b; py /= two_b; pz /= two_b; }
+                px = px * lv.scale; py = py * lv.scale; pz = pz * lv.scale;
+                px = px + 0.5f; py = py + 0.5f; pz = pz + 0.5f;
+                const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+                p.gx = (uint32_t)(int)flx; p.gy = (uint32_t)(int)fly; p.gz = (uint32_t)(int)flz;
+                p.fx = px - flx; p.fy = py - fly; p.fz = pz - flz;
             }
-        }
-        BIN_STAMP(1);
-        // ---- B: rank every record inside its bucket (tile-local)
+            corner_rows(p.gx, p.gy, p.gz, lv.res, lv.hsize, row);
+            if (lv.compact) {  // wave-uniform: coarse level, merge runs of samples in the same cell first
+                ri = wave_cell_runs(p.gx, p.gy, p.gz, valid);
+                const unsigned long long seg = (nzmask >> ri.start) & ((2ull << (lane - ri.start)) - 1ull);
+                emit = valid && ri.tail && (!skip_zero || seg != 0ull);
+            } else {
+                emit = valid && (!skip_zero || nzg);
+            }
+        } else {
 #pragma unroll
-        for (int u = 0; u < SPT; ++u) {
+            for (int c = 0; c < 8; ++c) row[c] = 0u;
+        }
+        // ---- D (a lambda: placed behind the reservations on hashed levels): the values w * g (run sums on coarse
+        // levels), packed into records; the bound of |value| goes to the level's LDS maximum
+        REC rec[8];
+        auto values = [&]() __attribute__((always_inline)) {
+            if (!wave_live) return;
+            float v0[8], v1[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const bool e = (emit[u] >> c) & 1u;
-                const int b = (int)(row[u][c] >> BK_SHIFT);
-                rank[u][c] = 0;
-                if (few_buckets) {  // all lanes of a wave mostly target one or two buckets
-                    unsigned long long todo = __ballot(e);
-                    while (todo) {
-                        const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
-                        const int bl = __builtin_amdgcn_readlane(b, leader);
-                        const unsigned long long mm = __ballot(e && b == bl);
-                        int base = 0;
-                        if (lane == leader) base = atomicAdd(&s_cnt[cur][bl], __popcll(mm));
-                        base = __builtin_amdgcn_readlane(base, leader);
-                        if (e && b == bl) rank[u][c] = base + mbcnt(mm);
-                        todo &= ~mm;
-                    }
-                } else if (e) {
-                    rank[u][c] = atomicAdd(&s_cnt[cur][b], 1);
-                }
+                const float wx = (c & 1) ? p.fx : 1.0f - p.fx;
+                const float wy = (c & 2) ? p.fy : 1.0f - p.fy;
+                const float wz = (c & 4) ? p.fz : 1.0f - p.fz;
+                const float w = (wx * wy) * wz;
+                v0[c] = w * gg.x;
+                v1[c] = w * gg.y;
             }
-        }
-        BIN_STAMP(2);
-        __syncthreads();  // barrier 1: the tile's bucket counts are final
-        BIN_STAMP(3);
-        for (int i = tid; i < BK_MAX_PER_LEVEL; i += BIN_T) s_cnt[cur ^ 1][i] = 0;
-        if (tid == 0) { s_max[cur ^ 1] = 0u; s_ovf[cur ^ 1] = 0; }
-        // ---- C: ONE returning global atomic per touched bucket reserves its span; the next item's inputs follow
-        // them into the memory queue; both are consumed after the arithmetic below
-        int my_base[(BK_MAX_PER_LEVEL + BIN_T - 1) / BIN_T];
-#pragma unroll
-        for (int kk = 0; kk < (BK_MAX_PER_LEVEL + BIN_T - 1) / BIN_T; ++kk) {
-            const int i = tid + kk * BIN_T;
-            my_base[kk] = 0;
-            if (i < nb) {
-                const int c = s_cnt[cur][i];
-                // dbg (TIMING-ONLY experiments, wrong results): 1 = no reservation, every tile writes slots 0.. of
-                // the bucket; 2 = reservations made, stores folded into the first 64 slots of the bucket
-                if (c && !(dbg & 1)) my_base[kk] = atomicAdd(&cursor[b0 + i], c);
-            }
-        }
-        if (have_next) fetch(l_next, tile_next);
-        // ---- D: the values w * g (run sums on coarse levels) and the tile's largest |value|
-        float v0[SPT][8], v1[SPT][8];
-#pragma unroll
-        for (int u = 0; u < SPT; ++u) {
-            if (wave_live[u]) {
+            float mx = fmaxf(fabsf(gg.x), fabsf(gg.y));  // weights are <= 1 ...
+            const bool odd = ((__float_as_uint(gg.x) & 0x7F800000u) == 0x7F800000u) ||
+                             ((__float_as_uint(gg.y) & 0x7F800000u) == 0x7F800000u);  // NaN / inf in the gradient
+            if (lv.compact) {
+                wave_inclusive_sum_x16(v0, v1);   // run sum = P[tail] - P[start - 1]
+                const int prev = (ri.start - 1) << 2;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    const uint32_t bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
-                    const float wx = bx ? p[u].fx : 1.0f - p[u].fx;
-                    const float wy = by ? p[u].fy : 1.0f - p[u].fy;
-                    const float wz = bz ? p[u].fz : 1.0f - p[u].fz;
-                    const float w = (wx * wy) * wz;
-                    v0[u][c] = w * gg[u].x;
-                    v1[u][c] = w * gg[u].y;
+                    const float a = __int_as_float(__builtin_amdgcn_ds_bpermute(prev, __float_as_int(v0[c])));
+                    const float b = __int_as_float(__builtin_amdgcn_ds_bpermute(prev, __float_as_int(v1[c])));
+                    if (ri.start > 0) { v0[c] -= a; v1[c] -= b; }
                 }
-                if (compact) {
+                mx *= 64.0f;                             // ... and a run sums at most 64 samples
+            }
+            const bool any_odd = __ballot(odd) != 0ull;
+            // (a per-lane LDS maximum, filtered by the current bound, measured 32 us SLOWER than this wave reduction)
+            const unsigned int mb = wave_max_u32(__float_as_uint(any_odd ? 3.0e38f : mx));  // (bits of floats >= 0 order as uints)
+            if (lane == 0 && mb != 0u) atomicMax(&s_lmax[lv.level], mb);
+            if (!any_odd) {
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        v0[u][c] = run_sum(v0[u][c], ri[u]);
-                        v1[u][c] = run_sum(v1[u][c], ri[u]);
-                    }
-                }
-                float mx = 0.f;
-#pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    if ((emit[u] >> c) & 1u) mx = fmaxf(mx, fmaxf(fabsf(v0[u][c]), fabsf(v1[u][c])));
-                mx = wave_max_nonneg(mx);  // DPP wave max, one LDS atomic per wave (+floats order as uints)
-                if (lane == 0 && mx > 0.f) atomicMax(&s_max[cur], __float_as_uint(mx));
+                for (int c = 0; c < 8; ++c) rec[c] = PackRec<REC, false>::make(row[c] & ((1u << 20) - 1u), v0[c], v1[c]);
             } else {
 #pragma unroll
-                for (int c = 0; c < 8; ++c) { v0[u][c] = 0.f; v1[u][c] = 0.f; }
+                for (int c = 0; c < 8; ++c) rec[c] = PackRec<REC, true>::make(row[c] & ((1u << 20) - 1u), v0[c], v1[c]);
+            }
+        };
+        // ranks the wavefront's records of corner c in `counters` (LDS): where the lanes of a wave mostly target one or
+        // two buckets (dense levels, tiny tables) one LDS atomic per (wave, bucket) instead of one per lane -- same-address
+        // LDS atomics serialise
+        auto rank_by_ballot = [&](int *counters, int c) __attribute__((always_inline)) {
+            const int b = (int)(row[c] >> BK_SHIFT);
+            int rk = 0;
+            unsigned long long todo = __ballot(emit);
+            while (todo) {
+                const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+                const int bl = __builtin_amdgcn_readlane(b, leader);
+                const unsigned long long mm = __ballot(emit && b == bl);
+                int base = 0;
+                if (lane == leader) base = atomicAdd(&counters[bl], __popcll(mm));
+                base = __builtin_amdgcn_readlane(base, leader);
+                if (emit && b == bl) rk = base + mbcnt(mm);
+                todo &= ~mm;
+            }
+            row[c] |= (uint32_t)rk << 20;
+        };
+        BIN_STAMP(1);
+        const int cur = hk & 1;
+        // the rank of a record inside its bucket -- among the item's records (hashed) / the wavefront's (dense), < 4096 --
+        // is kept in bits [20, 32) of its row (rows of a level are < 2^20: at most 256 buckets of 4096 rows)
+        constexpr uint32_t ROW_MASK = (1u << 20) - 1u;
+        int my_base = 0;   // hashed: thread b holds the reserved base of bucket b; dense: lane b the wave's span base
+        if (lv.direct) {
+            // ================= dense level: every wavefront places its own records, no workgroup barrier ==========
+            int *hist = s_wave[wave];
+            if (lane < BIN_DIRECT_NB) hist[lane] = 0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (LDS is in order within a wave)
+            if (lv.compact) {  // few lanes emit (run tails): plain per-lane counter increments (measured 17 us faster)
+                if (emit) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) row[c] |= (uint32_t)atomicAdd(&hist[row[c] >> BK_SHIFT], 1) << 20;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) rank_by_ballot(hist, c);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane < nb) {
+                const int n = hist[lane];
+                if (n) my_base = atomicAdd(&cursor[lv.b0 + lane], n);  // the wave's span in bucket `lane`
+            }
+        } else {
+            // ================= hashed level ==================================================================
+            ++hk;
+            // ---- B: rank every record inside its bucket (item-local)
+            if (nb <= 32 && !lv.compact) {  // wave-uniform: every lane emits into one or two buckets
+#pragma unroll
+                for (int c = 0; c < 8; ++c) rank_by_ballot(s_cnt[cur], c);
+            } else if (emit) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) row[c] |= (uint32_t)atomicAdd(&s_cnt[cur][row[c] >> BK_SHIFT], 1) << 20;
+            }
+            BIN_STAMP(2);
+            __syncthreads();  // barrier 1: the item's bucket counts are final
+            BIN_STAMP(3);
+            // (the other set was last read before barrier 3 of the previous hashed item: clear it for the next one)
+            for (int i = tid; i < BK_MAX_PER_LEVEL; i += BIN_T) s_cnt[cur ^ 1][i] = 0;
+            if (tid == 0) s_ovf[cur ^ 1] = 0;
+            // ---- C: ONE returning global atomic per touched bucket reserves its span
+            if (tid < nb) {
+                const int c = s_cnt[cur][tid];
+                if (c) my_base = atomicAdd(&cursor[lv.b0 + tid], c);
             }
         }
+        // the next item's inputs follow the reservations into the memory queue; both are consumed after the arithmetic
+        if (have_next) fetch(l_next, tile_next);
+        values();
         BIN_STAMP(4);
+        if (lv.direct) {
+            int *wbase = s_wave[wave];
+            if (lane < BIN_DIRECT_NB) wbase[lane] = my_base;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (emit) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int b = (int)((row[c] & ROW_MASK) >> BK_SHIFT);
+                    const int pos = wbase[b] + (int)(row[c] >> 20);
+                    if (pos < cap) lrec[(int64_t)b * cap + pos] = rec[c];
+                    else spill(lv.off, rec[c], b);
+                }
+            }
+            BIN_STAMP(8);
+            l = l_next; tile = tile_next; have = have_next;
+            continue;
+        }
         // ---- E: exclusive scan of the bucket counts.  EVERY wave computes it (4 buckets per lane, one DPP scan) and
         // writes the same offsets: a wave reads s_off only after its own writes, so no barrier and no idle waves
         int total;
@@ -636,68 +759,58 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const TG *__restrict_
             total = __builtin_amdgcn_readlane(inc, 63);
         }
         // ---- F: group the records by bucket in LDS
-#pragma unroll
-        for (int u = 0; u < SPT; ++u) {
+        if (emit) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                if ((emit[u] >> c) & 1u) {
-                    const int b = (int)(row[u][c] >> BK_SHIFT);
-                    const int slot = s_off[b] + rank[u][c];
-                    s_stage[slot] = REC::make(row[u][c], v0[u][c], v1[u][c]);
-                    if (REC::kPacked) s_bkt[slot] = (uint8_t)b;
-                }
+                const int b = (int)((row[c] & ROW_MASK) >> BK_SHIFT);
+                const int slot = s_off[b] + (int)(row[c] >> 20);
+                s_stage[slot] = rec[c];
+                if (REC::kPacked) s_bkt[slot] = (uint8_t)b;
             }
         }
         BIN_STAMP(5);
-#pragma unroll
-        for (int kk = 0; kk < (BK_MAX_PER_LEVEL + BIN_T - 1) / BIN_T; ++kk) {  // waits for the reservations
-            const int i = tid + kk * BIN_T;
-            if (i < nb) {
-                s_base[i] = my_base[kk];
-                s_dest[i] = i * cap + ((dbg & 2) ? (my_base[kk] & 63) : my_base[kk]) - s_off[i];
-                if (!(dbg & 2) && my_base[kk] + s_cnt[cur][i] > cap) s_ovf[cur] = 1;
-            }
+        if (tid < nb) {  // waits for the reservations
+            s_base[tid] = my_base;
+            s_dest[tid] = tid * cap + my_base - s_off[tid];
+            if (my_base + s_cnt[cur][tid] > cap) s_ovf[cur] = 1;
         }
         BIN_STAMP(6);
-        __syncthreads();  // barrier 3: stage, destinations, tile maximum complete
+        __syncthreads();  // barrier 3: stage and destinations complete
         BIN_STAMP(7);
-        if (tid == BIN_T - 1 && s_max[cur] != 0u) atomicMax(&gmax[l], s_max[cur]);  // one value per LEVEL
         // the prefetched inputs are pinned in registers here, so that the next item starts without waiting for the
         // stores below to be acknowledged (one in-order memory counter covers loads and stores)
-#pragma unroll
-        for (int u = 0; u < SPT; ++u)
-            asm volatile("" : "+v"(n_gg[u].x), "+v"(n_gg[u].y), "+v"(n_x[u]), "+v"(n_y[u]), "+v"(n_z[u]));
+        asm volatile("" : "+v"(n_g.x), "+v"(n_g.y), "+v"(n_x), "+v"(n_y), "+v"(n_z));
         // ---- G: copy out: consecutive lanes -> consecutive slots of (mostly) the same bucket: coalesced
-        auto bucket_of = [&](const REC &r, int i) -> int {
+        auto bucket_of = [&](const REC &r, int i) __attribute__((always_inline)) -> int {
             if constexpr (REC::kPacked) return (int)s_bkt[i];
             else return (int)(r.row >> BK_SHIFT);
         };
-        if (!s_ovf[cur]) {  // uniform fast path: every record of the tile has a slot
+        if (!s_ovf[cur]) {  // uniform fast path: every record of the item has a slot
+            char *lbytes = reinterpret_cast<char *>(lrec);  // (a level's region is < 4 GiB: 32-bit byte offsets)
             for (int i = tid; i < total; i += BIN_T) {
                 const REC r = s_stage[i];
-                lrec[s_dest[bucket_of(r, i)] + i] = r;
+                const uint32_t at = (uint32_t)(s_dest[bucket_of(r, i)] + i) * (uint32_t)sizeof(REC);
+                *reinterpret_cast<REC *>(lbytes + at) = r;
             }
         } else {
             for (int i = tid; i < total; i += BIN_T) {
                 const REC r = s_stage[i];
                 const int b = bucket_of(r, i);
                 const int slot = s_base[b] + (i - s_off[b]);
-                if (slot < cap) {
-                    lrec[(int64_t)b * cap + slot] = r;
-                } else {  // bucket region full: finish this record with global atomics
-                    const int64_t full_row = ((int64_t)b << BK_SHIFT) | r.row_in_bucket();
-                    atomicAdd(lt + full_row * 2, r.a());
-                    atomicAdd(lt + full_row * 2 + 1, r.b());
-                }
+                if (slot < cap) lrec[(int64_t)b * cap + slot] = r;
+                else spill(lv.off, r, b);   // bucket region full: finish this record with global atomics
             }
         }
         BIN_STAMP(8);
-        // (the next item rewrites s_off / s_stage / s_dest only after ITS barrier 1, which every wave reaches after
-        // finishing the copy-out above)
+        // (the next hashed item rewrites s_off / s_stage / s_dest only after ITS barrier 1, which every wave reaches
+        // after finishing the copy-out above)
         l = l_next; tile = tile_next; have = have_next;
     }
+    __syncthreads();
+    if (tid < L && s_lmax[tid] != 0u) atomicMax(&gmax[tid], s_lmax[tid]);  // one value per LEVEL and workgroup
     BIN_STAMP_FLUSH();
 }
+#undef LNERF_BIN_LEVEL
 
 // Pass 2.  LDS float atomics run at ~0.5 lane/clk on gfx950 while integer LDS atomics run at the
 // plain-store rate (measured: profiles/README.md, "reduce_dbg"), so the tile accumulates in 64-bit
@@ -954,47 +1067,16 @@ static int g_compact_max_res = 512;
 static int g_gather_pairs = 1;
 // gather: levels with resolution <= this fetch a cell's vertices once per run of lanes in that cell (0 = off)
 static int g_gather_dedup_res = 512;
-// workgroup -> (level, tile) map of the binning pass: 0 = level on blockIdx.y, 1 = XCD-aware, 2 = persistent
-// workgroups striding over the (tile, level) list with the level rotated per round
-static int g_bin_map = 2;
-// persistent workgroups of map 2 (3 per CU fit the 52 KiB LDS stage: 768 on 256 CUs)
-static int g_bin_wgs = 768;
-// samples per thread of the binning pass with the 8-byte records (1 or 2)
-static int g_bin_spt = 1;
-// samples per binning tile (256 or 512)
-static int g_bin_tile = 512;
+// persistent workgroups of the binning pass per CU (3 fit its 44 KiB of LDS with the 8-byte records)
+static int g_bin_per_cu = 3;
+// persistent workgroups of the binning pass (0 = 256 CUs x g_bin_per_cu); rounded down to a multiple of the level count
+static int g_bin_wgs = 0;
 // drop contributions that are exactly zero (samples behind a ray's termination point)
 static int g_skip_zero = 1;
-// first level of group A (fine levels reduced on a side stream next to the binning of the others); 0 = no split
-static int g_scatter_split = 0;  // measured: 0.344 ms split at 8/11/13 vs 0.313 ms single stream -> off by default
-// TIMING-ONLY experiment switch of the binning pass (non-zero values give wrong sums)
-static int g_bin_dbg = 0;
 // threads per workgroup of the reduce pass (512 or 1024; two 64 KiB workgroups fit a CU either way)
 static int g_reduce_threads = 1024;
 
 // device header of the workspace: bucket cursors (int32) followed by the per-level maxima (uint32)
-// side stream + events of the split launch, one set per device, created on the first eager call (never while
-// the caller's stream is being captured)
-struct ScatterAux {
-    hipStream_t side;
-    hipEvent_t fork, join;
-};
-static ScatterAux *scatter_aux(hipStream_t s) {
-    static ScatterAux aux[16];
-    static bool have[16] = {false};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    if (!have[dev]) {
-        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
-        if (hipStreamCreateWithFlags(&aux[dev].side, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&aux[dev].fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&aux[dev].join, hipEventDisableTiming) != hipSuccess) return nullptr;
-        have[dev] = true;
-    }
-    return &aux[dev];
-}
-
 static size_t cursor_bytes(int n_buckets) {
     return ((size_t)(n_buckets + LNERF_MAX_LEVELS) * sizeof(int32_t) + 4095) / 4096 * 4096;
 }
@@ -1023,6 +1105,7 @@ static int fill_bucket_meta(const GridMeta &meta, int64_t m_host, BucketMeta &bm
         if (cap > 8 * m_host) cap = 8 * m_host;
         if (cap < 64) cap = 64;
         if (cap > 0x7FFFFFFF) return -1;
+        if ((int64_t)nb * cap * (int64_t)sizeof(Rec12) >= (1ll << 32)) return -1;  // (the copy-out uses 32-bit byte offsets)
         int slices = (int)((per_bucket + 65535) / 65536);    // <= ~64 Ki records per pass-2 workgroup
         if (slices < 1) slices = 1;
         if (slices > 64) slices = 64;
@@ -1130,19 +1213,14 @@ int lnerf_set_tuning(const char *key, int value) {
         g_compact_max_res = value;
         return LNERF_OK;
     }
-    if (strcmp(key, "scatter_bin_map") == 0) {
-        LNERF_REQUIRE(value >= 0 && value <= 2, "set_tuning: scatter_bin_map must be 0, 1 or 2");
-        g_bin_map = value;
-        return LNERF_OK;
-    }
-    if (strcmp(key, "scatter_bin_spt") == 0) {
-        LNERF_REQUIRE(value == 1 || value == 2, "set_tuning: scatter_bin_spt must be 1 or 2");
-        g_bin_spt = value;
-        return LNERF_OK;
-    }
     if (strcmp(key, "scatter_bin_wgs") == 0) {
-        LNERF_REQUIRE(value >= 1 && value <= 65535, "set_tuning: scatter_bin_wgs out of range");
+        LNERF_REQUIRE(value >= 0 && value <= 65535, "set_tuning: scatter_bin_wgs out of range");
         g_bin_wgs = value;
+        return LNERF_OK;
+    }
+    if (strcmp(key, "scatter_bin_per_cu") == 0) {
+        LNERF_REQUIRE(value >= 1 && value <= 4, "set_tuning: scatter_bin_per_cu must be in 1 .. 4");
+        g_bin_per_cu = value;
         return LNERF_OK;
     }
     if (strcmp(key, "gather_dedup_max_res") == 0) {
@@ -1159,31 +1237,13 @@ int lnerf_set_tuning(const char *key, int value) {
         g_mlp_fwd_blocks = value;
         return LNERF_OK;
     }
-    if (strcmp(key, "scatter_split_level") == 0) {
-        LNERF_REQUIRE(value >= 0 && value < LNERF_MAX_LEVELS, "set_tuning: scatter_split_level out of range");
-        g_scatter_split = value;
-        return LNERF_OK;
-    }
     if (strcmp(key, "scatter_skip_zero") == 0) {
         g_skip_zero = value ? 1 : 0;
-        return LNERF_OK;
-    }
-    if (strcmp(key, "scatter_bin_tile") == 0) {
-        LNERF_REQUIRE(value == 256 || value == 512 || value == 1024, "set_tuning: scatter_bin_tile must be 256, 512 or 1024");
-        g_bin_tile = value;
         return LNERF_OK;
     }
     if (strcmp(key, "scatter_reduce_threads") == 0) {
         LNERF_REQUIRE(value == 512 || value == 1024, "set_tuning: scatter_reduce_threads must be 512 or 1024");
         g_reduce_threads = value;
-        return LNERF_OK;
-    }
-    if (strcmp(key, "scatter_bin_debug") == 0) {
-        // non-zero values produce WRONG sums (timing-only experiments of tools/microbench.py): refuse them unless
-        // the process opted in
-        LNERF_REQUIRE(value == 0 || getenv("LNERF_TIMING_EXPERIMENTS") != nullptr,
-                      "set_tuning: scatter_bin_debug is a timing-only switch (set LNERF_TIMING_EXPERIMENTS=1 to use it)");
-        g_bin_dbg = value;
         return LNERF_OK;
     }
     set_error("set_tuning: unknown key '%s'", key);
@@ -1223,6 +1283,7 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
     int rc = fill_meta("grid_encode_backward", meta, num_levels, level_dim, offsets_host, scales_host, res_host);
     if (rc) return rc;
     LNERF_REQUIRE(m_host >= 0 && level_stride >= m_host, "grid_encode_backward: need 0 <= m_host <= level_stride");
+    LNERF_REQUIRE(m_host < (1ll << 30), "grid_encode_backward: m_host must be below 2^30 samples");
     LNERF_REQUIRE(bound > 0.f, "grid_encode_backward: bound must be > 0");
     LNERF_REQUIRE(variant >= 0 && variant <= 3, "grid_encode_backward: unknown variant %d", variant);
     LNERF_REQUIRE(dfeat_dtype == LNERF_F32, "grid_encode_backward: dfeat must be f32");
@@ -1258,44 +1319,24 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
         set_error("grid_encode_backward: hipMemsetAsync failed");
         return LNERF_ERR_HIP;
     }
-    // Optional (tuning "scatter_split_level", off by default): two level groups, A = fine levels, B = the rest,
-    // with reduce(A) on a second stream next to bin(B).  Measured slower than the single-stream order
-    // (profiles/README.md), kept as a switch for future tile shapes.
-    int split = g_scatter_split < 0 ? 0 : g_scatter_split;
-    if (split == 0 || split >= num_levels || g_bin_map != 0) split = 0;  // 0: one group
-    ScatterAux *aux = split ? scatter_aux(s) : nullptr;
-    if (!aux) split = 0;
-    const int BIN_T = packed ? 512 : g_bin_tile;
-    const int SPT = (packed && g_bin_spt == 2) ? 2 : 1;  // samples per thread (two only with the 8-byte records: LDS)
-    auto launch_bin = [&](int l0, int l1) {
-        dim3 g;
-        if (g_bin_map == 2) {  // persistent: G workgroups, G a multiple of the level count
-            const int wgs = SPT == 2 ? (g_bin_wgs * 2) / 3 : g_bin_wgs;  // 2 instead of 3 workgroups per CU
-            int64_t G = (int64_t)(wgs / num_levels) * num_levels;
-            const int64_t items = div_up(m_host, (int64_t)BIN_T * SPT) * num_levels;
-            if (G > items) G = items;
-            if (G < num_levels) G = num_levels;
-            g = dim3((unsigned)G, 1, 1);
-        } else {
-            launch_dims(g_bin_map, g_bin_map == 0 ? (l1 - l0) : num_levels, div_up(m_host * 256, (int64_t)BIN_T * SPT), g);
-        }
-#define LAUNCH_BIN(T, REC, S)                                                                                          \
-    hipLaunchKernelGGL((k_scatter_bin<float, T, REC, S>), g, dim3(T), 0, s, xyzs, bound, (const float *)dfeat, meta, bm, \
-                       m_host, m_dev, level_stride, cursor, gmax, (REC *)rec, dtable, g_bin_map,                       \
-                       g_skip_zero, l0, g_bin_dbg)
-        if (packed && SPT == 2) LAUNCH_BIN(512, Rec8, 2);
-        else if (packed) LAUNCH_BIN(512, Rec8, 1);
-        else if (BIN_T == 256) LAUNCH_BIN(256, Rec12, 1);
-        else if (BIN_T == 1024) LAUNCH_BIN(1024, Rec12, 1);
-        else LAUNCH_BIN(512, Rec12, 1);
-#undef LAUNCH_BIN
+    auto launch_bin = [&]() {
+        // persistent: G workgroups, G a multiple of the level count (item k of a workgroup: next tile group, next level)
+        const int wgs = g_bin_wgs > 0 ? g_bin_wgs : 256 * g_bin_per_cu;
+        int64_t G = (int64_t)(wgs / num_levels) * num_levels;
+        const int64_t items = div_up(m_host, (int64_t)BIN_T) * num_levels;
+        if (G > items) G = items;
+        if (G < num_levels) G = num_levels;
+        const dim3 g((unsigned)G, 1, 1);
+        if (packed)
+            hipLaunchKernelGGL((k_scatter_bin<Rec8>), g, dim3(BIN_T), 0, s, xyzs, bound, (const float *)dfeat, meta, bm,
+                               m_host, m_dev, level_stride, cursor, gmax, (Rec8 *)rec, dtable, g_skip_zero);
+        else
+            hipLaunchKernelGGL((k_scatter_bin<Rec12>), g, dim3(BIN_T), 0, s, xyzs, bound, (const float *)dfeat, meta, bm,
+                               m_host, m_dev, level_stride, cursor, gmax, (Rec12 *)rec, dtable, g_skip_zero);
     };
     FusedUpdate fu0;
     memset(&fu0, 0, sizeof(fu0));
-    if (fu) {
-        fu0 = *fu;
-        split = 0;
-    }
+    if (fu) fu0 = *fu;
     auto launch_reduce = [&](hipStream_t st, int l0, int l1) {
         const int w0 = bm.wgstart[l0], w1 = bm.wgstart[l1];
         if (w1 <= w0) return;
@@ -1318,28 +1359,11 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
         else
             hipLaunchKernelGGL(k_scatter_finish<false>, g, dim3(256), 0, s, meta, bm, cursor, gmax, partials, dtable, fu0);
     };
-    if (!split) {
-        launch_bin(0, num_levels);
-        LNERF_CHECK_LAUNCH("grid_encode_backward(bin)");
-        launch_reduce(s, 0, num_levels);
-        LNERF_CHECK_LAUNCH("grid_encode_backward(reduce)");
-        launch_finish();
-    } else {
-        launch_bin(split, num_levels);                       // A: fine levels
-        LNERF_CHECK_LAUNCH("grid_encode_backward(bin A)");
-        bool ok = hipEventRecord(aux->fork, s) == hipSuccess && hipStreamWaitEvent(aux->side, aux->fork, 0) == hipSuccess;
-        launch_reduce(ok ? aux->side : s, split, num_levels);
-        LNERF_CHECK_LAUNCH("grid_encode_backward(reduce A)");
-        launch_bin(0, split);                                // B next to reduce(A)
-        LNERF_CHECK_LAUNCH("grid_encode_backward(bin B)");
-        launch_reduce(s, 0, split);
-        if (ok && !(hipEventRecord(aux->join, aux->side) == hipSuccess &&
-                    hipStreamWaitEvent(s, aux->join, 0) == hipSuccess)) {
-            set_error("grid_encode_backward: could not join the side stream");
-            return LNERF_ERR_HIP;
-        }
-        launch_finish();
-    }
+    launch_bin();
+    LNERF_CHECK_LAUNCH("grid_encode_backward(bin)");
+    launch_reduce(s, 0, num_levels);
+    LNERF_CHECK_LAUNCH("grid_encode_backward(reduce)");
+    launch_finish();
     LNERF_CHECK_LAUNCH("grid_encode_backward(finish)");
     return LNERF_OK;
 }

@@ -60,9 +60,9 @@ class RenderConfig:
     # jitter of the march start (perturb=True): seed of the in-kernel counter-based generator
     # (lnerf_march_rays_train `noise_counter`: graph-capturable, no host RNG state); None = torch.rand(N) per call
     noise_seed: Optional[int] = 0x5EED
-    # sample buffer capacity per view.  0 = automatic: rays * min(max_steps, 256) until the renderer has seen
-    # `update_extra_interval` training marches, then 2 x the running mean sample count (rounded up to 64 Ki; rays
-    # that do not fit are dropped by the march's scan pass and counted, never written out of bounds)
+    # sample buffer capacity per view.  0 = automatic: rays * min(max_steps, 256) until the first occupancy refresh
+    # has read the march counters back, then 1.5 x the largest sample count seen between refreshes (rounded up to
+    # 64 Ki; rays that do not fit are dropped by the march's scan pass and counted, never written out of bounds)
     max_samples: int = 0
 
     def precision(self, name: str) -> str:

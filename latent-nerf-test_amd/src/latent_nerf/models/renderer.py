@@ -62,6 +62,7 @@ class NeRFRenderer(nn.Module):
         self._march = None
         self._march_key = None
         self._budget = None       # ((N, max_steps), capacity) derived from observed marches
+        self._m_peak = None       # device int32 [1]: largest M since the last budget update
         self.mean_count = 0
         self._noise_counter = None
         self._occ_scratch = None
@@ -113,23 +114,23 @@ class NeRFRenderer(nn.Module):
 
     def update_sample_budget(self):
         """Called where the training loop synchronises anyway (the occupancy refresh, every `update_extra_interval`
-        steps): reads the last march's device counters [M, live rays, dropped rays] back ONCE and re-derives the
-        capacity for marches of that shape: 2 x M rounded up to 128 Ki samples, changed only when the march came
-        within 2/3 of the current capacity (or dropped rays: back to the worst case) or fell below a quarter of
-        it.  The upstream renderer sizes its buffers from a running `mean_count` the same way, but reads the
-        counter back every step."""
+        steps): reads the march statistics back ONCE -- the largest sample count M of any training march since the
+        previous call (kept on the device by run_cuda) and the last march's dropped-ray count -- and re-derives the
+        capacity for marches of that shape: 1.5 x M rounded up to 64 Ki samples.  It changes only when the peak came
+        within 80 % of the current capacity (or rays were dropped: back to the worst case) or fell below 40 % of it.
+        The upstream renderer sizes its buffers from a running `mean_count` the same way, but reads the counter
+        back every step."""
         m = self._march
-        if m is None or self.cfg.max_samples > 0:
+        if m is None or self._m_peak is None or self.cfg.max_samples > 0:
             return None
-        M, _, dropped = [int(v) for v in m.counter[:3].tolist()]
-        N = m.rays.shape[0]
-        key = self._march_key
-        cap = m.capacity
-        self.mean_count = M if self.mean_count == 0 else int(0.9 * self.mean_count + 0.1 * M)
-        want = -(-max(2 * M, 1) // 131072) * 131072
+        peak, dropped = int(self._m_peak.item()), int(m.counter[2].item())
+        self._m_peak.zero_()
+        key, cap = self._march_key, m.capacity
+        self.mean_count = peak if self.mean_count == 0 else int(0.9 * self.mean_count + 0.1 * peak)
+        want = -(-max(int(1.5 * peak), 1) // 65536) * 65536
         if dropped > 0:
             self._budget = None                      # back to the worst case for the next marches
-        elif 3 * M > 2 * cap or 4 * M < cap or self._budget is None or self._budget[0] != key:
+        elif 5 * peak > 4 * cap or 5 * peak < 2 * cap or self._budget is None or self._budget[0] != key:
             self._budget = (key, want)
         return self._budget
 
@@ -166,7 +167,11 @@ class NeRFRenderer(nn.Module):
                                         max_steps=max_steps, capacity=cap, out=self._march,
                                         noises=kwargs.get("noises"), noise_state=self._noise_state(rays_o.device))
             self._march = march
-            self._march_key = (N, int(max_steps))
+            if self._march_key != (N, int(max_steps)) or self._m_peak is None:
+                self._march_key = (N, int(max_steps))
+                self._m_peak = torch.zeros(1, device=rays_o.device, dtype=torch.int32)
+            if self.cfg.max_samples <= 0:   # running peak of M, on the device (one tiny launch, no host sync)
+                torch.maximum(self._m_peak, march.counter[0:1], out=self._m_peak)
             self.local_step += 1
             m_dev = march.counter[0:1]
             sigmas, rgbs = self.field(march.xyzs, cap, m_dev, cap)
