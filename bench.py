@@ -16,8 +16,13 @@ phi = 45 deg * rank, fovy 55 deg, upstream gradient g = randn * sqrt(a)(1-a), a 
 
 Prints ONE JSON line (rank 0).  `roofline` is the hash-grid gather (the kernel the metric names):
 algorithmic bytes (1164 B/sample f32 table, 588 B/sample bf16) x samples / the
-kernel's duration measured with HIP events inside the timed steps.  `cpu_baseline` is the oracle
-(oracle/nerf_oracle.py, pure PyTorch fp32) doing the same step on the host cores.
+kernel's duration measured with HIP events inside the timed steps; `roofline.traffic` and `mfma.busy_frac` come
+from the committed rocprofv3 --pmc passes (profiles/pmc_latest.json) and are null unless that file was collected on
+THIS build of the library (build tags compared).  `mfma` prices the MLP kernels (the only MFMA users) against the
+dense bf16 peak from their live HIP-event times.  `occ_refresh` times the amortised occupancy-grid refresh (H10) that
+the trainer runs every 16 steps (outside the step, after the timed region, state restored).  `f32` is the same step
+with the exact-f32 parity configuration.  `cpu_baseline` is the oracle (oracle/nerf_oracle.py, pure PyTorch fp32)
+doing the same step on the host cores.
 """
 import argparse
 import json
@@ -34,6 +39,11 @@ for _p in (ROOT, os.path.join(ROOT, "latent-nerf-test_amd")):
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense peaks of the same guide (bf16 MFMA; f32-input MFMA)
+MLP_FLOP_PER_SAMPLE = (12928, 25856)  # forward, backward (32 -> 64 -> 64 -> 5)
+# sample-buffer capacity of the bench: 1.5 x the ~430 k samples of its view, rounded up to 64 Ki -- what the renderer's
+# own budget (NeRFRenderer.update_sample_budget) settles on; the worst case 4096 rays x 256 would be 1 Mi
+BENCH_CAPACITY = 10 * 65536
 H = W = 64
 GRID = 128
 FOVY = 55.0
@@ -58,7 +68,8 @@ def parse():
                     help="dtype of the hash table the gather reads (auto: follows --precision, the SURVEY §8(b) dtype policy; "
                          "bf16 = half-size shadow refreshed by the fused Adam pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--cpu-frames", type=int, default=5, help="timed CPU frames (~2 s each on 16 cores; + 1 warm-up)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed companions (f32 step, occupancy refresh)")
     ap.add_argument("--gather-variant", type=int, default=0)
     ap.add_argument("--fuse-table-update", default="auto", choices=["auto", "0", "1"],
                     help="hash-table Adam step applied inside the scatter's reduce pass (single GPU only; auto = on at N=1)")
@@ -70,7 +81,8 @@ def parse():
     ap.add_argument("--breakdown", action="store_true", help="extra untimed pass: per-kernel event timings")
     ap.add_argument("--graph", type=int, default=1,
                     help="1: replay the captured hipGraph of the whole step (every --probe-every-th timed step still runs "
-                         "eagerly so that the gather can be bracketed by HIP events); 0: eager launches only")
+                         "eagerly so that the gather can be bracketed by HIP events); a capture failure is FATAL; "
+                         "0: eager launches only")
     ap.add_argument("--probe-every", type=int, default=8)
     ap.add_argument("--grad-transport", default="auto", choices=["auto", "f32", "bf16"],
                     help="dtype of the table-gradient all-reduce at N > 1 (auto: follows --precision)")
@@ -85,7 +97,8 @@ def build(dev, precision, variant, rank, table="f32", jitter_rng="kernel"):
 
     torch.manual_seed(0)
     cfg = RenderConfig(grid_size=GRID, train_h=H, train_w=W, mlp_precision=precision, table_dtype=table,
-                       gather_variant=variant, noise_seed=(0x5EED + rank) if jitter_rng == "kernel" else None)
+                       gather_variant=variant, noise_seed=(0x5EED + rank) if jitter_rng == "kernel" else None,
+                       max_samples=BENCH_CAPACITY)
     net = NeRFNetwork(cfg)
     net.encoder.embeddings.data.normal_(0, 0.1)
     net = net.to(dev).train()
@@ -223,6 +236,66 @@ def cpu_baseline(frames):
                       "oracle/nerf_oracle.py fp32 PyTorch, %d threads" % (len(times), M, cores)}
 
 
+def load_pmc(build_tag):
+    """profiles/pmc_latest.json (tools/run_pmc_all.sh) if it was collected on this very build of the library."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None
+    if d.get("build") != build_tag:
+        log("profiles/pmc_latest.json was collected on build %r, this is %r: counter-derived fields are null"
+            % (d.get("build"), build_tag))
+        return None
+    return d
+
+
+def time_occ_refresh(net, rounds=4):
+    """One steady-state occupancy refresh (`update_extra_state()`: G^3/4 random + G^3/4 occupied cells through the
+    gather + MLP, decayed max, mean, bitfield) timed with HIP events; grid, bitfield and counters are restored."""
+    keep = (net.density_grid.clone(), net.density_bitfield.clone(), net.mean_density_dev.clone(), net.iter_density)
+    net.iter_density = 16            # past the 16 full-grid refreshes of a fresh model: the steady-state form
+    budget = net._budget
+    ts = []
+    for i in range(rounds + 1):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        net.update_extra_state()
+        b.record()
+        torch.cuda.synchronize()
+        if i:
+            ts.append(a.elapsed_time(b))
+        net.density_grid.copy_(keep[0]); net.density_bitfield.copy_(keep[1]); net.mean_density_dev.copy_(keep[2])
+    net.iter_density = keep[3]
+    net._budget = budget
+    return sorted(ts)[len(ts) // 2]
+
+
+def companion_f32(dev, rank, steps=40, warmup=6):
+    """The exact-f32 parity configuration (f32 table, f32 features, exact-f32 MFMA MLP, 12-byte scatter records) through
+    the same captured step: frames/s beside the headline (bf16) number."""
+    from src.latent_nerf.training.graph_step import GraphedTrainStep
+    from src.latent_nerf.training.optimizer import FusedAdam
+    net, pose, intr, bg, grad = build(dev, "f32", 0, rank, "f32")
+    opt = FusedAdam(net.get_params(LR), betas=(0.9, 0.99), eps=1e-15, encoder=net.encoder, capturable=True,
+                    fuse_table_update=True)
+    step, fwd_bwd, opt_step, sync = make_step(net, pose, intr, bg, grad, opt, 1)
+    gstep = GraphedTrainStep(fwd_bwd, opt_step, list(net.parameters()), sync=sync, world=1, warmup=3,
+                             stream=torch.cuda.current_stream())
+    for _ in range(warmup):
+        gstep()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = gstep()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "latent-frames/sec", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+            "samples_per_view": int(out["counter"][0].item()),
+            "what": "--precision f32 (f32 table + features, exact-f32 MFMA MLP, exact 12-byte scatter records): the "
+                    "configuration the fp32-tolerance parity tests run"}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -276,20 +349,16 @@ def main():
     gstep = None
     if args.graph:
         from src.latent_nerf.training.graph_step import GraphedTrainStep
-        try:
-            gstep = GraphedTrainStep(fwd_bwd, opt_step, list(net.parameters()), sync=sync, world=world, warmup=3,
-                                     stream=main_stream)
-            launch = "hipgraph"
-        except Exception as e:  # launch mechanism only: the kernels and the maths are identical either way
-            log("hipGraph capture failed (%s: %s); running eager launches" % (type(e).__name__, e))
-            torch.cuda.synchronize()
-            gstep = None
+        # (a capture failure raises: the line must not silently describe eager launches; use --graph 0 for those)
+        gstep = GraphedTrainStep(fwd_bwd, opt_step, list(net.parameters()), sync=sync, world=world, warmup=3,
+                                 stream=main_stream)
+        launch = "hipgraph"
     emb0 = net.encoder.embeddings.detach().clone()
     for i in range(args.warmup):
         (gstep if (gstep is not None and i % 2) else step)()
     torch.cuda.synchronize()
     log("warm-up done (%s)" % launch)
-    timer = KernelTimer(["lnerf_grid_encode_forward", scatter_call])
+    timer = KernelTimer(["lnerf_grid_encode_forward", scatter_call, "lnerf_mlp_forward", "lnerf_mlp_backward"])
     barrier()
     t0 = time.perf_counter()
     n_probe = 0
@@ -309,6 +378,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     M = int(out["counter"][0].item())
+    if int(out["counter"][2].item()) != 0:
+        raise SystemExit("bench: %d rays did not fit the sample capacity %d" % (int(out["counter"][2].item()), BENCH_CAPACITY))
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -354,14 +425,22 @@ def main():
         s_ms = timer.mean_ms(scatter_call)
         achieved = M * bytes_per_sample / (g_ms * 1e-3) / 1e9
         scatter = M * 1164 / (s_ms * 1e-3) / 1e9 if s_ms > 0 else None
+        build_tag = B.get_lib().lnerf_build_info().decode()
+        pmc = load_pmc(build_tag)
         traffic = None   # HBM-side bytes per launch of the gather from the committed PMC passes (profiles/)
-        pmc = os.path.join(ROOT, "profiles", "pmc_gather_latest.json")
-        if os.path.exists(pmc):
-            try:
-                key = "%s_table_%s_out" % (table, args.precision)
-                traffic = json.load(open(pmc))["variants"][key].get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        if pmc:
+            traffic = pmc.get("gather", {}).get("%s_table_%s_out" % (table, args.precision), {}).get("hbm_bytes_per_launch")
+        # the MLP kernels (H7) are the only MFMA users: FLOP / live kernel time against the dense peak of the MFMA type
+        f_ms, b_ms = timer.mean_ms("lnerf_mlp_forward"), timer.mean_ms("lnerf_mlp_backward")
+        peak = MFMA_PEAK_TFLOPS[args.precision]
+        mfma = {"kernels": "k_mlp_forward_%s / k_mlp_backward_%s (H7, 32 -> 64 -> 64 -> 5)" % ((args.precision,) * 2),
+                "fwd_ms": f_ms, "bwd_ms": b_ms,
+                "fwd_tflops": M * MLP_FLOP_PER_SAMPLE[0] / (f_ms * 1e-3) / 1e12,
+                "bwd_tflops": M * MLP_FLOP_PER_SAMPLE[1] / (b_ms * 1e-3) / 1e12,
+                "peak_tflops": peak, "busy_frac": None}
+        mfma["frac_of_peak"] = {"fwd": mfma["fwd_tflops"] / peak, "bwd": mfma["bwd_tflops"] / peak}
+        if pmc and args.precision == "bf16":   # SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), per kernel
+            mfma["busy_frac"] = {k: pmc.get("mfma", {}).get(k, {}).get("busy_frac") for k in ("fwd", "bwd")}
         res = {
             "metric": "latent-frames/sec (64x64x4, 128^3 grid), render forward+backward",
             "value": world * args.steps / elapsed,
@@ -379,11 +458,13 @@ def main():
             "data": "synthetic",
             "config": {"workload": "configs[1]: unconstrained latent-NeRF 64x64x4, 128^3 occupancy grid, hash grid "
                                    "L=16 F=2 T=2^19, 1 view/GPU/step, fwd+bwd+grad all-reduce+Adam",
-                       "rays_per_view": H * W, "samples_per_view": M, "views_per_step": world,
+                       "rays_per_view": H * W, "samples_per_view": M, "sample_capacity": BENCH_CAPACITY,
+                       "views_per_step": world,
                        "parallelism": "dp%d (1 view per GPU, RCCL all-reduce of gradients, %s on the wire)" % (world, tr)},
             "roofline": {"kernel": "k_grid_forward (hash-grid gather, H5)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "bytes_per_sample": bytes_per_sample, "samples_per_launch": M, "kernel_ms": g_ms},
+            "mfma": mfma,
             "scatter": {"kernel": scatter_call.replace("lnerf_", "") + " (H6: two-pass bucketed scatter"
                                   + (" + fused Adam step of the table)" if fuse else
                                      ", gradient written in the bf16 wire format)" if scatter_call.endswith("bf16") else ")"),
@@ -391,6 +472,14 @@ def main():
         }
         if breakdown:
             res["kernel_ms_per_step"] = breakdown
+        res["build"] = build_tag
+        if not args.no_extras and world == 1:
+            ms = time_occ_refresh(net)
+            iv = net.cfg.update_extra_interval
+            res["occ_refresh"] = {"ms_per_refresh": ms, "interval_steps": iv, "ms_per_step_amortised": ms / iv,
+                                  "what": "NeRFRenderer.update_extra_state() (H10), steady-state form, timed after the "
+                                          "timed region; the trainer runs it every %d steps, the bench step excludes it" % iv}
+            res["f32"] = companion_f32(dev, rank)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.cpu_frames)
         print(json.dumps(res), flush=True)

@@ -22,7 +22,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=20)
     ap.add_argument("--check", action="store_true")
-    ap.add_argument("--configs", default="3:0,2:0")   # per_cu:wgs pairs
+    ap.add_argument("--configs", default="3:0")   # per_cu:wgs pairs
+    ap.add_argument("--tune", default="")            # extra variants: "key=val+key=val,key=val" (comma separates variants)
     args = ap.parse_args()
     import bench
     from src.latent_nerf.models import encoding as E
@@ -84,6 +85,20 @@ def main():
             B.call("lnerf_set_tuning", b"scatter_bin_wgs", wgs)
             scatter(3)
         fns["v3_percu%d_wgs%d" % (per_cu, wgs)] = f
+    defaults = {"scatter_compact_max_res": 512, "scatter_skip_zero": 1, "scatter_reduce_threads": 1024}
+    for var in [v for v in args.tune.split(",") if v]:
+        kv = dict((k, int(x)) for k, x in (t.split("=") for t in var.split("+")))
+
+        def f(kv=kv):
+            B.call("lnerf_set_tuning", b"scatter_bin_per_cu", 3)
+            B.call("lnerf_set_tuning", b"scatter_bin_wgs", 0)
+            for k, x in kv.items():
+                B.call("lnerf_set_tuning", k.encode(), x)
+            scatter(3)
+            for k in kv:
+                if k in defaults:
+                    B.call("lnerf_set_tuning", k.encode(), defaults[k])
+        fns["v3_" + var] = f
     for _ in range(3):
         for f in fns.values():
             f()
