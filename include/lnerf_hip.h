@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define LNERF_ABI_VERSION 2
+#define LNERF_ABI_VERSION 3
 
 #define LNERF_OK 0
 #define LNERF_ERR_INVALID_ARG (-1)
@@ -161,6 +161,20 @@ int lnerf_grid_encode_backward_bf16(const float *xyzs, float bound, const void *
                                     const int32_t *res_host, int64_t m_host, const int32_t *m_dev,
                                     int64_t level_stride, float *dtable_zero, int variant, void *workspace,
                                     size_t workspace_bytes, void *grad_bf16, lnerf_stream_t stream);
+/* Split form of lnerf_grid_encode_backward_bf16 for a PIPELINED data-parallel exchange: pass 1 once for all levels
+ * (lnerf_grid_scatter_bin; clears the bucket cursors), then pass 2 + the finishing pass per level range
+ * (lnerf_grid_scatter_reduce_bf16: writes rows offsets[level_lo] .. offsets[level_hi] of grad_bf16), so that the
+ * all-reduce of a level group can be launched while the next group is still being summed.  Same workspace, same
+ * arithmetic, same bits as the one-call form. */
+int lnerf_grid_scatter_bin(const float *xyzs, float bound, const void *dfeat, int dfeat_dtype, int num_levels,
+                           int level_dim, const int32_t *offsets_host, const float *scales_host, const int32_t *res_host,
+                           int64_t m_host, const int32_t *m_dev, int64_t level_stride, float *dtable_zero, int variant,
+                           void *workspace, size_t workspace_bytes, lnerf_stream_t stream);
+int lnerf_grid_scatter_reduce_bf16(float bound, int num_levels, int level_dim, const int32_t *offsets_host,
+                                   const float *scales_host, const int32_t *res_host, int64_t m_host,
+                                   int64_t level_stride, int level_lo, int level_hi, float *dtable_zero, int variant,
+                                   void *workspace, size_t workspace_bytes, void *grad_bf16, lnerf_stream_t stream);
+
 /* Backward of the hash grid fused with the table's optimiser step (single-GPU training: no gradient
  * exchange sits between the two).  Same scatter as above (variant 2 or 3), but the kernel that
  * finishes a row's sum (pass 2, or the finishing kernel of the sliced coarse levels) applies
@@ -215,14 +229,18 @@ int lnerf_composite_rays_train_backward(const float *grad_weights_sum, const flo
                                         lnerf_stream_t stream);
 
 /* ---- H10: occupancy grid refresh pieces (`update_extra_state`): cell sample points,
- * decayed max update, mean, then lnerf_packbits. */
+ * decayed max update, mean, then lnerf_packbits.  Update and mean are ORDER-INDEPENDENT (replicas of a data-parallel
+ * run refresh their grids redundantly and must stay bit-identical): a cell listed several times takes the maximum of
+ * its new densities, the mean is summed in a fixed order. */
 int lnerf_occ_cell_points(const uint32_t *indices, int64_t n, int cascade_level, int grid_size, float bound,
                           const float *noise, float *xyzs, lnerf_stream_t stream);
-/* indices == NULL means cells 0..n-1 */
+/* grid[idx] = max(grid[idx] * decay, max of the new_sigmas listed for idx) for every listed cell with a new density
+ * >= 0 (cells holding a negative value are never updated).  indices == NULL means cells 0..n-1.  scratch_cells: one
+ * uint32 per cell of the level, all zero on entry; left all zero. */
 int lnerf_occ_update(float *grid_level, const uint32_t *indices, int64_t n, const float *new_sigmas, float decay,
-                     lnerf_stream_t stream);
-/* mean of max(grid,0) over n cells -> *mean_dev ; scratch2: 2 floats of device scratch */
-int lnerf_occ_mean(const float *grid, int64_t n, float *mean_dev, float *scratch2, lnerf_stream_t stream);
+                     uint32_t *scratch_cells, lnerf_stream_t stream);
+/* mean of max(grid,0) over n cells -> *mean_dev ; scratch256: 256 floats of device scratch */
+int lnerf_occ_mean(const float *grid, int64_t n, float *mean_dev, float *scratch256, lnerf_stream_t stream);
 
 /* ---- H11: background net, frequency encoding (degree 6: 39 dims) -> 64 -> C, one thread per ray. */
 int lnerf_bg_forward(const float *dirs, int64_t N, const float *w1, const float *b1, const float *w2, const float *b2,

@@ -1003,12 +1003,13 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
 template <bool FUSE>
 __global__ void __launch_bounds__(256)
 k_scatter_finish(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ cursor, const unsigned int *__restrict__ gmax,
-                 const long long *__restrict__ partials, float *__restrict__ dtable, FusedUpdate fu) {
+                 const long long *__restrict__ partials, float *__restrict__ dtable, FusedUpdate fu, int lv_lo, int lv_hi) {
     constexpr int WG_PER_BUCKET = BK_ROWS / 256;
     const int fb = blockIdx.x / WG_PER_BUCKET;  // index among the buckets of sliced levels
     int l = 0;
     while (l + 1 < meta.num_levels && (bm.slices[l] <= 1 || fb >= bm.fstart[l] + bm.nb[l])) ++l;
     if (bm.slices[l] <= 1) return;  // (cannot happen: the grid covers sliced buckets only)
+    if (l < lv_lo || l >= lv_hi) return;  // a launch over a level range (pipelined data-parallel exchange)
     const int b = fb - bm.fstart[l];
     const int Smax = bm.slices[l], cap = bm.cap[l];
     const int n_raw = cursor[bm.bstart[l] + b];
@@ -1274,11 +1275,12 @@ size_t lnerf_grid_encode_backward_workspace_bytes(int num_levels, const int32_t 
 
 // fu == nullptr: dtable += scatter.  fu != nullptr: every row's Adam step is applied by whichever kernel finishes its
 // sum (pass 2 on unsliced levels, the finishing pass on sliced ones); dtable only carries overflow records.
+// phases: 1 = pass 1 (binning, all levels; clears the cursors), 2 = pass 2 + finishing pass of levels [lv_lo, lv_hi)
 static int scatter_backward(const float *xyzs, float bound, const void *dfeat, int dfeat_dtype, int num_levels,
                             int level_dim, const int32_t *offsets_host, const float *scales_host,
                             const int32_t *res_host, int64_t m_host, const int32_t *m_dev, int64_t level_stride,
                             float *dtable, int variant, void *workspace, size_t workspace_bytes,
-                            lnerf_stream_t stream, FusedUpdate *fu) {
+                            lnerf_stream_t stream, FusedUpdate *fu, int phases = 3, int lv_lo = 0, int lv_hi = -1) {
     GridMeta meta;
     int rc = fill_meta("grid_encode_backward", meta, num_levels, level_dim, offsets_host, scales_host, res_host);
     if (rc) return rc;
@@ -1289,7 +1291,10 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
     LNERF_REQUIRE(dfeat_dtype == LNERF_F32, "grid_encode_backward: dfeat must be f32");
     LNERF_REQUIRE(!fu || (variant >= 2 && m_host > 0), "grid_encode_backward_adam: needs variant 2/3 and m_host > 0");
     if (m_host == 0) return LNERF_OK;
-    LNERF_REQUIRE(xyzs && dfeat && dtable, "grid_encode_backward: null pointer");
+    LNERF_REQUIRE(dtable && (!(phases & 1) || (xyzs && dfeat)), "grid_encode_backward: null pointer");
+    if (lv_hi < 0) lv_hi = num_levels;
+    LNERF_REQUIRE(lv_lo >= 0 && lv_lo <= lv_hi && lv_hi <= num_levels, "grid_encode_backward: bad level range");
+    LNERF_REQUIRE(phases == 3 || variant >= 2, "grid_encode_backward: the split form needs the bucketed scatter");
     hipStream_t s = as_stream(stream);
     dim3 grid;
     if (variant < 2) {
@@ -1315,7 +1320,7 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
     void *rec = (char *)workspace + cbytes;
     long long *partials = (long long *)((char *)workspace + cbytes + plan.rec_bytes);
     const bool packed = variant == 3;
-    if (hipMemsetAsync(cursor, 0, cbytes, s) != hipSuccess) {
+    if ((phases & 1) && hipMemsetAsync(cursor, 0, cbytes, s) != hipSuccess) {
         set_error("grid_encode_backward: hipMemsetAsync failed");
         return LNERF_ERR_HIP;
     }
@@ -1355,16 +1360,24 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
         if (plan.fbuckets == 0) return;
         const dim3 g((unsigned)(plan.fbuckets * (BK_ROWS / 256)));
         if (fu)
-            hipLaunchKernelGGL(k_scatter_finish<true>, g, dim3(256), 0, s, meta, bm, cursor, gmax, partials, dtable, fu0);
+            hipLaunchKernelGGL(k_scatter_finish<true>, g, dim3(256), 0, s, meta, bm, cursor, gmax, partials, dtable, fu0,
+                               lv_lo, lv_hi);
         else
-            hipLaunchKernelGGL(k_scatter_finish<false>, g, dim3(256), 0, s, meta, bm, cursor, gmax, partials, dtable, fu0);
+            hipLaunchKernelGGL(k_scatter_finish<false>, g, dim3(256), 0, s, meta, bm, cursor, gmax, partials, dtable, fu0,
+                               lv_lo, lv_hi);
     };
-    launch_bin();
-    LNERF_CHECK_LAUNCH("grid_encode_backward(bin)");
-    launch_reduce(s, 0, num_levels);
-    LNERF_CHECK_LAUNCH("grid_encode_backward(reduce)");
-    launch_finish();
-    LNERF_CHECK_LAUNCH("grid_encode_backward(finish)");
+    if (phases & 1) {
+        launch_bin();
+        LNERF_CHECK_LAUNCH("grid_encode_backward(bin)");
+    }
+    if (phases & 2) {
+        launch_reduce(s, lv_lo, lv_hi);
+        LNERF_CHECK_LAUNCH("grid_encode_backward(reduce)");
+        bool any_sliced = false;
+        for (int l = lv_lo; l < lv_hi; ++l) any_sliced = any_sliced || bm.slices[l] > 1;
+        if (any_sliced) launch_finish();
+        LNERF_CHECK_LAUNCH("grid_encode_backward(finish)");
+    }
     return LNERF_OK;
 }
 
@@ -1391,6 +1404,32 @@ int lnerf_grid_encode_backward_bf16(const float *xyzs, float bound, const void *
     fu.grad_out = (uint16_t *)grad_bf16;
     return scatter_backward(xyzs, bound, dfeat, dfeat_dtype, num_levels, level_dim, offsets_host, scales_host, res_host,
                             m_host, m_dev, level_stride, dtable_zero, variant, workspace, workspace_bytes, stream, &fu);
+}
+
+int lnerf_grid_scatter_bin(const float *xyzs, float bound, const void *dfeat, int dfeat_dtype, int num_levels,
+                           int level_dim, const int32_t *offsets_host, const float *scales_host, const int32_t *res_host,
+                           int64_t m_host, const int32_t *m_dev, int64_t level_stride, float *dtable_zero, int variant,
+                           void *workspace, size_t workspace_bytes, lnerf_stream_t stream) {
+    LNERF_REQUIRE(dtable_zero, "grid_scatter_bin: null output");
+    return scatter_backward(xyzs, bound, dfeat, dfeat_dtype, num_levels, level_dim, offsets_host, scales_host, res_host,
+                            m_host, m_dev, level_stride, dtable_zero, variant, workspace, workspace_bytes, stream, nullptr,
+                            1);
+}
+
+int lnerf_grid_scatter_reduce_bf16(float bound, int num_levels, int level_dim, const int32_t *offsets_host,
+                                   const float *scales_host, const int32_t *res_host, int64_t m_host,
+                                   int64_t level_stride, int level_lo, int level_hi, float *dtable_zero, int variant,
+                                   void *workspace, size_t workspace_bytes, void *grad_bf16, lnerf_stream_t stream) {
+    LNERF_REQUIRE(grad_bf16 && dtable_zero, "grid_scatter_reduce_bf16: null output");
+    LNERF_REQUIRE((((uintptr_t)grad_bf16 | (uintptr_t)dtable_zero) & 15) == 0,
+                  "grid_scatter_reduce_bf16: buffers must be 16-byte aligned");
+    FusedUpdate fu;
+    memset(&fu, 0, sizeof(fu));
+    adam_host_args(fu.a, 0.f, 0.5f, 0.5f, 1.f, 1, nullptr, 1.f, 0);  // (unused in this mode)
+    fu.grad_out = (uint16_t *)grad_bf16;
+    return scatter_backward(nullptr, bound, nullptr, LNERF_F32, num_levels, level_dim, offsets_host, scales_host, res_host,
+                            m_host, nullptr, level_stride, dtable_zero, variant, workspace, workspace_bytes, stream, &fu, 2,
+                            level_lo, level_hi);
 }
 
 int lnerf_grid_encode_backward_adam(const float *xyzs, float bound, const void *dfeat, int dfeat_dtype, int num_levels,

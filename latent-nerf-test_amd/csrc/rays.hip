@@ -414,26 +414,56 @@ k_occ_cell_points(const uint32_t *__restrict__ indices, int64_t n, float mip_bou
     }
 }
 
-__global__ void __launch_bounds__(256) k_occ_update(float *__restrict__ grid, const uint32_t *__restrict__ indices,
-                                                    int64_t n, const float *__restrict__ sig, float decay) {
+// Occupancy refresh, order-independent form (replicas of a data-parallel run must stay bit-identical, and the sampled
+// index list may name a cell more than once): pass 1 takes the MAXIMUM of the new densities per cell into a scratch
+// grid (non-negative floats order as unsigned integers: atomicMax on the bits), pass 2 applies
+// grid = max(grid * decay, scratch) to the touched cells.  scratch: one uint32 per cell, all zero between calls.
+__global__ void __launch_bounds__(256) k_occ_update_max(unsigned int *__restrict__ scratch,
+                                                        const uint32_t *__restrict__ indices, int64_t n,
+                                                        const float *__restrict__ sig) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t idx = indices ? indices[i] : (uint32_t)i;
-        const float old = grid[idx], s = sig[i];
-        if (old >= 0.f && s >= 0.f) grid[idx] = fmaxf(old * decay, s);
+        const float s = sig[i];
+        // bit 31 marks "touched" (a density of exactly 0 must still decay the cell); densities < 0 never update
+        if (s >= 0.f) atomicMax(&scratch[idx], __float_as_uint(s) | 0x80000000u);
+    }
+}
+__global__ void __launch_bounds__(256) k_occ_update_apply(float *__restrict__ grid, unsigned int *__restrict__ scratch,
+                                                          const uint32_t *__restrict__ indices, int64_t n, float decay) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t idx = indices ? indices[i] : (uint32_t)i;
+        // the first entry of a cell takes its maximum (and leaves the scratch word zero for the next call); further
+        // entries of the same cell find zero: exactly one thread updates the cell, whatever the order
+        const unsigned int m = atomicExch(&scratch[idx], 0u);
+        if (!(m & 0x80000000u)) continue;
+        const float old = grid[idx];
+        if (old >= 0.f) grid[idx] = fmaxf(old * decay, __uint_as_float(m & 0x7FFFFFFFu));
     }
 }
 
-// mean of max(grid, 0) over all cells; scratch = {sum, unused}
+// mean of max(grid, 0) over all cells, in a FIXED summation order (a float atomicAdd over the partial sums would make
+// the mean -- and with it the occupancy threshold min(mean, thresh) and the bitfield -- depend on arrival order):
+// OCC_MEAN_BLOCKS workgroups each sum a fixed strided slice (wave sums, then the 4 waves in order) into partial[block];
+// one workgroup adds the partials in index order.
+constexpr int OCC_MEAN_BLOCKS = 256;
 __global__ void __launch_bounds__(256) k_occ_mean_partial(const float *__restrict__ grid, int64_t n,
-                                                          float *__restrict__ scratch) {
+                                                          float *__restrict__ partial) {
+    __shared__ float s_w[4];
     float s = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         s += fmaxf(grid[i], 0.f);
     s = wave_sum(s);
-    if (lane_id() == 0) atomicAdd(&scratch[0], s);
+    if (lane_id() == 0) s_w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
 }
-__global__ void k_occ_mean_final(const float *__restrict__ scratch, float n, float *__restrict__ mean) {
-    *mean = scratch[0] / n;
+__global__ void __launch_bounds__(64) k_occ_mean_final(const float *__restrict__ partial, int blocks, float n,
+                                                       float *__restrict__ mean) {
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int b = 0; b < blocks; ++b) s += partial[b];
+        *mean = s / n;
+    }
 }
 
 static MarchParams make_params(float bound, int cascade, int G, int max_steps, float dt_gamma) {
@@ -628,23 +658,24 @@ int lnerf_occ_cell_points(const uint32_t *indices, int64_t n, int cascade_level,
 }
 
 int lnerf_occ_update(float *grid_level, const uint32_t *indices, int64_t n, const float *new_sigmas, float decay,
-                     lnerf_stream_t stream) {
+                     uint32_t *scratch_cells, lnerf_stream_t stream) {
     LNERF_REQUIRE(n >= 0, "occ_update: negative n");
     if (n == 0) return LNERF_OK;
-    LNERF_REQUIRE(grid_level && new_sigmas, "occ_update: null pointer");
-    hipLaunchKernelGGL(k_occ_update, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), grid_level, indices, n,
-                       new_sigmas, decay);
-    LNERF_CHECK_LAUNCH("occ_update");
+    LNERF_REQUIRE(grid_level && new_sigmas && scratch_cells, "occ_update: null pointer");
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(k_occ_update_max, dim3(grid_for(n)), dim3(256), 0, s, scratch_cells, indices, n, new_sigmas);
+    LNERF_CHECK_LAUNCH("occ_update(max)");
+    hipLaunchKernelGGL(k_occ_update_apply, dim3(grid_for(n)), dim3(256), 0, s, grid_level, scratch_cells, indices, n, decay);
+    LNERF_CHECK_LAUNCH("occ_update(apply)");
     return LNERF_OK;
 }
 
-int lnerf_occ_mean(const float *grid, int64_t n, float *mean_dev, float *scratch2, lnerf_stream_t stream) {
-    LNERF_REQUIRE(n > 0 && grid && mean_dev && scratch2, "occ_mean: bad arguments");
-    (void)hipMemsetAsync(scratch2, 0, 2 * sizeof(float), as_stream(stream));
-    hipLaunchKernelGGL(k_occ_mean_partial, dim3(grid_for(n, 256, 512)), dim3(256), 0, as_stream(stream), grid, n,
-                       scratch2);
+int lnerf_occ_mean(const float *grid, int64_t n, float *mean_dev, float *scratch256, lnerf_stream_t stream) {
+    LNERF_REQUIRE(n > 0 && grid && mean_dev && scratch256, "occ_mean: bad arguments");
+    hipLaunchKernelGGL(k_occ_mean_partial, dim3(OCC_MEAN_BLOCKS), dim3(256), 0, as_stream(stream), grid, n, scratch256);
     LNERF_CHECK_LAUNCH("occ_mean(partial)");
-    hipLaunchKernelGGL(k_occ_mean_final, dim3(1), dim3(1), 0, as_stream(stream), scratch2, (float)n, mean_dev);
+    hipLaunchKernelGGL(k_occ_mean_final, dim3(1), dim3(64), 0, as_stream(stream), scratch256, OCC_MEAN_BLOCKS, (float)n,
+                       mean_dev);
     LNERF_CHECK_LAUNCH("occ_mean(final)");
     return LNERF_OK;
 }

@@ -52,6 +52,9 @@ class OptimConfig:
     views_per_step: int = 1
     # single process and one view per step: the hash table's Adam step runs inside the scatter of the backward pass
     fuse_table_update: bool = True
+    # data parallel, bf16: level groups the table gradient is exchanged in (each group's all-reduce is launched behind
+    # its own sums while the next group is still being summed); 1 = one collective for the whole table
+    exchange_groups: int = 4
 
 
 @dataclass

@@ -140,12 +140,34 @@ def grid_encode_backward_adam(xyzs, bound, dfeat, encoder, m_host, m_dev, level_
 class GradSink:
     """Set on a GridEncoder (`encoder.grad_sink`) by GradSync.attach_sink(): the backward pass WRITES the table
     gradient as bf16 into `wire` (lnerf_grid_encode_backward_bf16) -- the buffer the data-parallel all-reduce sends --
-    instead of accumulating an f32 `.grad`: no zero fill, no read-modify-write, no cast.  One backward per step."""
+    instead of accumulating an f32 `.grad`: no zero fill, no read-modify-write, no cast.  One backward per step.
 
-    def __init__(self, table):
+    `groups` (list of (level_lo, level_hi)) selects the PIPELINED form: the backward pass only bins the records
+    (lnerf_grid_scatter_bin); GradSync.allreduce_pipelined() then sums one level group at a time
+    (lnerf_grid_scatter_reduce_bf16) and launches that group's all-reduce while the next group is being summed."""
+
+    def __init__(self, table, groups=None):
         self.wire = torch.zeros(table.shape, device=table.device, dtype=torch.bfloat16)
         self.zero = torch.zeros(table.shape, device=table.device, dtype=torch.float32)  # overflow records only
         self.written = 0
+        self.groups = groups
+        self.pending = None   # (bound, levels, m_host, level_stride, variant, workspace) of a binned, not yet summed backward
+
+
+def level_groups(levels: GridLevels, n_groups=4):
+    """Level ranges of roughly equal table rows (the exchange is priced per row): [(lo, hi), ...]."""
+    n_groups = max(1, min(int(n_groups), levels.num_levels))
+    target = levels.n_rows / n_groups
+    out, lo = [], 0
+    for l in range(levels.num_levels):
+        done_rows = levels.offsets[l + 1]
+        if done_rows >= target * (len(out) + 1) - 1e-9 or l == levels.num_levels - 1:
+            if len(out) < n_groups - 1 or l == levels.num_levels - 1:
+                out.append((lo, l + 1))
+                lo = l + 1
+    if lo < levels.num_levels:
+        out.append((lo, levels.num_levels))
+    return out
 
 
 def grid_encode_backward_bf16(xyzs, bound, dfeat, encoder, m_host, m_dev, level_stride, variant):
@@ -154,11 +176,29 @@ def grid_encode_backward_bf16(xyzs, bound, dfeat, encoder, m_host, m_dev, level_
     if variant < 2:
         raise _b.LnerfError("the bf16 gradient output needs the bucketed scatter (variant 2 or 3)")
     wst = scatter_workspace(levels, m_host, xyzs.device)
+    if sink.groups:   # pipelined: pass 1 now, pass 2 per level group inside GradSync.allreduce_pipelined()
+        _b.call("lnerf_grid_scatter_bin", _chk(xyzs, "xyzs"), float(bound), _chk(dfeat, "dfeat"), _b.F32,
+                levels.num_levels, levels.level_dim, levels.c_offsets, levels.c_scales, levels.c_res, int(m_host),
+                _chk(m_dev, "m_dev", torch.int32, allow_none=True), int(level_stride), _p(sink.zero), int(variant),
+                _p(wst), wst.numel(), _stream())
+        sink.pending = (float(bound), levels, int(m_host), int(level_stride), int(variant), wst)
+        return
     _b.call("lnerf_grid_encode_backward_bf16", _chk(xyzs, "xyzs"), float(bound), _chk(dfeat, "dfeat"), _b.F32,
             levels.num_levels, levels.level_dim, levels.c_offsets, levels.c_scales, levels.c_res, int(m_host),
             _chk(m_dev, "m_dev", torch.int32, allow_none=True), int(level_stride), _p(sink.zero), int(variant), _p(wst),
             wst.numel(), _p(sink.wire), _stream())
     sink.written += 1
+
+
+def grid_scatter_reduce_group(sink: GradSink, level_lo, level_hi):
+    """Pass 2 (+ finishing pass) of levels [level_lo, level_hi) of the backward that sink.pending describes: writes rows
+    offsets[level_lo] .. offsets[level_hi] of sink.wire."""
+    if sink.pending is None:
+        raise _b.LnerfError("no binned backward pass is pending on this gradient sink")
+    bound, levels, m_host, level_stride, variant, wst = sink.pending
+    _b.call("lnerf_grid_scatter_reduce_bf16", bound, levels.num_levels, levels.level_dim, levels.c_offsets,
+            levels.c_scales, levels.c_res, m_host, level_stride, int(level_lo), int(level_hi), _p(sink.zero), variant,
+            _p(wst), wst.numel(), _p(sink.wire), _stream())
 
 
 class _GridEncode(torch.autograd.Function):

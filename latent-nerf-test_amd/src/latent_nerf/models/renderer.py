@@ -66,6 +66,8 @@ class NeRFRenderer(nn.Module):
         self.mean_count = 0
         self._noise_counter = None
         self._occ_scratch = None
+        self._occ_cells = None
+        self._occ_gen = None
 
     # subclasses provide the field -------------------------------------------------------
     def forward(self, x, d=None):
@@ -267,28 +269,42 @@ class NeRFRenderer(nn.Module):
         return {"image": image.view(*prefix, C), "depth": depth.view(*prefix),
                 "weights_sum": weights_sum.view(*prefix)}
 
+    def occupancy_generator(self, seed=None):
+        """The generator the occupancy refresh draws its cell samples and jitter from.  Replicas of a data-parallel run
+        refresh their grids redundantly: with the same seed on every rank (the trainer passes `optim.seed`) and the
+        order-independent update kernels they stay bit-identical without any exchange."""
+        dev = self.density_grid.device
+        if seed is not None or self._occ_gen is None or self._occ_gen.device != dev:
+            self._occ_gen = torch.Generator(device=dev)
+            self._occ_gen.manual_seed(0x0CC0 + (0 if seed is None else int(seed)))
+        return self._occ_gen
+
     @torch.no_grad()
     def update_extra_state(self, decay=0.95, S=128):
         """Occupancy-grid refresh (every `update_extra_interval` steps): evaluate the density at
         jittered cell centres (all cells for the first 16 refreshes, then G^3/4 random + G^3/4
-        occupied cells), decayed-max into the grid, recompute the mean and repack the bitfield."""
+        occupied cells), decayed-max into the grid, recompute the mean and repack the bitfield.
+        Deterministic given the generator state and the weights (see occupancy_generator)."""
         if not self.cuda_ray:
             return
         if self.training:
             self.update_sample_budget()
         dev = self.density_grid.device
+        gen = self.occupancy_generator()
         G, G3 = self.grid_size, self.grid_size ** 3
         chunk = 1 << 20
+        if self._occ_cells is None or self._occ_cells.device != dev:
+            self._occ_cells = torch.zeros(G3, device=dev, dtype=torch.int32)   # scratch of lnerf_occ_update, zero between calls
         for cas in range(self.cascade):
             if self.iter_density < 16:
                 indices = None
                 n = G3
             else:
                 n_rand = G3 // 4
-                rand_idx = torch.randint(0, G3, (n_rand,), device=dev, dtype=torch.int32)
+                rand_idx = torch.randint(0, G3, (n_rand,), device=dev, dtype=torch.int32, generator=gen)
                 occ = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
                 if occ.numel() > 0:
-                    pick = torch.randint(0, occ.numel(), (n_rand,), device=dev)
+                    pick = torch.randint(0, occ.numel(), (n_rand,), device=dev, generator=gen)
                     occ_idx = occ[pick].to(torch.int32)
                     indices = torch.cat([rand_idx, occ_idx])
                 else:
@@ -300,14 +316,15 @@ class NeRFRenderer(nn.Module):
                 idx = None if indices is None else indices[s:e].contiguous()
                 if idx is None:
                     idx = torch.arange(s, e, device=dev, dtype=torch.int32)
-                noise = torch.rand(e - s, 3, device=dev)
+                noise = torch.rand(e - s, 3, device=dev, generator=gen)
                 xyzs = torch.empty(e - s, 3, device=dev)
                 _b.call("lnerf_occ_cell_points", _p(idx), e - s, cas, G, self.bound, _p(noise), _p(xyzs), _stream())
                 sigmas, _ = self.field(xyzs, e - s)
                 sigmas = (sigmas * self.density_scale).contiguous()
-                _b.call("lnerf_occ_update", _p(level), _p(idx), e - s, _p(sigmas), float(decay), _stream())
+                _b.call("lnerf_occ_update", _p(level), _p(idx), e - s, _p(sigmas), float(decay), _p(self._occ_cells),
+                        _stream())
         if self._occ_scratch is None or self._occ_scratch.device != dev:
-            self._occ_scratch = torch.zeros(2, device=dev)
+            self._occ_scratch = torch.zeros(256, device=dev)
         _b.call("lnerf_occ_mean", _p(self.density_grid), self.density_grid.numel(), _p(self.mean_density_dev),
                 _p(self._occ_scratch), _stream())
         self.iter_density += 1

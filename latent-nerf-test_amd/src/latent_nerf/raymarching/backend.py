@@ -32,7 +32,7 @@ _F = _c.c_float
 _Z = _c.c_size_t
 _U = _c.c_uint32
 
-ABI_VERSION = 2  # LNERF_ABI_VERSION of include/lnerf_hip.h this host side was written against
+ABI_VERSION = 3  # LNERF_ABI_VERSION of include/lnerf_hip.h this host side was written against
 
 # name -> argtypes (return type int unless listed in _RESTYPES)
 _SIGNATURES = {
@@ -53,6 +53,8 @@ _SIGNATURES = {
     "lnerf_grid_encode_backward_workspace_bytes": [_I, _P, _L],
     "lnerf_grid_encode_backward": [_P, _F, _P, _I, _I, _I, _P, _P, _P, _L, _P, _L, _P, _I, _P, _Z, _P],
     "lnerf_grid_encode_backward_bf16": [_P, _F, _P, _I, _I, _I, _P, _P, _P, _L, _P, _L, _P, _I, _P, _Z, _P, _P],
+    "lnerf_grid_scatter_bin": [_P, _F, _P, _I, _I, _I, _P, _P, _P, _L, _P, _L, _P, _I, _P, _Z, _P],
+    "lnerf_grid_scatter_reduce_bf16": [_F, _I, _I, _P, _P, _P, _L, _L, _I, _I, _P, _I, _P, _Z, _P, _P],
     "lnerf_grid_encode_backward_adam": [_P, _F, _P, _I, _I, _I, _P, _P, _P, _L, _P, _L, _P, _I, _P, _Z, _P, _P, _P, _P, _F,
                                         _F, _F, _F, _I, _P, _F, _P],
     "lnerf_mlp_forward": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _L, _P, _P, _P, _I, _P],
@@ -62,7 +64,7 @@ _SIGNATURES = {
     "lnerf_composite_rays_train_forward": [_P, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P, _P],
     "lnerf_composite_rays_train_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P],
     "lnerf_occ_cell_points": [_P, _L, _I, _I, _F, _P, _P, _P],
-    "lnerf_occ_update": [_P, _P, _L, _P, _F, _P],
+    "lnerf_occ_update": [_P, _P, _L, _P, _F, _P, _P],
     "lnerf_occ_mean": [_P, _L, _P, _P, _P],
     "lnerf_bg_forward": [_P, _L, _P, _P, _P, _P, _I, _P, _P],
     "lnerf_bg_backward": [_P, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P],

@@ -17,6 +17,40 @@ def world_info():
     return 0, 1
 
 
+def init_distributed():
+    """Call FIRST in a training process, before anything touches the GPU: binds this rank to its device and, when
+    the launcher (`python -m torch.distributed.run --nproc-per-node N ...`) set WORLD_SIZE > 1, joins the process
+    group -- backend "nccl" (= RCCL over xGMI on ROCm), one process per GPU.  LNERF_DIST_BACKEND=gloo lets several
+    ranks share one card for functional rehearsals (the collectives then stage through the host).
+    Returns (rank, world, device)."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("LNERF_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()          # (counting devices does not initialise the GPU)
+    if ndev == 0:
+        raise RuntimeError("no GPU visible: the render path runs on the HIP library only")
+    local_dev = local if backend == "nccl" else local % ndev
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    return rank, world, dev
+
+
+def broadcast_parameters(params, src=0, group=None):
+    """Replicas start from rank `src`'s values (one flat bucket for the small tensors, big ones on their own)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    for p in params:
+        dist.broadcast(p.data, src=src, group=group)
+
+
 def views_for_rank(views_per_step: int, rank: int, world: int) -> List[int]:
     """Indices (within a step's batch of random views) rendered by `rank`: round-robin, so that
     8 views/step on 8 GPUs is 1 view per GPU (BASELINE config 4)."""
@@ -70,17 +104,20 @@ class GradSync:
             self._wire[id(p)] = buf
         return buf
 
-    def attach_sink(self, encoder):
+    def attach_sink(self, encoder, pipeline_groups=0):
         """bf16 transport, more than one rank: let the encoder's backward write the table gradient straight into the
         wire buffer this object all-reduces (GradSink): the table then has no `.grad`, use reduced() for the sums.
-        No-op otherwise.  One backward per step."""
+        No-op otherwise.  One backward per step.
+        pipeline_groups >= 1: the table is exchanged in that many level groups by allreduce_pipelined() (0: one
+        collective through allreduce(copy_back=False))."""
         if self.world == 1 or self.transport == torch.float32:
             return None
-        from ..models.encoding import GradSink
+        from ..models.encoding import GradSink, level_groups
         p = encoder.embeddings
         if not any(p is q for q in self.big):
             raise ValueError("attach_sink: encoder.embeddings is not one of the big buckets")
-        sink = GradSink(p.data)
+        sink = GradSink(p.data, groups=level_groups(encoder.levels, pipeline_groups) if pipeline_groups >= 1 else None)
+        self._sink_levels = getattr(encoder, "levels", None)
         self._wire[id(p)] = sink.wire
         self._sinks[id(p)] = sink
         encoder.grad_sink = sink
@@ -132,3 +169,54 @@ class GradSync:
             h.wait()
             if wire is not None and copy_back:
                 p.grad.copy_(wire)  # bf16 -> f32
+
+    def allreduce_pipelined(self):
+        """The exchange of a step whose table gradient sits in a pipelined GradSink (attach_sink(pipeline_groups=G)):
+        the backward pass has only binned the scatter records; here one level group at a time is summed
+        (lnerf_grid_scatter_reduce_bf16) and its all-reduce launched right behind it on the collective's own stream, so
+        group g travels over xGMI while group g + 1 is still being summed; the small parameters follow as one flat async
+        bucket.  Returns a PendingExchange: `table_groups` = [(row_lo, row_hi, work)] for FusedAdam.step(row_groups=...)
+        -- the optimiser waits for a group right before it steps those rows -- and finish_small()."""
+        from ..models.encoding import grid_scatter_reduce_group
+        table = self.big[0]
+        sink = self._sinks.get(id(table))
+        if sink is None or not sink.groups:
+            raise RuntimeError("allreduce_pipelined() needs attach_sink(encoder, pipeline_groups >= 1)")
+        offs = self._sink_levels.offsets
+        groups = []
+        for lo, hi in sink.groups:
+            grid_scatter_reduce_group(sink, lo, hi)
+            rows = sink.wire[offs[lo]:offs[hi]]
+            work = dist.all_reduce(rows, group=self.group, async_op=True) if self.world > 1 else None
+            groups.append((offs[lo], offs[hi], work))
+        sink.pending = None
+        sink.written += 1
+        small_work, flat = None, None
+        if self.small:
+            flat = self._flat_buffer()
+            o = 0
+            for p in self.small:
+                if p.grad is None:
+                    raise RuntimeError("GradSync: a parameter has no gradient on this rank")
+                flat[o:o + p.numel()].copy_(p.grad.reshape(-1))
+                o += p.numel()
+            if self.world > 1:
+                small_work = dist.all_reduce(flat, group=self.group, async_op=True)
+        return PendingExchange(groups, self.small, flat, small_work)
+
+
+class PendingExchange:
+    def __init__(self, table_groups, small, flat, small_work):
+        self.table_groups = table_groups
+        self._small, self._flat, self._work = small, flat, small_work
+
+    def finish_small(self):
+        """Waits for the flat bucket and hands the sums back to the `.grad` tensors of the small parameters."""
+        if self._work is not None:
+            self._work.wait()
+        if self._flat is not None:
+            o = 0
+            for p in self._small:
+                p.grad.copy_(self._flat[o:o + p.numel()].view_as(p.grad))
+                o += p.numel()
+        self._work = self._flat = None

@@ -70,9 +70,11 @@ class FusedAdam:
         if self.fused is not None and (self.fused.armed or self.fused.applied):
             raise RuntimeError("FusedAdam.zero_grad(): a fused table update is pending or already applied this step")
 
-    def step(self, grad_scale=None, set_to_none=True, grads=None):
+    def step(self, grad_scale=None, set_to_none=True, grads=None, row_groups=None):
         """grads: optional {parameter: gradient tensor} overriding `.grad` for the big tensors -- f32, or the bf16
-        wire buffer of GradSync (`GradSync.reduced()`), which the Adam kernel then reads directly."""
+        wire buffer of GradSync (`GradSync.reduced()`), which the Adam kernel then reads directly.
+        row_groups: optional {parameter: [(row_lo, row_hi, work), ...]} -- that parameter is stepped one row range at a
+        time, each after `work.wait()` (a pipelined exchange: PendingExchange.table_groups); `work` may be None."""
         if grad_scale is None:
             grad_scale = self.grad_scale
         elif self.fused is not None and float(grad_scale) != float(self.grad_scale):
@@ -95,9 +97,15 @@ class FusedAdam:
             if g.dtype not in (torch.float32, torch.bfloat16) or g.numel() != p.numel() or not g.is_contiguous():
                 raise ValueError("FusedAdam: gradient must be a contiguous f32 or bf16 tensor of the parameter's size")
             shadow = enc.shadow() if (enc is not None and p is enc.embeddings) else None
-            _b.call("lnerf_adam_step", _p(p.data), _p(g), _b.F32 if g.dtype == torch.float32 else _b.BF16, _p(m), _p(v),
-                    _p(shadow), p.numel(), lr, b1, b2, self.eps, self.step_no, _p(self.step_dev), float(grad_scale), 0,
-                    _stream())
+            gdt = _b.F32 if g.dtype == torch.float32 else _b.BF16
+            ranges = [(0, p.shape[0], None)] if (row_groups is None or p not in row_groups) else row_groups[p]
+            for r0, r1, work in ranges:
+                if work is not None:
+                    work.wait()        # (orders the current stream behind that group's all-reduce)
+                sl = slice(r0, r1)
+                _b.call("lnerf_adam_step", _p(p.data[sl]), _p(g[sl]), gdt, _p(m[sl]), _p(v[sl]),
+                        None if shadow is None else _p(shadow[sl]), p.data[sl].numel(), lr, b1, b2, self.eps,
+                        self.step_no, _p(self.step_dev), float(grad_scale), 0, _stream())
         if self.small:
             for k, (p, m, v, lr) in enumerate(self.small):
                 if p.grad is None:

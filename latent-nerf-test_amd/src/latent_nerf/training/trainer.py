@@ -30,11 +30,16 @@ _LATENT_TO_RGB = torch.tensor([[0.298, 0.207, 0.208], [0.187, 0.286, 0.173], [-0
 
 class Trainer:
     def __init__(self, cfg: TrainConfig, device=None, guidance=None):
+        """Data parallel: launch one process per GPU (`python -m torch.distributed.run --nproc-per-node N -m
+        scripts.train_latent_nerf ...`); scripts/train_latent_nerf.py calls distributed.init_distributed() before
+        anything touches the GPU.  Every rank holds a full replica, renders `optim.views_per_step / N` views per
+        step and exchanges gradients once per step (GradSync); replicas stay bit-identical (identical initial
+        weights, identical reduced gradients, identical Adam step, identically seeded occupancy refresh)."""
         self.cfg = cfg
         self.train_step = 0
         self.rank, self.world = D.world_info()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
-        seed_everything(cfg.optim.seed)
+        seed_everything(cfg.optim.seed)   # model initialisation: the same stream on every rank
         self.exp_path = make_path(cfg.log.exp_dir)
         self.ckpt_path = make_path(self.exp_path / "checkpoints")
         self.train_renders_path = make_path(self.exp_path / "vis" / "train")
@@ -43,7 +48,16 @@ class Trainer:
         if self.rank == 0:
             with open(self.exp_path / "config.json", "w") as f:
                 json.dump(_cfg_to_dict(cfg), f, indent=1, default=str)
+        if self.world > 1 and cfg.render.noise_seed is not None:
+            # march jitter: a different counter-based stream per rank (poses come from pose_generator(seed, step, view),
+            # which every rank can reproduce; jitter and guidance noise must NOT be correlated across ranks)
+            cfg.render.noise_seed = (int(cfg.render.noise_seed) + 0x9E3779B1 * self.rank) & 0x7FFFFFFF
         self.nerf = NeRFNetwork(cfg.render).to(self.device)
+        D.broadcast_parameters(list(self.nerf.parameters()))          # replicas start from rank 0's weights
+        self.nerf.occupancy_generator(seed=cfg.optim.seed)            # the same refresh samples on every rank
+        if self.world > 1:                                            # guidance noise / timesteps: per-rank streams
+            torch.manual_seed(cfg.optim.seed + 7919 * (self.rank + 1))
+            torch.cuda.manual_seed(cfg.optim.seed + 7919 * (self.rank + 1))
         self.diffusion = guidance if guidance is not None else self.init_diffusion()
         self.text_z = self.calc_text_embeddings()
         n_views = len(D.views_for_rank(max(cfg.optim.views_per_step, self.world), self.rank, self.world))
@@ -51,7 +65,14 @@ class Trainer:
         self.optimizer = FusedAdam(self.nerf.get_params(cfg.optim.lr), betas=(0.9, 0.99), eps=1e-15,
                                    encoder=self.nerf.encoder, fuse_table_update=fuse)
         small = [p for p in self.nerf.parameters() if p is not self.nerf.encoder.embeddings]
-        self.grad_sync = D.GradSync([self.nerf.encoder.embeddings], small)
+        # exchange: bf16 on the wire with the bf16 configuration (f32 otherwise); with one view per rank and step the
+        # backward pass writes the wire buffer itself and the table travels in level groups (pipelined with the sums)
+        bf16 = cfg.render.precision("mlp_precision") == "bf16"
+        self.grad_sync = D.GradSync([self.nerf.encoder.embeddings], small,
+                                    transport=torch.bfloat16 if bf16 else torch.float32)
+        self.pipelined = self.world > 1 and bf16 and n_views == 1
+        if self.pipelined:
+            self.grad_sync.attach_sink(self.nerf.encoder, pipeline_groups=max(1, cfg.optim.exchange_groups))
         self.dataloaders = self.init_dataloaders()
         self.shape_loss = self.init_shape_guidance()
         self.past_checkpoints = []
@@ -144,8 +165,15 @@ class Trainer:
                 if len(views) == 1:
                     self.optimizer.arm()   # one view, one process: the scatter applies the table's Adam step
                 self.train_render(data)
-            self.grad_sync.allreduce()
-            self.optimizer.step(grad_scale=1.0 / (len(views) * self.world))
+            scale = 1.0 / (len(views) * self.world)
+            if self.pipelined:
+                ex = self.grad_sync.allreduce_pipelined()
+                ex.finish_small()
+                self.optimizer.step(grad_scale=scale, grads=self.grad_sync.reduced(),
+                                    row_groups={self.nerf.encoder.embeddings: ex.table_groups})
+            else:
+                self.grad_sync.allreduce()
+                self.optimizer.step(grad_scale=scale)
             if self.train_step % self.cfg.log.save_interval == 0:
                 self.save_checkpoint(full=True)
                 self.evaluate(self.dataloaders["val"], self.eval_renders_path)

@@ -534,12 +534,16 @@ def occupancy_cell_points(indices: torch.Tensor, cascade_level: int, G: int, bou
 
 def update_density_grid(grid: torch.Tensor, indices: torch.Tensor, cascade_level: int,
                         new_sigma: torch.Tensor, decay: float = 0.95) -> torch.Tensor:
-    """grid[c, idx] = max(grid[c, idx]*decay, new_sigma) for the sampled cells where both the old
-    and the new value are valid (>= 0)."""
+    """grid[c, idx] = max(grid[c, idx]*decay, s) for the sampled cells where both the old value and the new density
+    are valid (>= 0).  A cell that is listed several times (the refresh draws its cells with replacement) takes the
+    MAXIMUM of its new densities, decayed once: the result does not depend on the order of the list."""
     g = grid.clone()
-    old = g[cascade_level, indices]
-    upd = torch.maximum(old * decay, new_sigma)
-    g[cascade_level, indices] = torch.where((old >= 0) & (new_sigma >= 0), upd, old)
+    lvl = g[cascade_level]
+    ok = new_sigma >= 0
+    best = torch.full_like(lvl, -1.0)
+    best = best.scatter_reduce(0, indices[ok], new_sigma[ok], reduce="amax", include_self=True)
+    touched = (best >= 0) & (lvl >= 0)
+    g[cascade_level] = torch.where(touched, torch.maximum(lvl * decay, best), lvl)
     return g
 
 

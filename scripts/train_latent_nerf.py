@@ -16,7 +16,11 @@ from src.latent_nerf.training.trainer import Trainer  # noqa: E402
 
 
 def main(cfg: TrainConfig):
-    trainer = Trainer(cfg)
+    # one process per GPU (`python -m torch.distributed.run --nproc-per-node N -m scripts.train_latent_nerf ...`): bind the
+    # device and join the RCCL process group BEFORE anything touches the GPU; a plain `python -m ...` is one rank
+    from src.latent_nerf.training.distributed import init_distributed
+    rank, world, device = init_distributed()
+    trainer = Trainer(cfg, device=device)
     if cfg.log.eval_only:
         trainer.full_eval()
     else:

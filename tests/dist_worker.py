@@ -1,0 +1,52 @@
+"""One rank of the on-card data-parallel rehearsal (tests/test_gpu_distributed.py): trains a small latent-NeRF with the
+real Trainer on the HIP path, several ranks sharing ONE card through the gloo backend (LNERF_DIST_BACKEND=gloo), and
+writes checksums of its replica.  Launched with RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT set."""
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "latent-nerf-test_amd")):
+    sys.path.insert(0, p)
+
+
+def digest(t):
+    return hashlib.sha256(t.detach().contiguous().cpu().numpy().tobytes()).hexdigest()
+
+
+def main():
+    out_dir, groups, steps, precision = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    from src.latent_nerf.training.distributed import init_distributed
+    rank, world, dev = init_distributed()          # before anything touches the GPU
+    import torch
+    from src.latent_nerf.configs.train_config import TrainConfig, apply_overrides
+    from src.latent_nerf.training.trainer import Trainer
+    cfg = apply_overrides(TrainConfig(), {
+        "log.exp_name": "dp", "log.exp_root": os.path.join(out_dir, "exp"), "render.train_h": 32, "render.train_w": 32,
+        "render.eval_h": 32, "render.eval_w": 32, "render.grid_size": 64, "optim.iters": steps, "optim.lr": 5e-3,
+        "log.save_interval": 10000, "log.eval_size": 1, "optim.fp16": precision == "bf16", "guide.text": "a lego man",
+        "optim.views_per_step": world, "optim.exchange_groups": groups})
+    tr = Trainer(cfg, device=dev)
+    table0 = tr.nerf.encoder.embeddings.detach().clone()
+    tr.train()
+    torch.cuda.synchronize()
+    res = {"rank": rank, "world": world, "pipelined": bool(tr.pipelined), "steps": tr.train_step,
+           "iter_density": tr.nerf.iter_density,
+           "table": digest(tr.nerf.encoder.embeddings), "bitfield": digest(tr.nerf.density_bitfield),
+           "density_grid": digest(tr.nerf.density_grid), "mean_density": float(tr.nerf.mean_density_dev),
+           "mlp": [digest(getattr(tr.nerf, k)) for k in ("w1", "b1", "w2", "b2", "w3", "b3")],
+           "table_moved": float((tr.nerf.encoder.embeddings.detach() - table0).abs().max()),
+           "finite": bool(torch.isfinite(tr.nerf.encoder.embeddings).all()),
+           "bits_set": int(tr.nerf.density_bitfield.count_nonzero()),
+           "noise_seed": int(cfg.render.noise_seed)}
+    with open(os.path.join(out_dir, "rank%d.json" % rank), "w") as f:
+        json.dump(res, f)
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
