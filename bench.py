@@ -86,6 +86,9 @@ def parse():
     ap.add_argument("--probe-every", type=int, default=8)
     ap.add_argument("--grad-transport", default="auto", choices=["auto", "f32", "bf16"],
                     help="dtype of the table-gradient all-reduce at N > 1 (auto: follows --precision)")
+    ap.add_argument("--exchange-groups", type=int, default=4,
+                    help="N > 1, bf16 on the wire: level groups the table gradient is exchanged in, each group's all-reduce "
+                         "launched behind its own sums (0 = one collective after the whole scatter)")
     return ap.parse_args()
 
 
@@ -113,13 +116,17 @@ def build(dev, precision, variant, rank, table="f32", jitter_rng="kernel"):
     return net, pose, intr, bg, grad
 
 
-def make_step(net, pose, intr, bg, grad, opt, world, transport=torch.float32, perturb=True):
+def make_step(net, pose, intr, bg, grad, opt, world, transport=torch.float32, perturb=True, exchange_groups=0):
     """Returns (eager_step, fwd_bwd, opt_step, sync)."""
     from src.latent_nerf.raymarching import raymarching as rm
     from src.latent_nerf.training.distributed import GradSync
     small = [p for p in net.parameters() if p is not net.encoder.embeddings]
     sync = GradSync([net.encoder.embeddings], small, transport=transport)
-    sync.attach_sink(net.encoder)        # N > 1 with bf16 on the wire: backward writes the wire buffer directly
+    # N > 1 with bf16 on the wire: backward writes the wire buffer directly; with exchange_groups >= 1 it only bins the
+    # scatter records and the exchange sums + sends one level group at a time (GradSync.allreduce_pipelined)
+    sink = sync.attach_sink(net.encoder, pipeline_groups=exchange_groups)
+    pipelined = sink is not None and sink.groups is not None
+    state = {}
 
     def fwd_bwd():
         rays_o, rays_d = rm.get_rays(pose, intr, H, W)
@@ -129,10 +136,18 @@ def make_step(net, pose, intr, bg, grad, opt, world, transport=torch.float32, pe
         return out
 
     def allreduce():
-        sync.allreduce(copy_back=False)  # no-op at world size 1; bf16 sums stay in the wire buffer
+        if pipelined:
+            state["ex"] = sync.allreduce_pipelined()
+            state["ex"].finish_small()
+        else:
+            sync.allreduce(copy_back=False)  # no-op at world size 1; bf16 sums stay in the wire buffer
 
     def opt_step():
-        opt.step(grad_scale=1.0 / world, grads=sync.reduced() if world > 1 else None)
+        if pipelined:   # the optimiser waits for a level group's all-reduce right before it steps those rows
+            opt.step(grad_scale=1.0 / world, grads=sync.reduced(),
+                     row_groups={net.encoder.embeddings: state.pop("ex").table_groups})
+        else:
+            opt.step(grad_scale=1.0 / world, grads=sync.reduced() if world > 1 else None)
 
     def step():
         out = fwd_bwd()
@@ -334,10 +349,12 @@ def main():
                     fuse_table_update=fuse)
     opt.grad_scale = 1.0 / world
     tr = args.precision if args.grad_transport == "auto" else args.grad_transport
+    groups = args.exchange_groups if (world > 1 and tr == "bf16") else 0
     scatter_call = ("lnerf_grid_encode_backward_adam" if fuse else
+                    "lnerf_grid_scatter_bin" if groups else
                     "lnerf_grid_encode_backward_bf16" if (world > 1 and tr == "bf16") else "lnerf_grid_encode_backward")
     step, fwd_bwd, opt_step, sync = make_step(net, pose, intr, bg, grad, opt, world,
-                                              torch.bfloat16 if tr == "bf16" else torch.float32, bool(args.perturb))
+                                              torch.bfloat16 if tr == "bf16" else torch.float32, bool(args.perturb), groups)
 
     def barrier():
         if world > 1:
@@ -351,14 +368,15 @@ def main():
         from src.latent_nerf.training.graph_step import GraphedTrainStep
         # (a capture failure raises: the line must not silently describe eager launches; use --graph 0 for those)
         gstep = GraphedTrainStep(fwd_bwd, opt_step, list(net.parameters()), sync=sync, world=world, warmup=3,
-                                 stream=main_stream)
+                                 stream=main_stream, opt_in_graph=not groups)
         launch = "hipgraph"
     emb0 = net.encoder.embeddings.detach().clone()
     for i in range(args.warmup):
         (gstep if (gstep is not None and i % 2) else step)()
     torch.cuda.synchronize()
     log("warm-up done (%s)" % launch)
-    timer = KernelTimer(["lnerf_grid_encode_forward", scatter_call, "lnerf_mlp_forward", "lnerf_mlp_backward"])
+    timer = KernelTimer(["lnerf_grid_encode_forward", scatter_call, "lnerf_mlp_forward", "lnerf_mlp_backward",
+                         "lnerf_grid_scatter_reduce_bf16"])
     barrier()
     t0 = time.perf_counter()
     n_probe = 0
@@ -423,6 +441,9 @@ def main():
             raise SystemExit("no eager probe step ran inside the timed region (lower --probe-every)")
         g_ms = timer.mean_ms("lnerf_grid_encode_forward")
         s_ms = timer.mean_ms(scatter_call)
+        if groups:   # pipelined exchange: pass 1 in the backward pass + pass 2 once per level group (collectives in between)
+            s_ms += timer.mean_ms("lnerf_grid_scatter_reduce_bf16") * len(timer.pairs["lnerf_grid_scatter_reduce_bf16"]) \
+                / max(n_probe, 1)
         achieved = M * bytes_per_sample / (g_ms * 1e-3) / 1e9
         scatter = M * 1164 / (s_ms * 1e-3) / 1e9 if s_ms > 0 else None
         build_tag = B.get_lib().lnerf_build_info().decode()
@@ -460,14 +481,16 @@ def main():
                                    "L=16 F=2 T=2^19, 1 view/GPU/step, fwd+bwd+grad all-reduce+Adam",
                        "rays_per_view": H * W, "samples_per_view": M, "sample_capacity": BENCH_CAPACITY,
                        "views_per_step": world,
-                       "parallelism": "dp%d (1 view per GPU, RCCL all-reduce of gradients, %s on the wire)" % (world, tr)},
+                       "parallelism": "dp%d (1 view per GPU, RCCL all-reduce of gradients, %s on the wire%s)"
+                                      % (world, tr, ", table in %d pipelined level groups" % groups if groups else "")},
             "roofline": {"kernel": "k_grid_forward (hash-grid gather, H5)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "bytes_per_sample": bytes_per_sample, "samples_per_launch": M, "kernel_ms": g_ms},
             "mfma": mfma,
             "scatter": {"kernel": scatter_call.replace("lnerf_", "") + " (H6: two-pass bucketed scatter"
                                   + (" + fused Adam step of the table)" if fuse else
-                                     ", gradient written in the bf16 wire format)" if scatter_call.endswith("bf16") else ")"),
+                                     ", gradient written in the bf16 wire format)" if scatter_call.endswith("bf16") else
+                                     " + grid_scatter_reduce_bf16 per level group: pipelined exchange)" if groups else ")"),
                         "algorithmic_GBps": scatter, "kernel_ms": s_ms},
         }
         if breakdown:

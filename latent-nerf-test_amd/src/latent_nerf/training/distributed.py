@@ -189,8 +189,7 @@ class GradSync:
             rows = sink.wire[offs[lo]:offs[hi]]
             work = dist.all_reduce(rows, group=self.group, async_op=True) if self.world > 1 else None
             groups.append((offs[lo], offs[hi], work))
-        sink.pending = None
-        sink.written += 1
+        sink.written += 1     # (`pending` stays: a replayed hipGraph bins again without running any Python)
         small_work, flat = None, None
         if self.small:
             flat = self._flat_buffer()

@@ -10,13 +10,17 @@ import torch
 
 
 class GraphedTrainStep:
-    def __init__(self, fwd_bwd, opt_step, params, sync=None, world=1, warmup=3, stream=None):
+    def __init__(self, fwd_bwd, opt_step, params, sync=None, world=1, warmup=3, stream=None, opt_in_graph=True):
         """fwd_bwd() -> dict of output tensors (leaves `.grad` set on `params`);
         opt_step() consumes the gradients; sync() all-reduces `.grad` in place (world > 1).
 
         Run the whole training loop (eager steps included) on ONE non-default stream and pass it as
         `stream` (or make it current): autograd pins each parameter's gradient accumulation to the stream
-        it first ran on, and accumulation on the legacy default stream cannot be captured."""
+        it first ran on, and accumulation on the legacy default stream cannot be captured.
+
+        opt_in_graph=False (world > 1, pipelined exchange): the optimiser step stays eager -- it waits for one level
+        group's all-reduce at a time (FusedAdam.step(row_groups=...)), which a captured graph cannot express."""
+        self.opt_step = opt_step
         self.world = world
         self.sync = sync
         self.params = list(params)
@@ -47,9 +51,12 @@ class GraphedTrainStep:
             with torch.cuda.graph(self.graph_a, stream=stream):
                 self.out = fwd_bwd()
             self.static_grads = [p.grad for p in self.params]
-            self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), stream=stream):
-                opt_step()
+            if opt_in_graph:
+                self.graph_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), stream=stream):
+                    opt_step()
+            else:
+                self.graph_b = False
         for p in self.params:
             p.grad = None
 
@@ -60,7 +67,10 @@ class GraphedTrainStep:
                 p.grad = g
             if self.sync is not None:
                 self.sync()
-            self.graph_b.replay()
+            if self.graph_b is False:
+                self.opt_step()
+            else:
+                self.graph_b.replay()
             for p in self.params:
                 p.grad = None
         return self.out
