@@ -160,6 +160,14 @@ template <> struct CellRaw<uint16_t> {
     __device__ __forceinline__ void load_one(const uint16_t *lt, uint32_t row, int c) {
         d[c] = reinterpret_cast<const uint32_t *>(lt)[row];
     }
+    // rows r0, r1 of ONE aligned group of four rows (16 bytes) with one load -> c, c + 1
+    __device__ __forceinline__ void load_quad(const uint16_t *lt, uint32_t r0, uint32_t r1, int c) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(lt + (int64_t)(r0 & ~3u) * 2);
+        const uint32_t k0 = r0 & 3u, k1 = r1 & 3u;
+        d[c] = (k0 & 2u) ? ((k0 & 1u) ? v.w : v.z) : ((k0 & 1u) ? v.y : v.x);
+        d[c + 1] = (k1 & 2u) ? ((k1 & 1u) ? v.w : v.z) : ((k1 & 1u) ? v.y : v.x);
+    }
+    static constexpr bool kHasQuad = true;
     __device__ __forceinline__ void swap_pair(int c) { const uint32_t t = d[c]; d[c] = d[c + 1]; d[c + 1] = t; }
     __device__ __forceinline__ void zero() {
 #pragma unroll
@@ -182,6 +190,8 @@ template <> struct CellRaw<float> {
     __device__ __forceinline__ void load_one(const float *lt, uint32_t row, int c) {
         d[c] = reinterpret_cast<const float2 *>(lt)[row];
     }
+    __device__ __forceinline__ void load_quad(const float *, uint32_t, uint32_t, int) {}   // (32 bytes: not used)
+    static constexpr bool kHasQuad = false;
     __device__ __forceinline__ void swap_pair(int c) { const float2 t = d[c]; d[c] = d[c + 1]; d[c + 1] = t; }
     __device__ __forceinline__ void zero() {
 #pragma unroll
@@ -197,16 +207,34 @@ template <> struct CellRaw<float> {
     __device__ __forceinline__ float2 get(int c) const { return d[c]; }
 };
 
+// variant 2: every XCD serves a fixed SET of levels (workgroups are dealt round-robin over the 8 XCDs -- observed, used
+// for speed only): the 4 MiB L2 of an XCD then holds the whole table of its one fine level (2 MiB bf16) instead of a
+// sixth of all sixteen, and the gather -- bound by the L1's miss concurrency x the latency of a miss -- waits for L2 hits
+// instead of Infinity-Cache hits.  The sets are balanced on the host from a per-level cost estimate.
+struct XcdPlan {
+    int n[8];
+    int lv[8][LNERF_MAX_LEVELS / 8 + 2];
+};
+
 template <typename TT, typename TO>
 __global__ void __launch_bounds__(256)
 k_grid_forward(const float *__restrict__ xyzs, float bound, const TT *__restrict__ table, GridMeta meta, int64_t m_host,
                const int32_t *__restrict__ m_dev, int64_t level_stride, TO *__restrict__ feat, int variant,
-               int pair_loads, int dedup_max_res) {
+               int pair_loads, int dedup_max_res, XcdPlan plan) {
     int64_t M = m_host;
     if (m_dev) { const int64_t md = *m_dev; M = md < M ? md : M; }
-    const TileMap tm = tile_map(variant, meta.num_levels);
+    TileMap tm = tile_map(variant == 2 ? 0 : variant, meta.num_levels);
+    int n_lv = 1;
+    const int xcd = blockIdx.x & 7;
+    if (variant == 2) {
+        n_lv = plan.n[xcd];
+        tm.tile0 = blockIdx.x >> 3;
+        tm.tstep = gridDim.x >> 3;
+        tm.ok = true;
+    }
     if (!tm.ok) return;
-    const int l = tm.level;
+  for (int li = 0; li < n_lv; ++li) {
+    const int l = variant == 2 ? plan.lv[xcd][li] : tm.level;
     const float scale = meta.scales[l];
     const uint32_t res = (uint32_t)meta.res[l];
     const uint32_t off = (uint32_t)meta.offsets[l];
@@ -241,6 +269,11 @@ k_grid_forward(const float *__restrict__ xyzs, float bound, const TT *__restrict
             if (pair_loads && dense) {
 #pragma unroll
                 for (int c = 0; c < 8; c += 2) cell.load_pair(lt, rows[c], c);  // rows[c+1] == rows[c] + 1
+            } else if (pair_loads == 2 && CellRaw<TT>::kHasQuad && pow2 && (p.gx & 3u) != 3u) {
+                // hashed, x mod 4 != 3: both x-neighbours sit in one aligned group of four rows (row = x ^ h: the group
+                // is (x ^ h) & ~3) -- one 16-byte access instead of one 8-byte or two 4-byte ones
+#pragma unroll
+                for (int c = 0; c < 8; c += 2) cell.load_quad(lt, rows[c], rows[c + 1], c);
             } else if (pair_loads && pow2 && !(p.gx & 1u)) {
                 // hashed, x even: the two x-neighbours are the two halves of one aligned pair
 #pragma unroll
@@ -268,6 +301,7 @@ k_grid_forward(const float *__restrict__ xyzs, float bound, const TT *__restrict
         }
         if (valid) Feat2<TO>::store(feat, (int64_t)l * level_stride + m, a0, a1);
     }
+  }
 }
 
 // Backward, variant 0: one (sample, level) per thread, 16 global float atomics each.
@@ -814,11 +848,12 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restri
 
 // Pass 2.  LDS float atomics run at ~0.5 lane/clk on gfx950 while integer LDS atomics run at the
 // plain-store rate (measured: profiles/README.md, "reduce_dbg"), so the tile accumulates in 64-bit
-// FIXED POINT: every value is scaled by a power of two chosen from the level's largest |value|
-// (found by pass 1) so that |q| < 2^44, which leaves 2^17 additions of head-room in an int64.  The
-// scaling is exact, the integer sum is exact and order-independent, and the only rounding is the
-// quantisation of each addend to 2^-45 of the bucket maximum plus one final conversion to f32:
-// the result is bitwise reproducible and at least as accurate as an f32 running sum.
+// FIXED POINT: every value is scaled by a power of two chosen from the level's bound of |value|
+// (found by pass 1) so that |q| < 2^44 (12-byte records; 2^30 with the 8-byte ones, see fix_scale), which leaves
+// 2^19 additions of head-room in an int64.  The scaling is exact, the integer sum is exact and
+// order-independent, and the only rounding is the quantisation of each addend to 2^-45 (2^-31) of the
+// level's bound plus one final conversion to f32: the result is bitwise reproducible; with the 12-byte
+// records it is at least as accurate as an f32 running sum.
 // records per slice workgroup of pass 2 (a bucket with fewer records is reduced by one workgroup)
 constexpr int REDUCE_SLICE_RECS = 16384;
 
@@ -833,21 +868,29 @@ struct FusedUpdate {
                          // format of the data-parallel all-reduce: no zero fill, no read-modify-write, no cast)
 };
 
-// power-of-two scale of a level's fixed-point sums: largest |value| < 2^(e-126) -> scale 2^(170-e) puts it below
-// 2^44 (2^17 additions of head-room in an int64); split so that both factors are normal floats
+// power-of-two scale of a level's fixed-point sums: |value| < 2^(e-126) (e = biased exponent of the level's bound
+// found by pass 1) is scaled by 2^(BITS+126-e), which puts every addend below 2^BITS; split so that both factors are
+// normal floats.  BITS = 44 (exact 12-byte records: quantum 2^-44 of the bound, 2^19 additions of head-room in an
+// int64, conversion through the 64-bit software path) or 30 (8-byte records, whose values carry 17 mantissa bits
+// anyway: quantum 2^-30 of the bound, conversion with the native v_cvt_i32_f32, a third of the pass's vector work).
 struct FixScale {
     float sc_a, sc_b, un_a, un_b;
 };
+template <int BITS>
 __device__ __forceinline__ FixScale fix_scale(unsigned int gmax_bits) {
     int e = (int)(gmax_bits >> 23);
     e = e < 1 ? 1 : (e > 254 ? 254 : e);
-    int k = 170 - e;
+    int k = BITS + 126 - e;
     k = k > 200 ? 200 : k;
     FixScale f;
     f.sc_a = ldexpf(1.0f, k / 2); f.sc_b = ldexpf(1.0f, k - k / 2);
     f.un_a = ldexpf(1.0f, -(k / 2)); f.un_b = ldexpf(1.0f, -(k - k / 2));
     return f;
 }
+template <typename REC> struct FixBits { static constexpr int kBits = REC::kPacked ? 30 : 44; };
+template <int BITS> __device__ __forceinline__ long long to_fixed(float x);
+template <> __device__ __forceinline__ long long to_fixed<44>(float x) { return __float2ll_rn(x); }
+template <> __device__ __forceinline__ long long to_fixed<30>(float x) { return (long long)__float2int_rn(x); }  // |x| < 2^30
 // slices a bucket with n records is cut into (decided on the device from the actual count; the launch provides
 // `smax` workgroups per bucket for the worst case)
 __device__ __forceinline__ int active_slices(int n, int smax) {
@@ -882,7 +925,8 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
     const int lo = (int)(((long long)n * s) / S), hi = (int)(((long long)n * (s + 1)) / S);
     const bool have = hi > lo;  // uniform
     if (!have && !fuse) return;  // (a fused bucket without records still owes its rows the Adam step, g = 0)
-    const FixScale fs = fix_scale(gmax[l]);  // from the largest |value| of the LEVEL (found by pass 1)
+    constexpr int FB = FixBits<REC>::kBits;
+    const FixScale fs = fix_scale<FB>(gmax[l]);  // from the bound of |value| of the LEVEL (found by pass 1)
     const int tid = threadIdx.x;
     const int hsize = meta.offsets[l + 1] - meta.offsets[l];
     const int row0 = b << BK_SHIFT;
@@ -896,8 +940,8 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
         unsigned long long *ua = reinterpret_cast<unsigned long long *>(acc);
         auto add = [&](const REC &r) {
             const uint32_t a0 = r.row_in_bucket();
-            atomicAdd(&ua[a0], (unsigned long long)__float2ll_rn((r.a() * fs.sc_a) * fs.sc_b));
-            atomicAdd(&ua[a0 + BK_ROWS], (unsigned long long)__float2ll_rn((r.b() * fs.sc_a) * fs.sc_b));
+            atomicAdd(&ua[a0], (unsigned long long)to_fixed<FB>((r.a() * fs.sc_a) * fs.sc_b));
+            atomicAdd(&ua[a0 + BK_ROWS], (unsigned long long)to_fixed<FB>((r.b() * fs.sc_a) * fs.sc_b));
         };
         // the pass waits on its record loads (rocprofv3: 82 % of wave cycles parked): keep four loads in flight
         // per lane
@@ -1000,7 +1044,7 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
 
 // Finishing pass of the sliced levels: one thread per table row adds the active slices' exact partial sums
 // (k_scatter_reduce), converts once and adds the result to dtable -- or applies the Adam step (FUSE).
-template <bool FUSE>
+template <bool FUSE, int FB>
 __global__ void __launch_bounds__(256)
 k_scatter_finish(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ cursor, const unsigned int *__restrict__ gmax,
                  const long long *__restrict__ partials, float *__restrict__ dtable, FusedUpdate fu, int lv_lo, int lv_hi) {
@@ -1026,7 +1070,7 @@ k_scatter_finish(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
         q0 += pt[(int64_t)s * (BK_ROWS * 2) + r];
         q1 += pt[(int64_t)s * (BK_ROWS * 2) + BK_ROWS + r];
     }
-    const FixScale fs = fix_scale(gmax[l]);
+    const FixScale fs = fix_scale<FB>(gmax[l]);
     float g0 = ((float)q0 * fs.un_a) * fs.un_b, g1 = ((float)q1 * fs.un_a) * fs.un_b;
     const int64_t R = (int64_t)meta.offsets[l] + row0 + r;
     float2 *d2 = reinterpret_cast<float2 *>(dtable) + R;
@@ -1064,8 +1108,10 @@ extern int g_mlp_fwd_blocks;  // mlp.hip
 
 // levels up to this resolution merge per-wave runs before binning (tunable: lnerf_set_tuning)
 static int g_compact_max_res = 512;
-// gather: fetch x-adjacent vertices with one load where they are adjacent rows
-static int g_gather_pairs = 1;
+// gather: fetch x-adjacent vertices with one load where they are adjacent rows (2: also aligned groups of four rows)
+static int g_gather_pairs = 2;
+// gather variant 2: workgroups per XCD (each strides over the tiles of its XCD's levels)
+static int g_gather_wgs_per_xcd = 256;
 // gather: levels with resolution <= this fetch a cell's vertices once per run of lanes in that cell (0 = off)
 static int g_gather_dedup_res = 512;
 // persistent workgroups of the binning pass per CU (3 fit its 44 KiB of LDS with the 8-byte records)
@@ -1186,18 +1232,41 @@ int lnerf_grid_encode_forward(const float *xyzs, float bound, const void *table,
     if (rc) return rc;
     LNERF_REQUIRE(m_host >= 0 && level_stride >= m_host, "grid_encode_forward: need 0 <= m_host <= level_stride");
     LNERF_REQUIRE(bound > 0.f, "grid_encode_forward: bound must be > 0");
-    LNERF_REQUIRE(variant == 0 || variant == 1, "grid_encode_forward: unknown variant %d", variant);
+    LNERF_REQUIRE(variant >= 0 && variant <= 2, "grid_encode_forward: unknown variant %d", variant);
     LNERF_REQUIRE((table_dtype == LNERF_F32 || table_dtype == LNERF_BF16) &&
                       (feat_dtype == LNERF_F32 || feat_dtype == LNERF_BF16),
                   "grid_encode_forward: bad dtype tag");
     if (m_host == 0) return LNERF_OK;
     LNERF_REQUIRE(xyzs && table && feat, "grid_encode_forward: null pointer");
     dim3 grid;
-    launch_dims(variant, num_levels, m_host, grid);
+    launch_dims(variant == 2 ? 0 : variant, num_levels, m_host, grid);
+    XcdPlan plan;
+    memset(&plan, 0, sizeof(plan));
+    if (variant == 2) {
+        // longest-processing-time assignment of levels to XCDs; cost ~ cache lines a sample touches on the level
+        double cost[LNERF_MAX_LEVELS], load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int order[LNERF_MAX_LEVELS];
+        for (int l = 0; l < num_levels; ++l) {
+            const double r = (double)res_host[l];
+            cost[l] = res_host[l] > g_gather_dedup_res ? 1.0 : (r < 64 ? 0.05 : r / (double)(g_gather_dedup_res > 0 ? g_gather_dedup_res : 512) * 0.9);
+            order[l] = l;
+        }
+        for (int a = 0; a < num_levels; ++a)
+            for (int b = a + 1; b < num_levels; ++b)
+                if (cost[order[b]] > cost[order[a]]) { const int t = order[a]; order[a] = order[b]; order[b] = t; }
+        for (int a = 0; a < num_levels; ++a) {
+            int best = -1;
+            for (int x = 0; x < 8; ++x)
+                if (plan.n[x] < LNERF_MAX_LEVELS / 8 + 2 && (best < 0 || load[x] < load[best])) best = x;
+            plan.lv[best][plan.n[best]++] = order[a];
+            load[best] += cost[order[a]];
+        }
+        grid = dim3((unsigned)(8 * g_gather_wgs_per_xcd), 1, 1);
+    }
     hipStream_t s = as_stream(stream);
 #define LAUNCH_FWD(TT, TO)                                                                                         \
     hipLaunchKernelGGL((k_grid_forward<TT, TO>), grid, dim3(256), 0, s, xyzs, bound, (const TT *)table, meta, m_host, \
-                       m_dev, level_stride, (TO *)feat, variant, g_gather_pairs, g_gather_dedup_res)
+                       m_dev, level_stride, (TO *)feat, variant, g_gather_pairs, g_gather_dedup_res, plan)
     if (table_dtype == LNERF_F32 && feat_dtype == LNERF_F32) LAUNCH_FWD(float, float);
     else if (table_dtype == LNERF_F32) LAUNCH_FWD(float, uint16_t);
     else if (feat_dtype == LNERF_F32) LAUNCH_FWD(uint16_t, float);
@@ -1229,8 +1298,14 @@ int lnerf_set_tuning(const char *key, int value) {
         g_gather_dedup_res = value;
         return LNERF_OK;
     }
+    if (strcmp(key, "gather_wgs_per_xcd") == 0) {
+        LNERF_REQUIRE(value >= 1 && value <= 4096, "set_tuning: gather_wgs_per_xcd out of range");
+        g_gather_wgs_per_xcd = value;
+        return LNERF_OK;
+    }
     if (strcmp(key, "gather_pair_loads") == 0) {
-        g_gather_pairs = value ? 1 : 0;
+        LNERF_REQUIRE(value >= 0 && value <= 2, "set_tuning: gather_pair_loads must be 0, 1 or 2");
+        g_gather_pairs = value;
         return LNERF_OK;
     }
     if (strcmp(key, "mlp_fwd_blocks") == 0) {
@@ -1359,12 +1434,14 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
     auto launch_finish = [&]() {  // sliced levels: add up the slices' exact partial sums
         if (plan.fbuckets == 0) return;
         const dim3 g((unsigned)(plan.fbuckets * (BK_ROWS / 256)));
-        if (fu)
-            hipLaunchKernelGGL(k_scatter_finish<true>, g, dim3(256), 0, s, meta, bm, cursor, gmax, partials, dtable, fu0,
-                               lv_lo, lv_hi);
-        else
-            hipLaunchKernelGGL(k_scatter_finish<false>, g, dim3(256), 0, s, meta, bm, cursor, gmax, partials, dtable, fu0,
-                               lv_lo, lv_hi);
+#define LAUNCH_FIN(FUSE, FB)                                                                                        \
+    hipLaunchKernelGGL((k_scatter_finish<FUSE, FB>), g, dim3(256), 0, s, meta, bm, cursor, gmax, partials, dtable, fu0,   \
+                       lv_lo, lv_hi)
+        if (fu && packed) LAUNCH_FIN(true, 30);
+        else if (fu) LAUNCH_FIN(true, 44);
+        else if (packed) LAUNCH_FIN(false, 30);
+        else LAUNCH_FIN(false, 44);
+#undef LAUNCH_FIN
     };
     if (phases & 1) {
         launch_bin();

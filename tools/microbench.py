@@ -63,15 +63,27 @@ def main():
         f32o = torch.empty(16, cap, 2, device=dev)
         bf16o = torch.empty(16, cap, 2, device=dev, dtype=torch.bfloat16)
         fns = {}
-        for dd in (0, 64, 128, 256, 512):
-            def mk(tab, out, dd=dd):
+        for dd, pl in ((512, 1), (512, 2)):
+            def mk(tab, out, dd=dd, pl=pl):
                 def f():
                     B.call("lnerf_set_tuning", b"gather_dedup_max_res", dd)
+                    B.call("lnerf_set_tuning", b"gather_pair_loads", pl)
                     E.grid_encode_forward(xyzs, 1.0, tab, levels, cap, m_dev, cap, out, variant=0)
                 return f
-            fns["f32tab_bf16out_dedup%d" % dd] = mk(table, bf16o)
-            fns["bf16tab_bf16out_dedup%d" % dd] = mk(table_bf, bf16o)
+            fns["f32tab_bf16out_dedup%d_pairs%d" % (dd, pl)] = mk(table, bf16o)
+            fns["bf16tab_bf16out_dedup%d_pairs%d" % (dd, pl)] = mk(table_bf, bf16o)
+        for wg in (64, 128, 256, 512):
+            def mk2(tab, out, wg=wg):
+                def f():
+                    B.call("lnerf_set_tuning", b"gather_dedup_max_res", 512)
+                    B.call("lnerf_set_tuning", b"gather_pair_loads", 1)
+                    B.call("lnerf_set_tuning", b"gather_wgs_per_xcd", wg)
+                    E.grid_encode_forward(xyzs, 1.0, tab, levels, cap, m_dev, cap, out, variant=2)
+                return f
+            fns["bf16tab_bf16out_xcdsets_wg%d" % wg] = mk2(table_bf, bf16o)
+            fns["f32tab_bf16out_xcdsets_wg%d" % wg] = mk2(table, bf16o)
         t = timed(fns)
+        B.call("lnerf_set_tuning", b"gather_pair_loads", 1)
         res["gather_ms(median,min)"] = t
         bps = lambda k: (1024 if k.startswith("f32tab") else 512) + 12 + (128 if "f32out" in k else 64)
         res["gather_GBps_algorithmic"] = {k: round(M * bps(k) / (v[0] * 1e-3) / 1e9, 1) for k, v in t.items()}
@@ -94,13 +106,11 @@ def main():
         res["dfeat_zero_fraction"] = float((dfeat[:, :M, :] == 0).all(-1).float().mean())
         dtable = torch.zeros_like(table)
         fns = {}
-        for spt in (1, 2):
-            def f(spt=spt):
-                B.call("lnerf_set_tuning", b"scatter_bin_spt", spt)
-                E.grid_encode_backward(xyzs, 1.0, dfeat, levels, cap, m_dev, cap, dtable, variant=3)
-            fns["variant3_spt%d" % spt] = f
+        for v in (2, 3):
+            def f(v=v):
+                E.grid_encode_backward(xyzs, 1.0, dfeat, levels, cap, m_dev, cap, dtable, variant=v)
+            fns["variant%d" % v] = f
         t = timed(fns, rounds=10)
-        B.call("lnerf_set_tuning", b"scatter_bin_spt", 1)
         res["scatter_ms(median,min)"] = t
 
     if "update" in which:
