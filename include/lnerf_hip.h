@@ -196,11 +196,13 @@ int lnerf_grid_encode_backward_adam(const float *xyzs, float bound, const void *
 /* ---- H7: fused sigma/latent MLP  32 -> 64 -> 64 -> out_dim (= 1 + C), ReLU hidden.
  * Weights are PyTorch nn.Linear layout: w1 [64,32], b1 [64], w2 [64,64], b2 [64], w3 [out_dim,64],
  * b3 [out_dim], all f32.  sigma = exp(h0 + blob_scale*exp(-|x|^2/(2 blob_std^2))), rgbs = h[1:].
- * precision: LNERF_F32 -> exact-f32 MFMA (v_mfma_f32_16x16x4_f32), LNERF_BF16 -> bf16 MFMA, f32 acc. */
+ * precision: LNERF_F32 -> exact-f32 MFMA (v_mfma_f32_16x16x4_f32), LNERF_BF16 -> bf16 MFMA, f32 acc.
+ * workspace (optional, 16-byte aligned, >= 32 KiB; the buffer of lnerf_mlp_backward_workspace_bytes() serves): with
+ * it the bf16 path builds its weight fragments once per launch instead of once per workgroup. */
 int lnerf_mlp_forward(const void *feat, int feat_dtype, int64_t level_stride, const float *xyzs, const float *w1,
                       const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, int out_dim,
                       float blob_scale, float blob_std, int64_t m_host, const int32_t *m_dev, float *sigmas,
-                      float *rgbs, int precision, lnerf_stream_t stream);
+                      float *rgbs, int precision, void *workspace, size_t workspace_bytes, lnerf_stream_t stream);
 /* Recomputes the hidden activations.  dfeat is written (level-major, f32); the d* parameter gradients
  * are accumulated (accumulate != 0: +=) or overwritten (accumulate == 0) deterministically:
  * per-workgroup partial slabs in `workspace` (lnerf_mlp_backward_workspace_bytes()) followed by one

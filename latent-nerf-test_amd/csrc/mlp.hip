@@ -380,6 +380,7 @@ k_mlp_reduce_slabs(const float *__restrict__ slabs, int n_slabs, int out_dim, in
 }
 
 int g_mlp_fwd_blocks = 512;
+int g_mlp_fwd_wps = 2;   // wavefronts per SIMD the bf16 forward is compiled for (2 or 4)
 
 static int mlp_common_checks(const char *who, const void *feat, int feat_dtype, int64_t level_stride, const float *xyzs,
                              const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
@@ -402,19 +403,26 @@ extern "C" {
 int lnerf_mlp_forward(const void *feat, int feat_dtype, int64_t level_stride, const float *xyzs, const float *w1,
                       const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, int out_dim,
                       float blob_scale, float blob_std, int64_t m_host, const int32_t *m_dev, float *sigmas,
-                      float *rgbs, int precision, lnerf_stream_t stream) {
+                      float *rgbs, int precision, void *workspace, size_t workspace_bytes, lnerf_stream_t stream) {
     int rc = mlp_common_checks("mlp_forward", feat, feat_dtype, level_stride, xyzs, w1, b1, w2, b2, w3, b3, out_dim,
                                blob_std, m_host, precision);
     if (rc) return rc;
     if (m_host == 0) return LNERF_OK;
     LNERF_REQUIRE(sigmas && rgbs, "mlp_forward: null output");
     MlpArgs a{feat, feat_dtype == LNERF_BF16, level_stride, xyzs, w1, b1, w2, b2, w3, b3, out_dim, blob_scale,
-              2.0f * blob_std * blob_std, m_host, m_dev};
+              2.0f * blob_std * blob_std, m_host, m_dev, nullptr};
     if (precision == LNERF_BF16) {
-        // persistent workgroups: each builds the weight fragments once and then walks ~M/128/blocks tiles
+        // persistent workgroups walk ~M/128/blocks tiles each; with a workspace the weight fragments are built once per
+        // launch (first MLP_FRAG_BYTES of it) instead of once per workgroup
         int64_t blocks = div_up(m_host, 128);
         if (blocks > g_mlp_fwd_blocks) blocks = g_mlp_fwd_blocks;
-        return launch_mlp_forward_bf16(a, sigmas, rgbs, (int)blocks, as_stream(stream));
+        if (workspace && workspace_bytes >= MLP_FRAG_BYTES) {
+            LNERF_REQUIRE(((uintptr_t)workspace & 15) == 0, "mlp_forward: workspace must be 16-byte aligned");
+            const int rcf = launch_mlp_fragments_bf16(a, workspace, false, as_stream(stream));
+            if (rcf) return rcf;
+            a.frag_global = workspace;
+        }
+        return launch_mlp_forward_bf16(a, sigmas, rgbs, (int)blocks, g_mlp_fwd_wps, as_stream(stream));
     }
     int64_t blocks = div_up(m_host, 64);
     if (blocks > 1024) blocks = 1024;
@@ -425,7 +433,7 @@ int lnerf_mlp_forward(const void *feat, int feat_dtype, int64_t level_stride, co
 
 size_t lnerf_mlp_backward_workspace_bytes(int out_dim) {
     (void)out_dim;
-    return (size_t)BWD_MAX_BLOCKS * SLAB * sizeof(float);
+    return MLP_FRAG_BYTES + (size_t)BWD_MAX_BLOCKS * SLAB * sizeof(float);  // fragment cache, then the slabs
 }
 
 int lnerf_mlp_backward(const void *feat, int feat_dtype, int64_t level_stride, const float *xyzs, const float *w1,
@@ -443,21 +451,26 @@ int lnerf_mlp_backward(const void *feat, int feat_dtype, int64_t level_stride, c
     LNERF_REQUIRE(workspace && workspace_bytes >= lnerf_mlp_backward_workspace_bytes(out_dim),
                   "mlp_backward: workspace too small (%zu < %zu)", workspace_bytes,
                   lnerf_mlp_backward_workspace_bytes(out_dim));
+    LNERF_REQUIRE(((uintptr_t)workspace & 15) == 0, "mlp_backward: workspace must be 16-byte aligned");
     MlpArgs a{feat, feat_dtype == LNERF_BF16, level_stride, xyzs, w1, b1, w2, b2, w3, b3, out_dim, blob_scale,
-              2.0f * blob_std * blob_std, m_host, m_dev};
+              2.0f * blob_std * blob_std, m_host, m_dev, nullptr};
     int64_t blocks = div_up(m_host, precision == LNERF_BF16 ? 128 : 64);
     if (blocks > BWD_MAX_BLOCKS) blocks = BWD_MAX_BLOCKS;
     hipStream_t s = as_stream(stream);
+    float *slabs = reinterpret_cast<float *>(static_cast<char *>(workspace) + MLP_FRAG_BYTES);
     if (precision == LNERF_BF16) {
-        int rc2 = launch_mlp_backward_bf16(a, sigmas, dsigmas, drgbs, dfeat, (float *)workspace, (int)blocks, s);
+        int rc2 = launch_mlp_fragments_bf16(a, workspace, true, s);   // once per launch, not once per workgroup
+        if (rc2) return rc2;
+        a.frag_global = workspace;
+        rc2 = launch_mlp_backward_bf16(a, sigmas, dsigmas, drgbs, dfeat, slabs, (int)blocks, s);
         if (rc2) return rc2;
     } else {
         hipLaunchKernelGGL(k_mlp_backward_f32, dim3((unsigned)blocks), dim3(256), 0, s, a, sigmas, dsigmas, drgbs,
-                           dfeat, (float *)workspace);
+                           dfeat, slabs);
         LNERF_CHECK_LAUNCH("mlp_backward");
     }
     hipLaunchKernelGGL(k_mlp_reduce_slabs, dim3((unsigned)div_up(SLAB, 64)), dim3(256), 0, s,
-                       (const float *)workspace, (int)blocks, out_dim, accumulate, dw1, db1, dw2, db2, dw3, db3);
+                       (const float *)slabs, (int)blocks, out_dim, accumulate, dw1, db1, dw2, db2, dw3, db3);
     LNERF_CHECK_LAUNCH("mlp_backward(reduce)");
     return LNERF_OK;
 }

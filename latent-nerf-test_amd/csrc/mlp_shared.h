@@ -24,7 +24,9 @@ struct MlpArgs {
     float blob_scale, blob_denom;  // blob = scale * exp(-|x|^2 / denom), denom = 2 std^2
     int64_t m_host;
     const int32_t *m_dev;
+    const void *frag_global;  // bf16 path: the weight fragments, built once per launch (NULL: every workgroup builds its own)
 };
+constexpr size_t MLP_FRAG_BYTES = 32 * 1024;  // room for the 30 one-KiB fragments of the bf16 path at the head of a workspace
 
 __device__ __forceinline__ float blob_of(const MlpArgs &a, int64_t m) {
     const float x = a.xyzs[m * 3], y = a.xyzs[m * 3 + 1], z = a.xyzs[m * 3 + 2];
@@ -33,7 +35,8 @@ __device__ __forceinline__ float blob_of(const MlpArgs &a, int64_t m) {
 }
 
 // bf16 path launchers (mlp_bf16.hip)
-int launch_mlp_forward_bf16(const MlpArgs &a, float *sigmas, float *rgbs, int blocks, hipStream_t stream);
+int launch_mlp_fragments_bf16(const MlpArgs &a, void *frag_out, bool backward_too, hipStream_t stream);
+int launch_mlp_forward_bf16(const MlpArgs &a, float *sigmas, float *rgbs, int blocks, int wps, hipStream_t stream);
 int launch_mlp_backward_bf16(const MlpArgs &a, const float *sigmas, const float *dsigmas, const float *drgbs,
                              float *dfeat, float *slabs, int blocks, hipStream_t stream);
 

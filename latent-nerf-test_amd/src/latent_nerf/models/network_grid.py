@@ -27,7 +27,8 @@ class _SigmaLatentMLP(torch.autograd.Function):
         _b.call("lnerf_mlp_forward", _chk(feat, "feat", feat.dtype), fdt, int(level_stride), _chk(xyzs, "xyzs"),
                 _chk(w1, "w1"), _chk(b1, "b1"), _chk(w2, "w2"), _chk(b2, "b2"), _chk(w3, "w3"), _chk(b3, "b3"),
                 out_dim, float(blob_scale), float(blob_std), int(m_host),
-                _chk(m_dev, "m_dev", torch.int32, allow_none=True), _p(sigmas), _p(rgbs), precision, _stream())
+                _chk(m_dev, "m_dev", torch.int32, allow_none=True), _p(sigmas), _p(rgbs), precision, _p(workspace),
+                0 if workspace is None else workspace.numel(), _stream())
         ctx.save_for_backward(feat, xyzs, w1, b1, w2, b2, w3, b3, sigmas,
                               m_dev if m_dev is not None else torch.empty(0))
         ctx.meta = (m_host, m_dev is not None, level_stride, blob_scale, blob_std, precision, workspace)
@@ -78,7 +79,7 @@ class _HashMLPField(torch.autograd.Function):
         _b.call("lnerf_mlp_forward", _p(feat), fdt, int(level_stride), _chk(xyzs, "xyzs"), _chk(w1, "w1"),
                 _chk(b1, "b1"), _chk(w2, "w2"), _chk(b2, "b2"), _chk(w3, "w3"), _chk(b3, "b3"), out_dim,
                 float(blob_scale), float(blob_std), int(m_host), _chk(m_dev, "m_dev", torch.int32, allow_none=True),
-                _p(sigmas), _p(rgbs), precision, _stream())
+                _p(sigmas), _p(rgbs), precision, _p(workspace), 0 if workspace is None else workspace.numel(), _stream())
         ctx.save_for_backward(xyzs, feat, w1, b1, w2, b2, w3, b3, sigmas,
                               m_dev if m_dev is not None else torch.empty(0))
         ctx.meta = (encoder, bound, m_host, m_dev is not None, level_stride, blob_scale, blob_std, precision, workspace,

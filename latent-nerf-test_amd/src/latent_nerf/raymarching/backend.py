@@ -57,7 +57,7 @@ _SIGNATURES = {
     "lnerf_grid_scatter_reduce_bf16": [_F, _I, _I, _P, _P, _P, _L, _L, _I, _I, _P, _I, _P, _Z, _P, _P],
     "lnerf_grid_encode_backward_adam": [_P, _F, _P, _I, _I, _I, _P, _P, _P, _L, _P, _L, _P, _I, _P, _Z, _P, _P, _P, _P, _F,
                                         _F, _F, _F, _I, _P, _F, _P],
-    "lnerf_mlp_forward": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _L, _P, _P, _P, _I, _P],
+    "lnerf_mlp_forward": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _L, _P, _P, _P, _I, _P, _Z, _P],
     "lnerf_mlp_backward_workspace_bytes": [_I],
     "lnerf_mlp_backward": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _L, _P, _P, _P, _P, _P, _P, _P, _P,
                            _P, _P, _P, _I, _P, _Z, _I, _P],

@@ -181,15 +181,17 @@ def main():
         from src.latent_nerf.models.network_grid import _SigmaLatentMLP
         featb = (torch.randn(16, cap, 2, device=dev) * 0.3).to(torch.bfloat16)
         fns = {}
-        for nb in (256, 512, 1024, 2048, 4096):
-            def f(n=nb):
+        for wps, nb in ((2, 512), (2, 1024), (4, 512), (4, 768), (4, 1024), (4, 2048)):
+            def f(n=nb, wps=wps):
                 B.call("lnerf_set_tuning", b"mlp_fwd_blocks", n)
+                B.call("lnerf_set_tuning", b"mlp_fwd_wps", wps)
                 with torch.no_grad():
                     _SigmaLatentMLP.apply(featb, xyzs, net.w1, net.b1, net.w2, net.b2, net.w3, net.b3, cap, m_dev, cap,
                                           5.0, 0.2, B.BF16, net._mlp_ws)
-            fns["mlp_fwd_bf16_blocks%d" % nb] = f
+            fns["mlp_fwd_bf16_wps%d_blocks%d" % (wps, nb)] = f
         res["mlp_ms(median,min)"] = timed(fns)
         B.call("lnerf_set_tuning", b"mlp_fwd_blocks", 512)
+        B.call("lnerf_set_tuning", b"mlp_fwd_wps", 2)
 
     print(json.dumps(res))
 
