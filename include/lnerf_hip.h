@@ -59,14 +59,18 @@ const char *lnerf_build_info(void);
 /* Performance knobs (never change results beyond float summation order).  Keys:
  *   "scatter_compact_max_res": levels with resolution <= value merge per-wavefront runs of samples in one cell
  *                              before binning (default 512).
- *   "scatter_bin_per_cu":      persistent workgroups of the binning pass per CU: 2 (default, what its LDS admits) or 1.
+ *   "scatter_bin_per_cu":      persistent workgroups of the binning pass per CU, 1 .. 4 (default 3).
  *   "scatter_bin_wgs":         persistent workgroups of the binning pass (default 0 = 256 x scatter_bin_per_cu).
  *   "scatter_skip_zero":       1 (default) = contributions that are exactly zero are not binned.
  *   "scatter_reduce_threads":  threads per workgroup of the reduce pass, 512 or 1024 (default 1024).
- *   "gather_pair_loads":       1 (default) = x-adjacent vertices fetched with one load where adjacent.
+ *   "gather_pair_loads":       0 = one load per vertex; 1 = x-adjacent vertices of dense levels with one load;
+ *                              2 (default) = additionally one aligned 16-byte load per 4-row group of a bf16 table.
  *   "gather_dedup_max_res":    levels with resolution <= value fetch a cell's 8 vertices once per run of
  *                              lanes (consecutive samples of a ray) in that cell (default 512; 0 = off).
- *   "mlp_fwd_blocks":          persistent workgroups of the bf16 MLP forward (default 512).
+ *   "mlp_fwd_blocks":          persistent workgroups of the bf16 MLP forward (default 768).
+ *   "mlp_fwd_wps":             wavefronts per SIMD the bf16 forward runs with, 2 (default) or 4.
+ *   "gather_wgs_per_xcd":      workgroups per XCD of the XCD-owned-level gather variant (variant 2).
+ *   "mlp_bwd_blocks":          persistent workgroups of the MLP backward (default and maximum 512 = slab count).
  */
 int lnerf_set_tuning(const char *key, int value);
 
@@ -197,8 +201,8 @@ int lnerf_grid_encode_backward_adam(const float *xyzs, float bound, const void *
  * Weights are PyTorch nn.Linear layout: w1 [64,32], b1 [64], w2 [64,64], b2 [64], w3 [out_dim,64],
  * b3 [out_dim], all f32.  sigma = exp(h0 + blob_scale*exp(-|x|^2/(2 blob_std^2))), rgbs = h[1:].
  * precision: LNERF_F32 -> exact-f32 MFMA (v_mfma_f32_16x16x4_f32), LNERF_BF16 -> bf16 MFMA, f32 acc.
- * workspace (optional, 16-byte aligned, >= 32 KiB; the buffer of lnerf_mlp_backward_workspace_bytes() serves): with
- * it the bf16 path builds its weight fragments once per launch instead of once per workgroup. */
+ * workspace (optional, 16-byte aligned, >= 36 KiB; the buffer of lnerf_mlp_backward_workspace_bytes() serves): with
+ * it the bf16 path builds its weight fragments (the backward's too) once per launch instead of once per workgroup. */
 int lnerf_mlp_forward(const void *feat, int feat_dtype, int64_t level_stride, const float *xyzs, const float *w1,
                       const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, int out_dim,
                       float blob_scale, float blob_std, int64_t m_host, const int32_t *m_dev, float *sigmas,
@@ -206,7 +210,11 @@ int lnerf_mlp_forward(const void *feat, int feat_dtype, int64_t level_stride, co
 /* Recomputes the hidden activations.  dfeat is written (level-major, f32); the d* parameter gradients
  * are accumulated (accumulate != 0: +=) or overwritten (accumulate == 0) deterministically:
  * per-workgroup partial slabs in `workspace` (lnerf_mlp_backward_workspace_bytes()) followed by one
- * reduction launch that sums them in a fixed order. */
+ * reduction launch that sums them in a fixed order.
+ * precision: LNERF_F32 or LNERF_BF16; LNERF_BF16 | LNERF_MLP_FRAGMENTS_READY says that the head of `workspace`
+ * still holds the fragments lnerf_mlp_forward built from these very weights (same workspace, no weight update in
+ * between), so the backward does not rebuild them. */
+#define LNERF_MLP_FRAGMENTS_READY 0x100
 size_t lnerf_mlp_backward_workspace_bytes(int out_dim);
 int lnerf_mlp_backward(const void *feat, int feat_dtype, int64_t level_stride, const float *xyzs, const float *w1,
                        const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, int out_dim,

@@ -1104,7 +1104,7 @@ k_scatter_finish(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
     }
 }
 
-extern int g_mlp_fwd_blocks, g_mlp_fwd_wps;  // mlp.hip
+extern int g_mlp_fwd_blocks, g_mlp_fwd_wps, g_mlp_bwd_blocks, g_mlp_bwd_variant;  // mlp.hip
 
 // levels up to this resolution merge per-wave runs before binning (tunable: lnerf_set_tuning)
 static int g_compact_max_res = 512;
@@ -1306,6 +1306,16 @@ int lnerf_set_tuning(const char *key, int value) {
     if (strcmp(key, "gather_pair_loads") == 0) {
         LNERF_REQUIRE(value >= 0 && value <= 2, "set_tuning: gather_pair_loads must be 0, 1 or 2");
         g_gather_pairs = value;
+        return LNERF_OK;
+    }
+    if (strcmp(key, "mlp_bwd_variant") == 0) {
+        LNERF_REQUIRE(value >= 0 && value <= 2, "set_tuning: mlp_bwd_variant must be 0, 1 or 2");
+        g_mlp_bwd_variant = value;
+        return LNERF_OK;
+    }
+    if (strcmp(key, "mlp_bwd_blocks") == 0) {
+        LNERF_REQUIRE(value >= 1 && value <= 512, "set_tuning: mlp_bwd_blocks must be in 1 .. 512");
+        g_mlp_bwd_blocks = value;
         return LNERF_OK;
     }
     if (strcmp(key, "mlp_fwd_wps") == 0) {

@@ -351,24 +351,27 @@ k_mlp_backward_f32(MlpArgs a, const float *__restrict__ sigmas, const float *__r
     for (int i = tid; i < SLAB; i += 256) gslab[i] = slab[i];
 }
 
-// 64 parameters per workgroup; 4 lane groups each sum every 4th slab (coalesced 256-B reads), then
-// the partials are added in a fixed order: deterministic.
+// 16 parameters per workgroup (421 workgroups: the chip is filled and a thread's chain of dependent adds is 32 long,
+// not 128); 16 lane groups each sum every 16th slab, then the partials are added in a fixed order: deterministic.
+constexpr int RED_P = 16, RED_G = 16;
 __global__ void __launch_bounds__(256)
 k_mlp_reduce_slabs(const float *__restrict__ slabs, int n_slabs, int out_dim, int accumulate,
                    float *__restrict__ dw1, float *__restrict__ db1, float *__restrict__ dw2, float *__restrict__ db2,
                    float *__restrict__ dw3, float *__restrict__ db3) {
-    __shared__ float part[4][64];
-    const int pi = threadIdx.x & 63, sg = threadIdx.x >> 6;
-    const int p = blockIdx.x * 64 + pi;
+    __shared__ float part[RED_G][RED_P];
+    const int pi = threadIdx.x & (RED_P - 1), sg = threadIdx.x / RED_P;
+    const int p = blockIdx.x * RED_P + pi;
     float s = 0.f;
     if (p < SLAB) {
 #pragma unroll 8
-        for (int b = sg; b < n_slabs; b += 4) s += slabs[(int64_t)b * SLAB + p];
+        for (int b = sg; b < n_slabs; b += RED_G) s += slabs[(int64_t)b * SLAB + p];
     }
     part[sg][pi] = s;
     __syncthreads();
     if (sg != 0 || p >= SLAB) return;
-    s = ((part[0][pi] + part[1][pi]) + part[2][pi]) + part[3][pi];
+    s = part[0][pi];
+#pragma unroll
+    for (int g = 1; g < RED_G; ++g) s += part[g][pi];
     float *dst = nullptr;
     if (p < SL_B1) dst = dw1 + (p - SL_W1);
     else if (p < SL_W2) dst = db1 + (p - SL_B1);
@@ -379,8 +382,10 @@ k_mlp_reduce_slabs(const float *__restrict__ slabs, int n_slabs, int out_dim, in
     if (dst) *dst = accumulate ? *dst + s : s;
 }
 
-int g_mlp_fwd_blocks = 512;
+int g_mlp_fwd_blocks = 768;   // 3 per CU: measured 24.5 us vs 28.1 (512) and 29.8 (1024) at the bench step
 int g_mlp_fwd_wps = 2;   // wavefronts per SIMD the bf16 forward is compiled for (2 or 4)
+int g_mlp_bwd_variant = 0;  // bf16 backward: 0 = shared staging images (barriers), 1 / 2 = operand-swap form at 1 / 2 waves per SIMD
+int g_mlp_bwd_blocks = MLP_BWD_MAX_BLOCKS;  // persistent workgroups of the backward (<= MLP_BWD_MAX_BLOCKS slabs)
 
 static int mlp_common_checks(const char *who, const void *feat, int feat_dtype, int64_t level_stride, const float *xyzs,
                              const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
@@ -418,7 +423,8 @@ int lnerf_mlp_forward(const void *feat, int feat_dtype, int64_t level_stride, co
         if (blocks > g_mlp_fwd_blocks) blocks = g_mlp_fwd_blocks;
         if (workspace && workspace_bytes >= MLP_FRAG_BYTES) {
             LNERF_REQUIRE(((uintptr_t)workspace & 15) == 0, "mlp_forward: workspace must be 16-byte aligned");
-            const int rcf = launch_mlp_fragments_bf16(a, workspace, false, as_stream(stream));
+            // all of them, the backward's too: lnerf_mlp_backward(... | LNERF_MLP_FRAGMENTS_READY) skips its own build
+            const int rcf = launch_mlp_fragments_bf16(a, workspace, true, as_stream(stream));
             if (rcf) return rcf;
             a.frag_global = workspace;
         }
@@ -442,6 +448,8 @@ int lnerf_mlp_backward(const void *feat, int feat_dtype, int64_t level_stride, c
                        const float *dsigmas, const float *drgbs, float *dfeat, float *dw1, float *db1, float *dw2,
                        float *db2, float *dw3, float *db3, int accumulate, void *workspace, size_t workspace_bytes,
                        int precision, lnerf_stream_t stream) {
+    const bool fragments_ready = (precision & LNERF_MLP_FRAGMENTS_READY) != 0;
+    precision &= ~LNERF_MLP_FRAGMENTS_READY;
     int rc = mlp_common_checks("mlp_backward", feat, feat_dtype, level_stride, xyzs, w1, b1, w2, b2, w3, b3, out_dim,
                                blob_std, m_host, precision);
     if (rc) return rc;
@@ -456,20 +464,21 @@ int lnerf_mlp_backward(const void *feat, int feat_dtype, int64_t level_stride, c
               2.0f * blob_std * blob_std, m_host, m_dev, nullptr};
     int64_t blocks = div_up(m_host, precision == LNERF_BF16 ? 128 : 64);
     if (blocks > BWD_MAX_BLOCKS) blocks = BWD_MAX_BLOCKS;
+    if (blocks > g_mlp_bwd_blocks) blocks = g_mlp_bwd_blocks;
     hipStream_t s = as_stream(stream);
     float *slabs = reinterpret_cast<float *>(static_cast<char *>(workspace) + MLP_FRAG_BYTES);
     if (precision == LNERF_BF16) {
-        int rc2 = launch_mlp_fragments_bf16(a, workspace, true, s);   // once per launch, not once per workgroup
+        int rc2 = fragments_ready ? LNERF_OK : launch_mlp_fragments_bf16(a, workspace, true, s);   // once per launch, not once per workgroup
         if (rc2) return rc2;
         a.frag_global = workspace;
-        rc2 = launch_mlp_backward_bf16(a, sigmas, dsigmas, drgbs, dfeat, slabs, (int)blocks, s);
+        rc2 = launch_mlp_backward_bf16(a, sigmas, dsigmas, drgbs, dfeat, slabs, (int)blocks, g_mlp_bwd_variant, s);
         if (rc2) return rc2;
     } else {
         hipLaunchKernelGGL(k_mlp_backward_f32, dim3((unsigned)blocks), dim3(256), 0, s, a, sigmas, dsigmas, drgbs,
                            dfeat, slabs);
         LNERF_CHECK_LAUNCH("mlp_backward");
     }
-    hipLaunchKernelGGL(k_mlp_reduce_slabs, dim3((unsigned)div_up(SLAB, 64)), dim3(256), 0, s,
+    hipLaunchKernelGGL(k_mlp_reduce_slabs, dim3((unsigned)div_up(SLAB, RED_P)), dim3(256), 0, s,
                        (const float *)slabs, (int)blocks, out_dim, accumulate, dw1, db1, dw2, db2, dw3, db3);
     LNERF_CHECK_LAUNCH("mlp_backward(reduce)");
     return LNERF_OK;

@@ -73,8 +73,10 @@ __device__ __forceinline__ void build_fragments(const MlpArgs &a, __bf16 *frag, 
 // The fragments of a launch, built ONCE into global memory (k_mlp_build_fragments) and copied into LDS by every
 // workgroup with coalesced 16-byte loads: a workgroup building its own took 28 (forward) / 60 (backward) dependent
 // scattered weight loads per thread before its first tile -- a quarter of the kernels' time at ~6 tiles per workgroup.
+__device__ __forceinline__ void build_selectors(__bf16 *frag, int tid, int nthreads);
 __global__ void __launch_bounds__(256) k_mlp_build_fragments(MlpArgs a, __bf16 *out, int n_frag) {
-    build_fragments(a, out, n_frag, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+    build_fragments(a, out, n_frag < F_ALL ? n_frag : F_ALL, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+    if (n_frag > F_ALL) build_selectors(out, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 __device__ __forceinline__ void fetch_fragments(const MlpArgs &a, __bf16 *frag, int n_frag, int tid, int nthreads) {
     if (a.frag_global) {
@@ -113,63 +115,111 @@ __device__ __forceinline__ bf16x8 load_x(const MlpArgs &a, int64_t m, bool in, i
     return x;
 }
 
-// relu + pack two C tiles (2s, 2s+1) into the B fragment of k-step s
-__device__ __forceinline__ bf16x8 pack_relu(const f32x4 &lo, const f32x4 &hi) {
-    bf16x8 r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        r[i] = (__bf16)fmaxf(lo[i], 0.f);
-        r[4 + i] = (__bf16)fmaxf(hi[i], 0.f);
-    }
-    return r;
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// v_cvt_pk_bf16_f32, left to the compiler: an inline-asm form hides the MFMA-result read from its hazard recogniser
+__device__ __forceinline__ uint32_t cvt_pk(float lo, float hi) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2));
 }
+// relu on a packed bf16 pair: the sign bit of a bf16 is the sign bit of the int16 holding it
+__device__ __forceinline__ uint32_t relu_pk(uint32_t v) {
+    const s16x2 z = {0, 0};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), z));
+}
+// 0xFFFF in every half of `act` (a relu'd pair: +0 or positive) that is non-zero
+__device__ __forceinline__ uint32_t live_pk(uint32_t act) {
+    const u16x2 one = {1, 1}, z = {0, 0};
+    return __builtin_bit_cast(uint32_t, z - __builtin_elementwise_min(__builtin_bit_cast(u16x2, act), one));
+}
+union Pk8 {
+    bf16x8 v;
+    uint32_t u[4];
+};
+__device__ __forceinline__ bf16x8 pack_relu_pk(const f32x4 &lo, const f32x4 &hi) {
+    Pk8 r;
+    r.u[0] = relu_pk(cvt_pk(lo[0], lo[1]));
+    r.u[1] = relu_pk(cvt_pk(lo[2], lo[3]));
+    r.u[2] = relu_pk(cvt_pk(hi[0], hi[1]));
+    r.u[3] = relu_pk(cvt_pk(hi[2], hi[3]));
+    return r.v;
+}
+__device__ __forceinline__ bf16x8 pack_masked_pk(const f32x4 &lo, const f32x4 &hi, const bf16x8 &act) {
+    Pk8 r, a;
+    a.v = act;
+    r.u[0] = cvt_pk(lo[0], lo[1]) & live_pk(a.u[0]);
+    r.u[1] = cvt_pk(lo[2], lo[3]) & live_pk(a.u[1]);
+    r.u[2] = cvt_pk(hi[0], hi[1]) & live_pk(a.u[2]);
+    r.u[3] = cvt_pk(hi[2], hi[3]) & live_pk(a.u[3]);
+    return r.v;
+}
+__device__ __forceinline__ bf16x8 pack_plain_pk(const f32x4 &lo, const f32x4 &hi) {
+    Pk8 r;
+    r.u[0] = cvt_pk(lo[0], lo[1]);
+    r.u[1] = cvt_pk(lo[2], lo[3]);
+    r.u[2] = cvt_pk(hi[0], hi[1]);
+    r.u[3] = cvt_pk(hi[2], hi[3]);
+    return r.v;
+}
+// sum of the 8 bf16 of a fragment, added to acc (v_dot2c_f32_bf16 against ones)
+__device__ __forceinline__ float sum8(const bf16x8 &v, float acc) {
+    Pk8 a;
+    a.v = v;
+    bf16x2 ones;
+    ones[0] = (__bf16)1.0f;
+    ones[1] = (__bf16)1.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a.u[i]), ones, acc, false);
+    return acc;
+}
+
+// relu + pack two C tiles (2s, 2s+1) into the B fragment of k-step s
+__device__ __forceinline__ bf16x8 pack_relu(const f32x4 &lo, const f32x4 &hi) { return pack_relu_pk(lo, hi); }
 // pack d(pre-activation) = d(activation) masked by the packed activation being positive
 __device__ __forceinline__ bf16x8 pack_masked(const f32x4 &lo, const f32x4 &hi, const bf16x8 &act) {
-    bf16x8 r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        r[i] = (float)act[i] > 0.f ? (__bf16)lo[i] : (__bf16)0.f;
-        r[4 + i] = (float)act[4 + i] > 0.f ? (__bf16)hi[i] : (__bf16)0.f;
-    }
-    return r;
+    return pack_masked_pk(lo, hi, act);
 }
 
 __device__ __forceinline__ f32x4 ld_bias4(const float *b, int base) {
     return (f32x4){b[base], b[base + 1], b[base + 2], b[base + 3]};
 }
 
-// shared forward: xB[2] -> h1B[2][2], h2B[2][2] (packed, relu'd); weights from LDS fragments
+// shared forward: xB[T] -> h1B[2][T], h2B[2][T] (packed, relu'd; T 16-sample column tiles); weights from LDS fragments
+template <int T>
 __device__ __forceinline__ void forward_hidden(const __bf16 *frag, const float *sB1, const float *sB2, int lane,
-                                               const bf16x8 xB[2], bf16x8 h1B[2][2], bf16x8 h2B[2][2]) {
+                                               const bf16x8 xB[T], bf16x8 h1B[2][T], bf16x8 h2B[2][T]) {
     const int q = lane >> 4;
-    f32x4 acc[4][2];
+    f32x4 acc[4][T];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const bf16x8 w = ld_frag(frag, F_W1A + mt, lane);
         const f32x4 b = ld_bias4(sB1, 16 * mt + 4 * q);
-        acc[mt][0] = MFMA32(w, xB[0], b);
-        acc[mt][1] = MFMA32(w, xB[1], b);
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[mt][t] = MFMA32(w, xB[t], b);
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) h1B[s][t] = pack_relu(acc[2 * s][t], acc[2 * s + 1][t]);
+        for (int t = 0; t < T; ++t) h1B[s][t] = pack_relu(acc[2 * s][t], acc[2 * s + 1][t]);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const f32x4 b = ld_bias4(sB2, 16 * mt + 4 * q);
-        acc[mt][0] = b;
-        acc[mt][1] = b;
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[mt][t] = b;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const bf16x8 w = ld_frag(frag, F_W2A + 2 * mt + s, lane);
-            acc[mt][0] = MFMA32(w, h1B[s][0], acc[mt][0]);
-            acc[mt][1] = MFMA32(w, h1B[s][1], acc[mt][1]);
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[mt][t] = MFMA32(w, h1B[s][t], acc[mt][t]);
         }
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) h2B[s][t] = pack_relu(acc[2 * s][t], acc[2 * s + 1][t]);
+        for (int t = 0; t < T; ++t) h2B[s][t] = pack_relu(acc[2 * s][t], acc[2 * s + 1][t]);
 }
 
 // ------------------------------------------------------------------ forward
@@ -187,12 +237,22 @@ k_mlp_forward_bf16(MlpArgs a, float *__restrict__ sigmas, float *__restrict__ rg
     if (tid < 16) sB3[tid] = tid < a.out_dim ? a.b3[tid] : 0.f;
     __syncthreads();
     const int nrgb = a.out_dim - 1;
+    bf16x8 xB[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int64_t m = (int64_t)blockIdx.x * 128 + w * 32 + 16 * t + c;
+        xB[t] = load_x(a, m, m < M, q);
+    }
     for (int64_t tile = blockIdx.x; tile * 128 < M; tile += gridDim.x) {
         const int64_t m0 = tile * 128 + w * 32;
-        bf16x8 xB[2], h1B[2][2], h2B[2][2];
+        // the next tile's features are requested now and waited for after this tile's arithmetic
+        bf16x8 xB_n[2], h1B[2][2], h2B[2][2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) xB[t] = load_x(a, m0 + 16 * t + c, m0 + 16 * t + c < M, q);
-        forward_hidden(frag, sB1, sB2, lane, xB, h1B, h2B);
+        for (int t = 0; t < 2; ++t) {
+            const int64_t m = m0 + (int64_t)gridDim.x * 128 + 16 * t + c;
+            xB_n[t] = load_x(a, m, m < M, q);
+        }
+        forward_hidden<2>(frag, sB1, sB2, lane, xB, h1B, h2B);
         const f32x4 b3 = ld_bias4(sB3, 4 * q);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -209,7 +269,49 @@ k_mlp_forward_bf16(MlpArgs a, float *__restrict__ sigmas, float *__restrict__ rg
                 }
             }
         }
+        xB[0] = xB_n[0];
+        xB[1] = xB_n[1];
     }
+}
+
+// upstream gradient of one lane (outputs 4q .. 4q+3 of its T samples), requested one step ahead of its use: raw
+// loads only -- d(sigma)/d(pre-activation) = sigma is applied when the values are consumed, so nothing waits here
+template <int T>
+struct Upstream { float v[T][4], sg[T]; };
+
+template <int T>
+__device__ __forceinline__ Upstream<T> load_upstream(const MlpArgs &a, const float *__restrict__ sigmas,
+                                                     const float *__restrict__ dsigmas, const float *__restrict__ drgbs,
+                                                     int64_t m0, int64_t M, int q, int c) {
+    const int nrgb = a.out_dim - 1;
+    Upstream<T> u;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int64_t m = m0 + 16 * t + c;
+        const bool in = m < M;
+        u.sg[t] = 1.0f;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) u.v[t][jj] = 0.f;
+        if (in && q == 0) { u.v[t][0] = dsigmas[m]; u.sg[t] = sigmas[m]; }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int n = 4 * q + jj;
+            if (in && n >= 1 && n < a.out_dim) u.v[t][jj] = drgbs[m * nrgb + (n - 1)];
+        }
+    }
+    return u;
+}
+// the B fragment of dZ3^T (slot (q, jj < 4) <-> output 4q + jj) of one column tile; returns whether any value is non-zero
+__device__ __forceinline__ bool upstream_fragment(const float v[4], float sg, int q, bf16x8 &d3) {
+    const float e15 = 3269017.3724721107f;  // exp(15)
+    const float v0 = q == 0 ? v[0] * fminf(sg, e15) : v[0];
+    Pk8 d;
+    d.u[0] = cvt_pk(v0, v[1]);
+    d.u[1] = cvt_pk(v[2], v[3]);
+    d.u[2] = 0u;
+    d.u[3] = 0u;
+    d3 = d.v;
+    return (v0 != 0.f) || (v[1] != 0.f) || (v[2] != 0.f) || (v[3] != 0.f);
 }
 
 // ------------------------------------------------------------------ backward
@@ -244,56 +346,67 @@ __device__ __forceinline__ bf16x8 ld_tr(const __bf16 *img, int k, int f0, int la
     return u.v;
 }
 
-__global__ void __launch_bounds__(256, 2)
+// NW wavefronts x T 16-sample column tiles per wavefront = one step of NW * 16 * T samples.  <4, 2> (two workgroups =
+// eight wavefronts per CU) is what runs; <8, 1> (half the registers per wavefront, four wavefronts per SIMD) measured
+// 65 us against 60: the kernel is not short of wavefronts but of LDS bandwidth and issue slots.
+// Ownership of the weight gradients (r = w & 3, h = w >> 2, NH = NW / 4): rows 16r..16r+15 of dW2 / dW1, their column
+// tiles split over h; db2 with h = 0, db1 with h = NH - 1; dW3 columns 16r.. with h = 0; db3 with the first wave of
+// the last h.  No cross-wave reduction.
+template <int NW, int T>
+__global__ void __launch_bounds__(NW * 64, (NW == 4 ? 2 : 4))
 k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__restrict__ dsigmas,
                     const float *__restrict__ drgbs, float *__restrict__ dfeat, float *__restrict__ slabs) {
+    constexpr int STEP = NW * 16 * T, KS = STEP / 32, NH = NW / 4, C2 = 4 / NH, C1 = 2 / NH;
     __shared__ __attribute__((aligned(16))) __bf16 frag[F_ALL * 512];
-    __shared__ __attribute__((aligned(16))) __bf16 imgA[128 * RS];  // [sample][feature]: H2, then H1, then X
-    __shared__ __attribute__((aligned(16))) __bf16 imgD[128 * RS];  // [sample][feature]: dZ3, then dZ2, then dZ1
+    __shared__ __attribute__((aligned(16))) __bf16 imgA[STEP * RS];  // [sample][feature]: H2, then H1, then X
+    __shared__ __attribute__((aligned(16))) __bf16 imgD[STEP * RS];  // [sample][feature]: dZ3, then dZ2, then dZ1
     __shared__ float sB1[MLP_HID], sB2[MLP_HID];
     int64_t M = a.m_host;
     if (a.m_dev) { const int64_t md = *a.m_dev; M = md < M ? md : M; }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, c = lane & 15;
-    fetch_fragments(a, frag, F_ALL, tid, 256);
+    const int r = w & 3, h = w >> 2;
+    fetch_fragments(a, frag, F_ALL, tid, NW * 64);
     if (tid < MLP_HID) { sB1[tid] = a.b1[tid]; sB2[tid] = a.b2[tid]; }
     __syncthreads();
-    const int nrgb = a.out_dim - 1;
-    const float e15 = 3269017.3724721107f;  // exp(15)
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     bf16x8 ones;
 #pragma unroll
     for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
 
-    // this wave's slice of the weight gradients: rows 16w..16w+15 of dW2 / dW1 (+ bias column),
-    // columns 16w..16w+15 of dW3; wave 0 also owns db3
-    f32x4 gW2[4], gB2 = zero4, gW1[2], gB1 = zero4, gW3 = zero4, gB3 = zero4;
+    f32x4 gW2[C2], gW1[C1], gB = zero4, gW3 = zero4;   // gB: db2 (h = 0) or db1 (h = NH-1); NW = 4 keeps both
+    f32x4 gB1x = zero4, gB3 = zero4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) gW2[i] = zero4;
-    gW1[0] = gW1[1] = zero4;
+    for (int i = 0; i < C2; ++i) gW2[i] = zero4;
+#pragma unroll
+    for (int i = 0; i < C1; ++i) gW1[i] = zero4;
+    const bool own_b2 = h == 0, own_b1 = h == NH - 1, own_w3 = h == 0, own_b3 = w == NW - 4;
 
-    for (int64_t tile = blockIdx.x; tile * 128 < M; tile += gridDim.x) {
-        const int64_t m0 = tile * 128 + w * 32;
-        bf16x8 xB[2], h1B[2][2], h2B[2][2], dzB[2][2], d3B[2];
-        // ---- dZ3^T as a B fragment: slot (q, jj < 4) <-> output 4q + jj
+    // this wave's inputs of the first step; every later step's are requested one step ahead
+    const int64_t wofs = (int64_t)w * 16 * T;
+    Upstream<T> up = load_upstream<T>(a, sigmas, dsigmas, drgbs, (int64_t)blockIdx.x * STEP + wofs, M, q, c);
+    bf16x8 xB[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int64_t m = (int64_t)blockIdx.x * STEP + wofs + 16 * t + c;
+        xB[t] = load_x(a, m, m < M, q);
+    }
+    for (int64_t tile = blockIdx.x; tile * STEP < M; tile += gridDim.x) {
+        const int64_t m0 = tile * STEP + wofs, m1 = m0 + (int64_t)gridDim.x * STEP;
+        const Upstream<T> up_c = up;
+        bf16x8 xC[T], h1B[2][T], h2B[2][T], dzB[2][T], d3B[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) xC[t] = xB[t];
+        up = load_upstream<T>(a, sigmas, dsigmas, drgbs, m1, M, q, c);
+#pragma unroll
+        for (int t = 0; t < T; ++t) xB[t] = load_x(a, m1 + 16 * t + c, m1 + 16 * t + c < M, q);
         bool live = false;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int64_t m = m0 + 16 * t + c;
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const int n = 4 * q + jj;
-                float v = 0.f;
-                if (jj < 4 && n < a.out_dim && m < M)
-                    v = n == 0 ? dsigmas[m] * fminf(sigmas[m], e15) : drgbs[m * nrgb + (n - 1)];
-                d3B[t][jj] = (__bf16)v;
-                live = live || (v != 0.f);
-            }
-        }
-        // 128 samples whose upstream gradient is exactly zero (rays past their termination point: the
-        // compositing backward writes zeros there) contribute nothing to any gradient: dfeat = 0, done
+        for (int t = 0; t < T; ++t) live = upstream_fragment(up_c.v[t], up_c.sg[t], q, d3B[t]) || live;
+        // a step whose upstream gradient is exactly zero (rays past their termination point: the compositing
+        // backward writes zeros there) contributes nothing to any gradient: dfeat = 0, done
         if (!__syncthreads_or(live ? 1 : 0)) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < T; ++t) {
                 const int64_t m = m0 + 16 * t + c;
                 if (m < M) {
 #pragma unroll
@@ -304,45 +417,44 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
             }
             continue;  // uniform for the whole workgroup
         }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) xB[t] = load_x(a, m0 + 16 * t + c, m0 + 16 * t + c < M, q);
-        forward_hidden(frag, sB1, sB2, lane, xB, h1B, h2B);
+        forward_hidden<T>(frag, sB1, sB2, lane, xC, h1B, h2B);
         // ================= stage 1: dW3 += dZ3^T (x) H2^T
         __syncthreads();  // previous step's readers of imgA/imgD are done
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int row = 32 * w + 16 * t + c;  // this lane's sample inside the 128-sample step
+        for (int t = 0; t < T; ++t) {
+            const int row = 16 * T * w + 16 * t + c;  // this lane's sample inside the step
 #pragma unroll
             for (int s = 0; s < 2; ++s) stage_pair(imgA, row, 32 * s + 4 * q, 32 * s + 16 + 4 * q, h2B[s][t]);
             stage_lo(imgD, row, 4 * q, d3B[t]);   // outputs 4q .. 4q+3 (columns 0..15; zero beyond out_dim)
         }
         __syncthreads();
+        if (own_w3 || own_b3) {   // wave-uniform
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const bf16x8 dA = ld_tr(imgD, k, 0, lane);        // A[i = output][k = sample]
-            const bf16x8 hB = ld_tr(imgA, k, 16 * w, lane);   // B[k = sample][j = hidden 16w + c]
-            gW3 = MFMA32(dA, hB, gW3);
-            if (w == 0) gB3 = MFMA32(dA, ones, gB3);
+            for (int k = 0; k < KS; ++k) {
+                const bf16x8 dA = ld_tr(imgD, k, 0, lane);        // A[i = output][k = sample]
+                if (own_w3) gW3 = MFMA32(dA, ld_tr(imgA, k, 16 * r, lane), gW3);   // B[k = sample][j = hidden 16r + c]
+                if (own_b3) gB3 = MFMA32(dA, ones, gB3);
+            }
         }
         // ---- dA2 = W3^T dZ3 ; dZ2 = dA2 masked by H2 > 0
         {
-            f32x4 acc[4][2];
+            f32x4 acc[4][T];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const bf16x8 wf = ld_frag(frag, F_W3T + mt, lane);
-                acc[mt][0] = MFMA32(wf, d3B[0], zero4);
-                acc[mt][1] = MFMA32(wf, d3B[1], zero4);
+#pragma unroll
+                for (int t = 0; t < T; ++t) acc[mt][t] = MFMA32(wf, d3B[t], zero4);
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) dzB[s][t] = pack_masked(acc[2 * s][t], acc[2 * s + 1][t], h2B[s][t]);
+                for (int t = 0; t < T; ++t) dzB[s][t] = pack_masked(acc[2 * s][t], acc[2 * s + 1][t], h2B[s][t]);
         }
         // ================= stage 2: dW2 += dZ2^T (x) H1^T
         __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int row = 32 * w + 16 * t + c;
+        for (int t = 0; t < T; ++t) {
+            const int row = 16 * T * w + 16 * t + c;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 stage_pair(imgA, row, 32 * s + 4 * q, 32 * s + 16 + 4 * q, h1B[s][t]);
@@ -351,59 +463,62 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const bf16x8 dA = ld_tr(imgD, k, 16 * w, lane);
+        for (int k = 0; k < KS; ++k) {
+            const bf16x8 dA = ld_tr(imgD, k, 16 * r, lane);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) gW2[nt] = MFMA32(dA, ld_tr(imgA, k, 16 * nt, lane), gW2[nt]);
-            gB2 = MFMA32(dA, ones, gB2);
+            for (int i = 0; i < C2; ++i) gW2[i] = MFMA32(dA, ld_tr(imgA, k, 16 * (C2 * h + i), lane), gW2[i]);
+            if (own_b2) gB = MFMA32(dA, ones, gB);
         }
         // ---- dA1 = W2^T dZ2 ; dZ1 = dA1 masked by H1 > 0   (dzB is overwritten by dZ1)
         {
-            f32x4 acc[4][2];
+            f32x4 acc[4][T];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                acc[mt][0] = acc[mt][1] = zero4;
+#pragma unroll
+                for (int t = 0; t < T; ++t) acc[mt][t] = zero4;
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const bf16x8 wf = ld_frag(frag, F_W2T + 2 * mt + s, lane);
-                    acc[mt][0] = MFMA32(wf, dzB[s][0], acc[mt][0]);
-                    acc[mt][1] = MFMA32(wf, dzB[s][1], acc[mt][1]);
+#pragma unroll
+                    for (int t = 0; t < T; ++t) acc[mt][t] = MFMA32(wf, dzB[s][t], acc[mt][t]);
                 }
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) dzB[s][t] = pack_masked(acc[2 * s][t], acc[2 * s + 1][t], h1B[s][t]);
+                for (int t = 0; t < T; ++t) dzB[s][t] = pack_masked(acc[2 * s][t], acc[2 * s + 1][t], h1B[s][t]);
         }
         // ================= stage 3: dW1 += dZ1^T (x) X^T
         __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int row = 32 * w + 16 * t + c;
-            stage_pair(imgA, row, 8 * q, 8 * q + 4, xB[t]);   // input features 8q .. 8q+7
+        for (int t = 0; t < T; ++t) {
+            const int row = 16 * T * w + 16 * t + c;
+            stage_pair(imgA, row, 8 * q, 8 * q + 4, xC[t]);   // input features 8q .. 8q+7
 #pragma unroll
             for (int s = 0; s < 2; ++s) stage_pair(imgD, row, 32 * s + 4 * q, 32 * s + 16 + 4 * q, dzB[s][t]);
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const bf16x8 dA = ld_tr(imgD, k, 16 * w, lane);
+        for (int k = 0; k < KS; ++k) {
+            const bf16x8 dA = ld_tr(imgD, k, 16 * r, lane);
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) gW1[nt] = MFMA32(dA, ld_tr(imgA, k, 16 * nt, lane), gW1[nt]);
-            gB1 = MFMA32(dA, ones, gB1);
+            for (int i = 0; i < C1; ++i) gW1[i] = MFMA32(dA, ld_tr(imgA, k, 16 * (C1 * h + i), lane), gW1[i]);
+            if (own_b1) { if (NH == 1) gB1x = MFMA32(dA, ones, gB1x); else gB = MFMA32(dA, ones, gB); }
         }
         // ---- dX = W1^T dZ1 -> dfeat (level-major f32): lane holds features 16mt + 4q + r of its sample
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            f32x4 ax[2] = {zero4, zero4};
+            f32x4 ax[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) ax[t] = zero4;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const bf16x8 wf = ld_frag(frag, F_W1T + 2 * mt + s, lane);
-                ax[0] = MFMA32(wf, dzB[s][0], ax[0]);
-                ax[1] = MFMA32(wf, dzB[s][1], ax[1]);
+#pragma unroll
+                for (int t = 0; t < T; ++t) ax[t] = MFMA32(wf, dzB[s][t], ax[t]);
             }
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < T; ++t) {
                 const int64_t m = m0 + 16 * t + c;
                 if (m < M) {
                     const int lv = 8 * mt + 2 * q;  // features 16mt+4q+{0,1} = level lv, {2,3} = level lv+1
@@ -415,19 +530,308 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
         }
     }
 
-    // ---- one slab per workgroup, every wave writes the rows it owns (layout: mlp_shared.h)
+    // ---- one slab per workgroup, every wave writes the tiles it owns (layout: mlp_shared.h)
+    float *slab = slabs + (int64_t)blockIdx.x * MLP_SLAB;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int o = 16 * r + 4 * q + rr;  // row of dW2 / dW1
+#pragma unroll
+        for (int i = 0; i < C2; ++i) slab[MLP_SL_W2 + o * MLP_HID + 16 * (C2 * h + i) + c] = gW2[i][rr];
+#pragma unroll
+        for (int i = 0; i < C1; ++i) slab[MLP_SL_W1 + o * MLP_IN + 16 * (C1 * h + i) + c] = gW1[i][rr];
+        if (c == 0) {
+            if (own_b2) slab[MLP_SL_B2 + o] = gB[rr];
+            if (own_b1) slab[MLP_SL_B1 + o] = NH == 1 ? gB1x[rr] : gB[rr];
+        }
+        // dW3: rows n3 = 4q + rr, columns (hidden) 16r + c
+        if (own_w3) slab[MLP_SL_W3 + (4 * q + rr) * MLP_HID + 16 * r + c] = gW3[rr];
+        if (own_b3 && c == 0) slab[MLP_SL_B3 + 4 * q + rr] = gB3[rr];
+    }
+}
+
+// ------------------------------------------------------------------ backward, operand-swap form
+// The weight gradients contract over SAMPLES, so their MFMA operands need the feature on the lane and samples in the
+// registers -- the transpose of what the sample-on-the-lane chain holds.  Instead of transposing through LDS, every
+// activation / pre-activation gradient the weight gradients need is computed a second time with the two MFMA operands
+// SWAPPED: A[i][k] and B[k][j] have the same lane map (index on the lane, k in the registers), so
+// MFMA(W-fragment, X^T-fragment) = Z^T (feature rows, sample columns: the chain) and MFMA(X^T-fragment, W-fragment) = Z
+// (sample rows 4q+r in the registers, feature column c on the lane) use the very same registers.  Two 16-sample
+// tiles of Z give 8 samples per lane = one k-step of dW = dZ^T (x) H (the k-slot -> sample map is the same for both
+// operands, which is all a contraction needs).  +54 MFMAs per 32 samples (a few us chip-wide), and in exchange: no
+// staging images, no transposing reads, no LDS round trips and NO BARRIER in the loop -- a wave carries its own 32
+// samples from load to store; the next step's inputs are requested before the current step is computed.
+// X and dZ3 (inputs, no weight to swap with) are transposed exactly by MFMAs against 0/1 selection fragments.
+constexpr int F_SELX = 30;   // [nt 0..1]  B[k = 8q+jj][j = c] = (8q + jj == 16nt + c)
+constexpr int F_SEL3 = 32;   //            B[k = 8q+jj][j = c] = (jj < 4 && 4q + jj == c)
+constexpr int F_SW = 33;
+constexpr int SW_TILES = 31;                                     // dW2 16 | dW1 8 | dW3 4 | biases 3 (db2 4, db1 4, db3 1 floats)
+static_assert((size_t)F_SW * 1024 <= MLP_FRAG_BYTES, "fragment cache");
+static_assert(SW_TILES * 1024 <= F_SW * 1024, "final reduction reuses the fragment area");
+
+// the three selection fragments (appended to the weight fragments by k_mlp_build_fragments)
+__device__ __forceinline__ void build_selectors(__bf16 *frag, int tid, int nthreads) {
+    for (int e = tid; e < (F_SW - F_SELX) * 512; e += nthreads) {
+        const int f = F_SELX + (e >> 9), l = (e >> 3) & 63, jj = e & 7;
+        const int q = l >> 4, c = l & 15;
+        const bool one = f < F_SEL3 ? (8 * q + jj == 16 * (f - F_SELX) + c) : (jj < 4 && 4 * q + jj == c);
+        frag[F_SELX * 512 + e] = (__bf16)(one ? 1.0f : 0.0f);
+    }
+}
+
+template <int WPS>
+__global__ void __launch_bounds__(256, WPS)
+k_mlp_backward_bf16_sw(MlpArgs a, const float *__restrict__ sigmas, const float *__restrict__ dsigmas,
+                       const float *__restrict__ drgbs, float *__restrict__ dfeat, float *__restrict__ slabs) {
+    __shared__ __attribute__((aligned(16))) __bf16 frag[F_SW * 512];
+    __shared__ float sB1[MLP_HID], sB2[MLP_HID];
+    int64_t M = a.m_host;
+    if (a.m_dev) { const int64_t md = *a.m_dev; M = md < M ? md : M; }
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, c = lane & 15;
+    fetch_fragments(a, frag, F_SW, tid, 256);
+    if (tid < MLP_HID) { sB1[tid] = a.b1[tid]; sB2[tid] = a.b2[tid]; }
+    __syncthreads();
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 gW2[16], gW1[8], gW3[4];
+    float gb2[4], gb1[4], gb3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) gW2[i] = zero4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gW1[i] = zero4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { gW3[i] = zero4; gb2[i] = 0.f; gb1[i] = 0.f; }
+
+    const int64_t stride = (int64_t)gridDim.x * 4 * 32;
+    int64_t m0 = ((int64_t)blockIdx.x * 4 + w) * 32;
+    Upstream<2> up = load_upstream<2>(a, sigmas, dsigmas, drgbs, m0, M, q, c);
+    bf16x8 xB[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) xB[t] = load_x(a, m0 + 16 * t + c, m0 + 16 * t + c < M, q);
+
+    while (m0 < M) {   // wave-uniform
+        asm volatile("" ::: "memory");   // the weight fragments are re-read from LDS every step, not hoisted into ~130 registers
+        const int64_t m1 = m0 + stride;
+        const Upstream<2> up_n = load_upstream<2>(a, sigmas, dsigmas, drgbs, m1, M, q, c);
+        bf16x8 xB_n[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) xB_n[t] = load_x(a, m1 + 16 * t + c, m1 + 16 * t + c < M, q);
+
+        bf16x8 d3B[2];
+        bool live = false;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) live = upstream_fragment(up.v[t], up.sg[t], q, d3B[t]) || live;
+        if (!__any(live ? 1 : 0)) {
+            // 32 samples whose upstream gradient is exactly zero (rays past their termination point: the compositing
+            // backward writes zeros there) contribute nothing to any gradient: dfeat = 0, done
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int64_t m = m0 + 16 * t + c;
+                if (m < M) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        reinterpret_cast<float2 *>(dfeat)[(int64_t)(4 * q + k) * a.level_stride + m] = make_float2(0.f, 0.f);
+                }
+            }
+        } else {
+            bf16x8 h1B[2][2], h2B[2][2], H1f[4], H2f[4], dZf[4];
+            // ---- layer 1, both forms (the fragment of W1 rows 16mt.. is A of the chain and B of the swap)
+            {
+                f32x4 acc[4][2];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const bf16x8 wf = ld_frag(frag, F_W1A + mt, lane);
+                    const f32x4 b = ld_bias4(sB1, 16 * mt + 4 * q);
+                    acc[mt][0] = MFMA32(wf, xB[0], b);
+                    acc[mt][1] = MFMA32(wf, xB[1], b);
+                    const float bc = sB1[16 * mt + c];
+                    const f32x4 bT = (f32x4){bc, bc, bc, bc};
+                    H1f[mt] = pack_relu_pk(MFMA32(xB[0], wf, bT), MFMA32(xB[1], wf, bT));
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) h1B[s][t] = pack_relu_pk(acc[2 * s][t], acc[2 * s + 1][t]);
+            }
+            // ---- layer 2, both forms
+            {
+                f32x4 acc[4][2];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const f32x4 b = ld_bias4(sB2, 16 * mt + 4 * q);
+                    const float bc = sB2[16 * mt + c];
+                    f32x4 t0 = (f32x4){bc, bc, bc, bc}, t1 = t0;
+                    acc[mt][0] = b;
+                    acc[mt][1] = b;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const bf16x8 wf = ld_frag(frag, F_W2A + 2 * mt + s, lane);
+                        acc[mt][0] = MFMA32(wf, h1B[s][0], acc[mt][0]);
+                        acc[mt][1] = MFMA32(wf, h1B[s][1], acc[mt][1]);
+                        t0 = MFMA32(h1B[s][0], wf, t0);
+                        t1 = MFMA32(h1B[s][1], wf, t1);
+                    }
+                    H2f[mt] = pack_relu_pk(t0, t1);
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) h2B[s][t] = pack_relu_pk(acc[2 * s][t], acc[2 * s + 1][t]);
+            }
+            // ---- dW3 += dZ3^T (x) H2 ; db3
+            {
+                const bf16x8 sel = ld_frag(frag, F_SEL3, lane);
+                const bf16x8 d3f = pack_plain_pk(MFMA32(d3B[0], sel, zero4), MFMA32(d3B[1], sel, zero4));
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) gW3[nt] = MFMA32(d3f, H2f[nt], gW3[nt]);
+                gb3 = sum8(d3f, gb3);
+            }
+            // ---- dA2 = dZ3 W3, both forms ; dZ2 = dA2 masked by H2 > 0 ; dW2 += dZ2^T (x) H1 ; db2
+            bf16x8 dzB[2][2];
+            {
+                f32x4 acc[4][2];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const bf16x8 wf = ld_frag(frag, F_W3T + mt, lane);
+                    acc[mt][0] = MFMA32(wf, d3B[0], zero4);
+                    acc[mt][1] = MFMA32(wf, d3B[1], zero4);
+                    dZf[mt] = pack_masked_pk(MFMA32(d3B[0], wf, zero4), MFMA32(d3B[1], wf, zero4), H2f[mt]);
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) dzB[s][t] = pack_masked_pk(acc[2 * s][t], acc[2 * s + 1][t], h2B[s][t]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) gW2[4 * mt + nt] = MFMA32(dZf[mt], H1f[nt], gW2[4 * mt + nt]);
+                gb2[mt] = sum8(dZf[mt], gb2[mt]);
+            }
+            // ---- dA1 = dZ2 W2, both forms ; dZ1 = dA1 masked by H1 > 0   (dzB is overwritten by dZ1)
+            {
+                f32x4 acc[4][2];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    f32x4 t0 = zero4, t1 = zero4;
+                    acc[mt][0] = acc[mt][1] = zero4;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const bf16x8 wf = ld_frag(frag, F_W2T + 2 * mt + s, lane);
+                        acc[mt][0] = MFMA32(wf, dzB[s][0], acc[mt][0]);
+                        acc[mt][1] = MFMA32(wf, dzB[s][1], acc[mt][1]);
+                        t0 = MFMA32(dzB[s][0], wf, t0);
+                        t1 = MFMA32(dzB[s][1], wf, t1);
+                    }
+                    dZf[mt] = pack_masked_pk(t0, t1, H1f[mt]);
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) dzB[s][t] = pack_masked_pk(acc[2 * s][t], acc[2 * s + 1][t], h1B[s][t]);
+            }
+            // ---- dW1 += dZ1^T (x) X ; db1
+            {
+                bf16x8 Xf[2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const bf16x8 sel = ld_frag(frag, F_SELX + nt, lane);
+                    Xf[nt] = pack_plain_pk(MFMA32(xB[0], sel, zero4), MFMA32(xB[1], sel, zero4));
+                }
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) gW1[2 * mt + nt] = MFMA32(dZf[mt], Xf[nt], gW1[2 * mt + nt]);
+                    gb1[mt] = sum8(dZf[mt], gb1[mt]);
+                }
+            }
+            // ---- dX = W1^T dZ1 -> dfeat (level-major f32): lane holds features 16mt + 4q + r of its sample
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                f32x4 ax[2] = {zero4, zero4};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 wf = ld_frag(frag, F_W1T + 2 * mt + s, lane);
+                    ax[0] = MFMA32(wf, dzB[s][0], ax[0]);
+                    ax[1] = MFMA32(wf, dzB[s][1], ax[1]);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int64_t m = m0 + 16 * t + c;
+                    if (m < M) {
+                        const int lv = 8 * mt + 2 * q;  // features 16mt+4q+{0,1} = level lv, {2,3} = level lv+1
+                        reinterpret_cast<float2 *>(dfeat)[(int64_t)lv * a.level_stride + m] = make_float2(ax[t][0], ax[t][1]);
+                        reinterpret_cast<float2 *>(dfeat)[(int64_t)(lv + 1) * a.level_stride + m] =
+                            make_float2(ax[t][2], ax[t][3]);
+                    }
+                }
+            }
+        }
+        up = up_n;
+        xB[0] = xB_n[0];
+        xB[1] = xB_n[1];
+        m0 = m1;
+    }
+
+    // ---- bias partials: a lane holds feature c of the samples of its q group -> sum the four groups
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        gb2[i] += __shfl_xor(gb2[i], 16);
+        gb2[i] += __shfl_xor(gb2[i], 32);
+        gb1[i] += __shfl_xor(gb1[i], 16);
+        gb1[i] += __shfl_xor(gb1[i], 32);
+    }
+    gb3 += __shfl_xor(gb3, 16);
+    gb3 += __shfl_xor(gb3, 32);
+    f32x4 gB[3] = {(f32x4){gb2[0], gb2[1], gb2[2], gb2[3]}, (f32x4){gb1[0], gb1[1], gb1[2], gb1[3]},
+                   (f32x4){gb3, 0.f, 0.f, 0.f}};
+    // ---- sum the four waves' tiles in the fixed order 0 + 1 + 2 + 3 (through the fragment area, now idle)
+    f32x4 *red = reinterpret_cast<f32x4 *>(frag);
+    for (int src = 1; src < 4; ++src) {
+        __syncthreads();
+        if (w == src) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) red[i * 64 + lane] = gW2[i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) red[(16 + i) * 64 + lane] = gW1[i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[(24 + i) * 64 + lane] = gW3[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) red[(28 + i) * 64 + lane] = gB[i];
+        }
+        __syncthreads();
+        if (w == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) gW2[i] += red[i * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) gW1[i] += red[(16 + i) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gW3[i] += red[(24 + i) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) gB[i] += red[(28 + i) * 64 + lane];
+        }
+    }
+    if (w != 0) return;
     float *slab = slabs + (int64_t)blockIdx.x * MLP_SLAB;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int o = 16 * w + 4 * q + r;  // row of dW2 / dW1
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) slab[MLP_SL_W2 + o * MLP_HID + 16 * nt + c] = gW2[nt][r];
-        slab[MLP_SL_W1 + o * MLP_IN + c] = gW1[0][r];
-        slab[MLP_SL_W1 + o * MLP_IN + 16 + c] = gW1[1][r];
-        if (c == 0) { slab[MLP_SL_B2 + o] = gB2[r]; slab[MLP_SL_B1 + o] = gB1[r]; }
-        // dW3: rows n3 = 4q + r, columns (hidden) 16w + c
-        slab[MLP_SL_W3 + (4 * q + r) * MLP_HID + 16 * w + c] = gW3[r];
-        if (w == 0 && c == 0) slab[MLP_SL_B3 + 4 * q + r] = gB3[r];
+        for (int mt = 0; mt < 4; ++mt) {
+            const int o = 16 * mt + 4 * q + r;  // row of dW2 / dW1
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) slab[MLP_SL_W2 + o * MLP_HID + 16 * nt + c] = gW2[4 * mt + nt][r];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) slab[MLP_SL_W1 + o * MLP_IN + 16 * nt + c] = gW1[2 * mt + nt][r];
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) slab[MLP_SL_W3 + (4 * q + r) * MLP_HID + 16 * nt + c] = gW3[nt][r];
+    }
+    // biases: lane c (of q group 0) holds db[16 mt + c]
+    if (q == 0) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            slab[MLP_SL_B2 + 16 * mt + c] = gB[0][mt];
+            slab[MLP_SL_B1 + 16 * mt + c] = gB[1][mt];
+        }
+        slab[MLP_SL_B3 + c] = gB[2][0];
     }
 }
 
@@ -436,8 +840,7 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
 namespace lnerf {
 
 int launch_mlp_fragments_bf16(const MlpArgs &a, void *frag_out, bool backward_too, hipStream_t stream) {
-    const int n = backward_too ? F_ALL : F_FWD;
-    static_assert((size_t)F_ALL * 1024 <= MLP_FRAG_BYTES, "fragment cache");
+    const int n = backward_too ? F_SW : F_FWD;
     hipLaunchKernelGGL(k_mlp_build_fragments, dim3((unsigned)(n * 2)), dim3(256), 0, stream, a, (__bf16 *)frag_out, n);
     LNERF_CHECK_LAUNCH("mlp(fragments)");
     return LNERF_OK;
@@ -451,9 +854,21 @@ int launch_mlp_forward_bf16(const MlpArgs &a, float *sigmas, float *rgbs, int bl
 }
 
 int launch_mlp_backward_bf16(const MlpArgs &a, const float *sigmas, const float *dsigmas, const float *drgbs,
-                             float *dfeat, float *slabs, int blocks, hipStream_t stream) {
-    hipLaunchKernelGGL(k_mlp_backward_bf16, dim3((unsigned)blocks), dim3(256), 0, stream, a, sigmas, dsigmas, drgbs,
-                       dfeat, slabs);
+                             float *dfeat, float *slabs, int blocks, int variant, hipStream_t stream) {
+    if (variant == 2) {
+        hipLaunchKernelGGL(k_mlp_backward_bf16_sw<2>, dim3((unsigned)blocks), dim3(256), 0, stream, a, sigmas, dsigmas,
+                           drgbs, dfeat, slabs);
+        LNERF_CHECK_LAUNCH("mlp_backward(bf16, operand swap)");
+        return LNERF_OK;
+    }
+    if (variant == 1) {
+        hipLaunchKernelGGL(k_mlp_backward_bf16_sw<1>, dim3((unsigned)blocks), dim3(256), 0, stream, a, sigmas, dsigmas,
+                           drgbs, dfeat, slabs);
+        LNERF_CHECK_LAUNCH("mlp_backward(bf16, operand swap)");
+        return LNERF_OK;
+    }
+    hipLaunchKernelGGL((k_mlp_backward_bf16<4, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, a, sigmas, dsigmas,
+                       drgbs, dfeat, slabs);
     LNERF_CHECK_LAUNCH("mlp_backward(bf16)");
     return LNERF_OK;
 }

@@ -48,6 +48,10 @@ class _SigmaLatentMLP(torch.autograd.Function):
         need = _b.get_lib().lnerf_mlp_backward_workspace_bytes(out_dim)
         if workspace is None or workspace.numel() < need:
             workspace = torch.empty(need, device=dev, dtype=torch.uint8)
+        elif precision == _b.BF16:
+            # this node's forward left the weight fragments at the head of the same workspace, and autograd's
+            # version check on the saved weights guarantees they have not changed since
+            precision |= _b.MLP_FRAGMENTS_READY
         fdt = _b.F32 if feat.dtype == torch.float32 else _b.BF16
         _b.call("lnerf_mlp_backward", _p(feat), fdt, int(level_stride), _p(xyzs), _p(w1), _p(b1), _p(w2), _p(b2),
                 _p(w3), _p(b3), out_dim, float(blob_scale), float(blob_std), int(m_host),
@@ -103,6 +107,10 @@ class _HashMLPField(torch.autograd.Function):
         need = _b.get_lib().lnerf_mlp_backward_workspace_bytes(out_dim)
         if workspace is None or workspace.numel() < need:
             workspace = torch.empty(need, device=dev, dtype=torch.uint8)
+        elif precision == _b.BF16:
+            # this node's forward left the weight fragments at the head of the same workspace, and autograd's
+            # version check on the saved weights guarantees they have not changed since
+            precision |= _b.MLP_FRAGMENTS_READY
         fdt = _b.F32 if feat.dtype == torch.float32 else _b.BF16
         _b.call("lnerf_mlp_backward", _p(feat), fdt, int(level_stride), _p(xyzs), _p(w1), _p(b1), _p(w2), _p(b2),
                 _p(w3), _p(b3), out_dim, float(blob_scale), float(blob_std), int(m_host), _p(m_dev), _p(sigmas),

@@ -14,6 +14,7 @@ HEADER_PATH = os.path.join(REPO_ROOT, "include", "lnerf_hip.h")
 
 LNERF_OK = 0
 F32, BF16 = 0, 1
+MLP_FRAGMENTS_READY = 0x100   # flag on lnerf_mlp_backward's precision tag (include/lnerf_hip.h)
 
 
 class LnerfLibraryError(RuntimeError):

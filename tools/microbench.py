@@ -181,7 +181,7 @@ def main():
         from src.latent_nerf.models.network_grid import _SigmaLatentMLP
         featb = (torch.randn(16, cap, 2, device=dev) * 0.3).to(torch.bfloat16)
         fns = {}
-        for wps, nb in ((2, 512), (2, 1024), (4, 512), (4, 768), (4, 1024), (4, 2048)):
+        for wps, nb in ((2, 512), (2, 768), (2, 1024), (4, 1024), (2, 1280)):
             def f(n=nb, wps=wps):
                 B.call("lnerf_set_tuning", b"mlp_fwd_blocks", n)
                 B.call("lnerf_set_tuning", b"mlp_fwd_wps", wps)
@@ -190,8 +190,56 @@ def main():
                                           5.0, 0.2, B.BF16, net._mlp_ws)
             fns["mlp_fwd_bf16_wps%d_blocks%d" % (wps, nb)] = f
         res["mlp_ms(median,min)"] = timed(fns)
-        B.call("lnerf_set_tuning", b"mlp_fwd_blocks", 512)
+        B.call("lnerf_set_tuning", b"mlp_fwd_blocks", 768)
         B.call("lnerf_set_tuning", b"mlp_fwd_wps", 2)
+        # backward (recomputes the forward): real upstream gradients of the bench step
+        import src.latent_nerf.models.network_grid as NG
+        store, keep = {}, {}
+        orig, orig_chk = B.call, NG._chk
+
+        def spy(name, *a):
+            if name == "lnerf_mlp_backward" and "args" not in store:
+                store["args"] = list(a)
+            return orig(name, *a)
+
+        def chk(t_, name, *a_, **k_):
+            keep[name] = t_            # the upstream gradients stay allocated after autograd drops them
+            return orig_chk(t_, name, *a_, **k_)
+        NG._b.call = spy
+        NG._chk = chk
+        netb, _, _, bgb, gradb = bench.build(dev, "bf16", 0, 0, "bf16")
+        out3 = netb.render(rays_o, rays_d, bg_color=bgb, perturb=False)
+        out3["image"].backward(gradient=gradb, retain_graph=True)   # saved feat / sigmas stay allocated
+        NG._b.call = orig
+        NG._chk = orig_chk
+        args = store["args"]
+        capb = netb._march.capacity
+        mine = [torch.empty(16, capb, 2, device=dev)] + [torch.empty_like(p_) for p_ in
+                                                         (netb.w1, netb.b1, netb.w2, netb.b2, netb.w3, netb.b3)]
+        for i, t_ in enumerate(mine):
+            args[18 + i] = t_.data_ptr()
+        Mb = int(out3["counter"][0])
+        fns = {}
+        for var, nb in ((0, 512), (0, 448), (1, 256)):
+            def f(nb=nb, var=var):
+                B.call("lnerf_set_tuning", b"mlp_bwd_variant", var)
+                B.call("lnerf_set_tuning", b"mlp_bwd_blocks", nb)
+                B.call("lnerf_mlp_backward", *args)
+            fns["mlp_bwd_bf16_v%d_blocks%d" % (var, nb)] = f
+        # the variants against each other: dfeat and the six weight gradients of the same inputs
+        outs = {}
+        for k, f in fns.items():
+            for t_ in mine:
+                t_.fill_(float("nan"))
+            f()
+            torch.cuda.synchronize()
+            outs[k] = [mine[0][:, :Mb].clone()] + [t_.clone() for t_ in mine[1:]]
+        base = outs["mlp_bwd_bf16_v0_blocks512"]
+        res["mlp_bwd_vs_v0(max_abs_diff / max_abs)"] = {
+            k: [[float((a_ - b_).abs().max()), float(b_.abs().max())] for a_, b_ in zip(v, base)] for k, v in outs.items()}
+        res["mlp_bwd_ms(median,min)"] = timed(fns)
+        B.call("lnerf_set_tuning", b"mlp_bwd_blocks", 512)
+        B.call("lnerf_set_tuning", b"mlp_bwd_variant", 0)
 
     print(json.dumps(res))
 
