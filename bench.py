@@ -86,6 +86,12 @@ def parse():
     ap.add_argument("--probe-every", type=int, default=8)
     ap.add_argument("--grad-transport", default="auto", choices=["auto", "f32", "bf16"],
                     help="dtype of the table-gradient all-reduce at N > 1 (auto: follows --precision)")
+    ap.add_argument("--prefetch-rays", type=int, default=0,
+                    help="1: rays + march of step k+1 on a side stream while step k runs (two steps per captured graph). "
+                         "Measured on MI355X / ROCm 7.2: 0.4725 vs 0.4721 ms per step -- the replayed graph does not run "
+                         "the side branch concurrently -- hence off by default (profiles/r02_exp_ray_prefetch.jsonl)")
+    ap.add_argument("--tune", default="", help="lnerf_set_tuning overrides for an experiment: key=value,key=value "
+                    "(recorded in the output line; the default run sets none)")
     ap.add_argument("--exchange-groups", type=int, default=4,
                     help="N > 1, bf16 on the wire: level groups the table gradient is exchanged in, each group's all-reduce "
                          "launched behind its own sums (0 = one collective after the whole scatter)")
@@ -116,8 +122,12 @@ def build(dev, precision, variant, rank, table="f32", jitter_rng="kernel"):
     return net, pose, intr, bg, grad
 
 
-def make_step(net, pose, intr, bg, grad, opt, world, transport=torch.float32, perturb=True, exchange_groups=0):
-    """Returns (eager_step, fwd_bwd, opt_step, sync)."""
+def make_step(net, pose, intr, bg, grad, opt, world, transport=torch.float32, perturb=True, exchange_groups=0,
+              prefetch=False):
+    """Returns (eager_step, fwd_bwd, opt_step, sync).
+    prefetch: the rays + occupancy march of step k+1 (NeRFRenderer.prepare_rays: they read neither the hash table
+    nor the MLP) run on a side stream while step k is shaded and back-propagated; the two sample-buffer sets of the
+    renderer alternate.  Every step still does one ray generation, one march, one shade, one backward, one update."""
     from src.latent_nerf.raymarching import raymarching as rm
     from src.latent_nerf.training.distributed import GradSync
     small = [p for p in net.parameters() if p is not net.encoder.embeddings]
@@ -128,11 +138,35 @@ def make_step(net, pose, intr, bg, grad, opt, world, transport=torch.float32, pe
     pipelined = sink is not None and sink.groups is not None
     state = {}
 
-    def fwd_bwd():
+    side = torch.cuda.Stream() if prefetch else None
+
+    def prepare(slot):
         rays_o, rays_d = rm.get_rays(pose, intr, H, W)
-        out = net.render(rays_o, rays_d, bg_color=bg, perturb=perturb)
-        opt.arm()                        # N = 1: the scatter applies the table's Adam step (no-op otherwise)
+        return net.prepare_rays(rays_o, rays_d, bg_color=bg, perturb=perturb, slot=slot)
+
+    def fwd_bwd(flip=True):
+        if not prefetch:
+            rays_o, rays_d = rm.get_rays(pose, intr, H, W)
+            out = net.render(rays_o, rays_d, bg_color=bg, perturb=perturb)
+            opt.arm()                        # N = 1: the scatter applies the table's Adam step (no-op otherwise)
+            out["image"].backward(gradient=grad)
+            return out
+        main = torch.cuda.current_stream()
+        if "prep" not in state:
+            state["prep"], state["slot"] = prepare(0), 0
+        cur, slot = state["prep"], state["slot"]
+        if flip:   # fork: the next step's march goes to the other buffer set on the side stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                nxt = prepare(1 - slot)
+        out = net.render(None, None, prepared=cur)
+        opt.arm()
         out["image"].backward(gradient=grad)
+        if flip:
+            main.wait_stream(side)   # join
+            state["prep"], state["slot"] = nxt, 1 - slot
+        else:      # eager probe step between graph replays: same buffer set again, after the backward that reads it
+            state["prep"] = prepare(slot)
         return out
 
     def allreduce():
@@ -150,7 +184,7 @@ def make_step(net, pose, intr, bg, grad, opt, world, transport=torch.float32, pe
             opt.step(grad_scale=1.0 / world, grads=sync.reduced() if world > 1 else None)
 
     def step():
-        out = fwd_bwd()
+        out = fwd_bwd(False) if prefetch else fwd_bwd()
         allreduce()
         opt_step()
         return out
@@ -336,6 +370,11 @@ def main():
 
     from src.latent_nerf.raymarching import backend as B
     B.get_lib()  # no fallback: raise here if the HIP library is missing
+    tuned = {}
+    for kv in [t for t in args.tune.split(",") if t]:
+        k, v = kv.split("=")
+        B.call("lnerf_set_tuning", k.encode(), int(v))
+        tuned[k] = int(v)
     # everything (eager steps, graph capture, replays, collectives) runs on one non-default stream
     main_stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(main_stream)
@@ -353,8 +392,12 @@ def main():
     scatter_call = ("lnerf_grid_encode_backward_adam" if fuse else
                     "lnerf_grid_scatter_bin" if groups else
                     "lnerf_grid_encode_backward_bf16" if (world > 1 and tr == "bf16") else "lnerf_grid_encode_backward")
+    prefetch = bool(args.prefetch_rays)
+    if prefetch and world > 1:
+        raise SystemExit("--prefetch-rays 1 needs --gpus 1")
     step, fwd_bwd, opt_step, sync = make_step(net, pose, intr, bg, grad, opt, world,
-                                              torch.bfloat16 if tr == "bf16" else torch.float32, bool(args.perturb), groups)
+                                              torch.bfloat16 if tr == "bf16" else torch.float32, bool(args.perturb), groups,
+                                              prefetch)
 
     def barrier():
         if world > 1:
@@ -368,11 +411,18 @@ def main():
         from src.latent_nerf.training.graph_step import GraphedTrainStep
         # (a capture failure raises: the line must not silently describe eager launches; use --graph 0 for those)
         gstep = GraphedTrainStep(fwd_bwd, opt_step, list(net.parameters()), sync=sync, world=world, warmup=3,
-                                 stream=main_stream, opt_in_graph=not groups)
+                                 stream=main_stream, opt_in_graph=not groups, steps_per_graph=2 if prefetch else 1)
         launch = "hipgraph"
     emb0 = net.encoder.embeddings.detach().clone()
-    for i in range(args.warmup):
-        (gstep if (gstep is not None and i % 2) else step)()
+    spg = gstep.steps_per_call if gstep is not None else 1
+    i = 0
+    while i < args.warmup:   # eager and replayed steps alternate; never more than --warmup steps
+        if gstep is not None and (i // spg) % 2 and i + spg <= args.warmup:
+            gstep()
+            i += spg
+        else:
+            step()
+            i += 1
     torch.cuda.synchronize()
     log("warm-up done (%s)" % launch)
     timer = KernelTimer(["lnerf_grid_encode_forward", scatter_call, "lnerf_mlp_forward", "lnerf_mlp_backward",
@@ -383,15 +433,21 @@ def main():
     # eager probe steps: every --probe-every-th step; a run shorter than that still gets one (its last step), so that
     # the roofline object can always be measured live, whatever --steps the caller picks
     pe = max(1, args.probe_every)
-    probes = {i for i in range(args.steps) if i % pe == pe - 1} or {args.steps - 1}
-    for i in range(args.steps):
-        if gstep is None or i in probes:
+    i, since = 0, 0   # steps done; steps since the last probe
+    while i < args.steps:   # EXACTLY --steps steps: a replay is `spg` of them
+        left = args.steps - i
+        if gstep is None or since >= pe - 1 or (n_probe == 0 and left == 1):
             B.set_profile_hook(timer.hook)   # eager step: the gather is bracketed by HIP events on its stream
             out = step()
             B.set_profile_hook(None)
             n_probe += 1
+            i, since = i + 1, 0
+        elif left < spg or (n_probe == 0 and left <= spg):
+            out = step()                     # a remainder shorter than one replay
+            i, since = i + 1, since + 1
         else:
             out = gstep()
+            i, since = i + spg, since + spg
     host_enqueue = time.perf_counter() - t0   # host time to enqueue the steps (GPU runs behind)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -472,6 +528,8 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps,
             "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
             "launch": launch, "eager_probe_steps": n_probe,
+            "ray_prefetch": ("rays + occupancy march of step k+1 on a side stream during step k "
+                             "(NeRFRenderer.prepare_rays, two buffer sets, two steps per captured graph)") if prefetch else None,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -496,6 +554,8 @@ def main():
         if breakdown:
             res["kernel_ms_per_step"] = breakdown
         res["build"] = build_tag
+        if tuned:
+            res["tuning_overrides"] = tuned
         if not args.no_extras and world == 1:
             ms = time_occ_refresh(net)
             iv = net.cfg.update_extra_interval

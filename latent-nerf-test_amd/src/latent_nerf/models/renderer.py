@@ -36,6 +36,15 @@ def _sample_pdf(bins, weights, n_samples, stratified):
     return b0 + t * (b1 - b0)
 
 
+class PreparedRays:
+    """Output of NeRFRenderer.prepare_rays(): the marched samples of one view (a MarchResult in one of the renderer's
+    two sample-buffer sets), its background colours and the ray-batch shape."""
+    __slots__ = ("march", "bg", "prefix", "N", "cap")
+
+    def __init__(self, march, bg, prefix, N, cap):
+        self.march, self.bg, self.prefix, self.N, self.cap = march, bg, prefix, N, cap
+
+
 class NeRFRenderer(nn.Module):
     def __init__(self, cfg, latent_mode: bool = True):
         super().__init__()
@@ -59,7 +68,8 @@ class NeRFRenderer(nn.Module):
         self.mean_density = 0.0
         self.iter_density = 0
         self.local_step = 0
-        self._march = None
+        self._march = None            # the most recent training march
+        self._march_slots = [None, None]  # two sample-buffer sets: prepare_rays(slot=...) alternates them when pipelined
         self._march_key = None
         self._budget = None       # ((N, max_steps), capacity) derived from observed marches
         self._m_peak = None       # device int32 [1]: largest M since the last budget update
@@ -145,35 +155,56 @@ class NeRFRenderer(nn.Module):
             self._noise_counter = torch.zeros(1, device=dev, dtype=torch.int32)
         return (int(seed), self._noise_counter)
 
-    def run_cuda(self, rays_o, rays_d, dt_gamma=0.0, bg_color=None, perturb=False, force_all_rays=False,
-                 max_steps=1024, T_thresh=1e-4, **kwargs):
-        """rays_o, rays_d [B,N,3] -> dict(image [B,N,C], depth [B,N], weights_sum [B,N]).
-        Training mode: march -> hash gather -> MLP -> composite, all on device, no host sync;
-        additionally returns the capacity-sized 'xyzs'/'sigmas' with the device counter 'counter'."""
-        prefix = rays_o.shape[:-1]
-        rays_o = rays_o.contiguous().view(-1, 3).float()
-        rays_d = rays_d.contiguous().view(-1, 3).float()
-        N = rays_o.shape[0]
-        C = self.img_dims
+    def _near_far(self, rays_o, rays_d):
         aabb = self.aabb_train if self.training else self.aabb_infer
         a = [-self.bound] * 3 + [self.bound] * 3 if aabb is None else aabb
         if torch.is_tensor(a) and a.is_cuda:
             a = self._aabb_host(a)
-        nears, fars = rm.near_far_from_aabb(rays_o, rays_d, a, self.min_near)
-        bg = self._bg_tensor(bg_color, rays_d, N, C)
+        return rm.near_far_from_aabb(rays_o, rays_d, a, self.min_near)
+
+    def prepare_rays(self, rays_o, rays_d, dt_gamma=0.0, bg_color=None, perturb=False, max_steps=1024, slot=0, **kwargs):
+        """The part of a TRAINING render that depends only on the rays and the occupancy bitfield -- AABB clip,
+        background, occupancy-pruned march -- done ahead of time into sample-buffer set `slot` (0 or 1).  Returns
+        a PreparedRays that `render(..., prepared=p)` / `run_cuda(..., prepared=p)` shades.  A training loop that
+        knows its next view calls this for view k+1 on a side stream while view k is shaded and back-propagated
+        (Trainer / bench.py: the two sets alternate); nothing in it reads the hash table or the MLP, so the result is
+        the one the un-pipelined order gives as long as the bitfield is not refreshed in between (after
+        update_extra_state() prepare again)."""
+        if not self.training:
+            raise RuntimeError("prepare_rays is the training-mode march; inference marches adaptively inside run_cuda")
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3).float()
+        rays_d = rays_d.contiguous().view(-1, 3).float()
+        N = rays_o.shape[0]
+        nears, fars = self._near_far(rays_o, rays_d)
+        bg = self._bg_tensor(bg_color, rays_d, N, self.img_dims)
+        cap = self._capacity(N, max_steps)
+        march = rm.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
+                                    self.grid_size, nears, fars, perturb=perturb, dt_gamma=dt_gamma,
+                                    max_steps=max_steps, capacity=cap, out=self._march_slots[slot],
+                                    noises=kwargs.get("noises"), noise_state=self._noise_state(rays_o.device))
+        self._march_slots[slot] = march
+        self._march = march
+        if self._march_key != (N, int(max_steps)) or self._m_peak is None:
+            self._march_key = (N, int(max_steps))
+            self._m_peak = torch.zeros(1, device=rays_o.device, dtype=torch.int32)
+        if self.cfg.max_samples <= 0:   # running peak of M, on the device (one tiny launch, no host sync)
+            torch.maximum(self._m_peak, march.counter[0:1], out=self._m_peak)
+        return PreparedRays(march, bg, prefix, N, cap)
+
+    def run_cuda(self, rays_o, rays_d, dt_gamma=0.0, bg_color=None, perturb=False, force_all_rays=False,
+                 max_steps=1024, T_thresh=1e-4, prepared=None, **kwargs):
+        """rays_o, rays_d [B,N,3] -> dict(image [B,N,C], depth [B,N], weights_sum [B,N]).
+        Training mode: march -> hash gather -> MLP -> composite, all on device, no host sync;
+        additionally returns the capacity-sized 'xyzs'/'sigmas' with the device counter 'counter'.
+        prepared: a PreparedRays of prepare_rays() (rays_o / rays_d are then ignored and may be None)."""
+        C = self.img_dims
         results = {}
         if self.training:
-            cap = self._capacity(N, max_steps)
-            march = rm.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
-                                        self.grid_size, nears, fars, perturb=perturb, dt_gamma=dt_gamma,
-                                        max_steps=max_steps, capacity=cap, out=self._march,
-                                        noises=kwargs.get("noises"), noise_state=self._noise_state(rays_o.device))
-            self._march = march
-            if self._march_key != (N, int(max_steps)) or self._m_peak is None:
-                self._march_key = (N, int(max_steps))
-                self._m_peak = torch.zeros(1, device=rays_o.device, dtype=torch.int32)
-            if self.cfg.max_samples <= 0:   # running peak of M, on the device (one tiny launch, no host sync)
-                torch.maximum(self._m_peak, march.counter[0:1], out=self._m_peak)
+            if prepared is None:
+                prepared = self.prepare_rays(rays_o, rays_d, dt_gamma=dt_gamma, bg_color=bg_color, perturb=perturb,
+                                             max_steps=max_steps, **kwargs)
+            march, bg, prefix, N, cap = prepared.march, prepared.bg, prepared.prefix, prepared.N, prepared.cap
             self.local_step += 1
             m_dev = march.counter[0:1]
             sigmas, rgbs = self.field(march.xyzs, cap, m_dev, cap)
@@ -182,6 +213,12 @@ class NeRFRenderer(nn.Module):
             results.update(xyzs=march.xyzs, sigmas=sigmas, counter=march.counter, rays=march.rays,
                            deltas=march.deltas)
         else:
+            prefix = rays_o.shape[:-1]
+            rays_o = rays_o.contiguous().view(-1, 3).float()
+            rays_d = rays_d.contiguous().view(-1, 3).float()
+            N = rays_o.shape[0]
+            nears, fars = self._near_far(rays_o, rays_d)
+            bg = self._bg_tensor(bg_color, rays_d, N, C)
             dev = rays_o.device
             weights_sum = torch.zeros(N, device=dev)
             depth = torch.zeros(N, device=dev)
@@ -336,6 +373,8 @@ class NeRFRenderer(nn.Module):
         if not self.cuda_ray:   # the uniform sampler takes its sample counts from the config (render.num_steps / upsample_steps)
             kwargs.setdefault("num_steps", self.cfg.num_steps)
             kwargs.setdefault("upsample_steps", self.cfg.upsample_steps)
+        if kwargs.get("prepared") is not None:
+            return self.run_cuda(None, None, **kwargs)
         B, N = rays_o.shape[:2]
         if staged and not self.cuda_ray:
             dev = rays_o.device

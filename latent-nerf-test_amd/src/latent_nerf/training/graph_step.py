@@ -10,7 +10,8 @@ import torch
 
 
 class GraphedTrainStep:
-    def __init__(self, fwd_bwd, opt_step, params, sync=None, world=1, warmup=3, stream=None, opt_in_graph=True):
+    def __init__(self, fwd_bwd, opt_step, params, sync=None, world=1, warmup=3, stream=None, opt_in_graph=True,
+                 steps_per_graph=1):
         """fwd_bwd() -> dict of output tensors (leaves `.grad` set on `params`);
         opt_step() consumes the gradients; sync() all-reduces `.grad` in place (world > 1).
 
@@ -19,7 +20,14 @@ class GraphedTrainStep:
         it first ran on, and accumulation on the legacy default stream cannot be captured.
 
         opt_in_graph=False (world > 1, pipelined exchange): the optimiser step stays eager -- it waits for one level
-        group's all-reduce at a time (FusedAdam.step(row_groups=...)), which a captured graph cannot express."""
+        group's all-reduce at a time (FusedAdam.step(row_groups=...)), which a captured graph cannot express.
+
+        steps_per_graph (world == 1): that many whole steps per captured graph -- 2 for a `fwd_bwd` that alternates
+        between two buffer sets (rays of step k+1 marched on a side stream while step k is shaded), whose pointers a
+        one-step graph could not alternate.  `__call__` then runs that many steps; `self.steps_per_call` says so."""
+        if steps_per_graph != 1 and world != 1:
+            raise ValueError("steps_per_graph > 1 needs world == 1")
+        self.steps_per_call = int(steps_per_graph)
         self.opt_step = opt_step
         self.world = world
         self.sync = sync
@@ -44,9 +52,13 @@ class GraphedTrainStep:
         self.graph_b = None
         if world == 1:
             with torch.cuda.graph(self.graph_a, stream=stream):
-                self.out = fwd_bwd()
-                self.static_grads = [p.grad for p in self.params]  # graph-pool tensors, rewritten by every replay
-                opt_step()
+                for _ in range(self.steps_per_call):
+                    self.out = fwd_bwd()
+                    self.static_grads = [p.grad for p in self.params]  # graph-pool tensors, rewritten by every replay
+                    opt_step()
+                    if self.steps_per_call > 1:
+                        for p in self.params:   # the next step's backward creates its gradients anew
+                            p.grad = None
         else:
             with torch.cuda.graph(self.graph_a, stream=stream):
                 self.out = fwd_bwd()
