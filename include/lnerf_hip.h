@@ -113,6 +113,15 @@ int lnerf_march_rays_train(const float *rays_o, const float *rays_d, const float
                            float dt_gamma, const float *noises, uint32_t noise_seed, int32_t *noise_counter,
                            int64_t capacity, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
                            lnerf_stream_t stream);
+/* The same with the AABB clip of lnerf_near_far_from_aabb done inside the two march passes (identical arithmetic):
+ * the training path of `NeRFRenderer.run_cuda` (SURVEY.md §8(a) H2 -> H4, line 465) calls near_far_from_aabb only
+ * to feed march_rays_train, and in a replayed graph every dispatch of a few thousand rays costs ~4.5 us whatever it
+ * computes. */
+int lnerf_march_rays_train_aabb(const float *rays_o, const float *rays_d, float xmin, float ymin, float zmin, float xmax,
+                                float ymax, float zmax, float min_near, int64_t N, const uint8_t *bitfield, float bound,
+                                int cascade, int grid_size, int max_steps, float dt_gamma, const float *noises,
+                                uint32_t noise_seed, int32_t *noise_counter, int64_t capacity, float *xyzs, float *dirs,
+                                float *deltas, int32_t *rays, int32_t *counter, lnerf_stream_t stream);
 
 /* ---- H4 (inference): `raymarching.march_rays` / `composite_rays` and the live-ray compaction
  * the upstream renderer does on the host (`rays_alive = rays_alive[rays_alive >= 0]`). */
@@ -300,7 +309,11 @@ int lnerf_adam_step(float *p, void *g, int grad_dtype, float *m, float *v, void 
  * captured hipGraph of the whole optimisation step can be replayed; lnerf_adam_tick() increments it. */
 int lnerf_adam_tick(int32_t *step_dev, lnerf_stream_t stream);
 /* The same update for up to 16 small tensors in ONE launch (MLP / background parameters).  The pointer
- * and size arrays are HOST arrays of `count` entries holding device pointers. */
+ * and size arrays are HOST arrays of `count` entries holding device pointers.
+ * zero_grad | LNERF_ADAM_TICK: the launch also advances *step_dev once all its workgroups have read it (saves the
+ * lnerf_adam_tick dispatch when this is the step's last Adam launch); step_dev is then int32[2], [1] = 0 on entry
+ * (arrival counter, 0 again on exit). */
+#define LNERF_ADAM_TICK 2
 int lnerf_adam_step_multi(int count, float *const *p_host, float *const *g_host, float *const *m_host,
                           float *const *v_host, const int64_t *n_host, const float *lr_host, float beta1, float beta2,
                           float eps, int step, const int32_t *step_dev, float grad_scale, int zero_grad,

@@ -69,8 +69,22 @@ struct AdamMulti {
     int64_t n[ADAM_MULTI_MAX];
     float lr[ADAM_MULTI_MAX];
 };
-__global__ void __launch_bounds__(256) k_adam_multi(AdamMulti t, AdamArgs a) {
+// tick: the last workgroup to finish advances the device step counter (every workgroup has read it by then) -- the
+// separate one-thread launch of lnerf_adam_tick costs a whole dispatch (~4 us in a replayed graph).  step_dev[1] is
+// the arrival counter (left at 0 again).
+__global__ void __launch_bounds__(256) k_adam_multi(AdamMulti t, AdamArgs a, int32_t *tick) {
     adam_bias(a);
+    if (tick) {
+        __syncthreads();   // every thread of this workgroup has taken its bias corrections from the counter
+        if (threadIdx.x == 0) {
+            __threadfence();
+            const int total = (int)(gridDim.x * gridDim.y);
+            if (atomicAdd(&tick[1], 1) == total - 1) {
+                tick[1] = 0;
+                tick[0] += 1;
+            }
+        }
+    }
     const int k = blockIdx.y;
     a.lr = t.lr[k];
     float *p = t.p[k], *g = t.g[k], *m = t.m[k], *v = t.v[k];
@@ -165,12 +179,15 @@ int lnerf_adam_step_multi(int count, float *const *p_host, float *const *g_host,
     a.bc1 = (float)(1.0 - pow((double)beta1, (double)(step < 1 ? 1 : step)));
     a.bc2 = (float)(1.0 - pow((double)beta2, (double)(step < 1 ? 1 : step)));
     a.grad_scale = grad_scale;
-    a.zero_grad = zero_grad;
+    a.zero_grad = zero_grad & 1;
     a.step_dev = step_dev;
+    const bool tick = (zero_grad & LNERF_ADAM_TICK) != 0;
+    LNERF_REQUIRE(!tick || step_dev, "adam_step_multi: LNERF_ADAM_TICK needs the device step counter");
     int64_t bx = div_up(nmax, 256);
     if (bx < 1) bx = 1;
     if (bx > 64) bx = 64;
-    hipLaunchKernelGGL(k_adam_multi, dim3((unsigned)bx, (unsigned)count), dim3(256), 0, as_stream(stream), t, a);
+    hipLaunchKernelGGL(k_adam_multi, dim3((unsigned)bx, (unsigned)count), dim3(256), 0, as_stream(stream), t, a,
+                       tick ? const_cast<int32_t *>(step_dev) : nullptr);
     LNERF_CHECK_LAUNCH("adam_step_multi");
     return LNERF_OK;
 }

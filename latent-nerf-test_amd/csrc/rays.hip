@@ -31,22 +31,29 @@ __global__ void __launch_bounds__(256) k_get_rays(const float *__restrict__ c2w,
 }
 
 // ------------------------------------------------------------------ H2
+struct RayBox {   // axis-aligned box + minimum near distance (by value)
+    float xmin, ymin, zmin, xmax, ymax, zmax, min_near;
+};
+__device__ __forceinline__ void ray_box(float ox, float oy, float oz, float dx, float dy, float dz, const RayBox &b,
+                                        float &near, float &far) {
+    const float rdx = 1.0f / dx, rdy = 1.0f / dy, rdz = 1.0f / dz;
+    const float ax = (b.xmin - ox) * rdx, bx = (b.xmax - ox) * rdx;
+    const float ay = (b.ymin - oy) * rdy, by = (b.ymax - oy) * rdy;
+    const float az = (b.zmin - oz) * rdz, bz = (b.zmax - oz) * rdz;
+    near = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    far = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    bool miss = !(far >= near);
+    near = fmaxf(near, b.min_near);
+    miss = miss || !(far >= near);
+    if (miss) near = far = 3.4028234663852886e38f;
+}
 __global__ void __launch_bounds__(256) k_near_far(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
-                                                  int64_t N, float xmin, float ymin, float zmin, float xmax, float ymax,
-                                                  float zmax, float min_near, float *__restrict__ nears,
+                                                  int64_t N, RayBox box, float *__restrict__ nears,
                                                   float *__restrict__ fars) {
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
-        const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
-        const float rdx = 1.0f / rays_d[n * 3], rdy = 1.0f / rays_d[n * 3 + 1], rdz = 1.0f / rays_d[n * 3 + 2];
-        const float ax = (xmin - ox) * rdx, bx = (xmax - ox) * rdx;
-        const float ay = (ymin - oy) * rdy, by = (ymax - oy) * rdy;
-        const float az = (zmin - oz) * rdz, bz = (zmax - oz) * rdz;
-        float near = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-        float far = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-        bool miss = !(far >= near);
-        near = fmaxf(near, min_near);
-        miss = miss || !(far >= near);
-        if (miss) near = far = 3.4028234663852886e38f;
+        float near, far;
+        ray_box(rays_o[n * 3], rays_o[n * 3 + 1], rays_o[n * 3 + 2], rays_d[n * 3], rays_d[n * 3 + 1], rays_d[n * 3 + 2],
+                box, near, far);
         nears[n] = near;
         fars[n] = far;
     }
@@ -155,13 +162,19 @@ __device__ __forceinline__ float march_noise(const MarchNoise &nz, int64_t n) {
 template <bool WRITE, bool UNIFORM_DT>
 __global__ void __launch_bounds__(256)
 k_march_train(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ nears,
-              const float *__restrict__ fars, int64_t N, const uint8_t *__restrict__ bitfield, MarchParams P,
+              const float *__restrict__ fars, RayBox box, int clip, int64_t N, const uint8_t *__restrict__ bitfield, MarchParams P,
               MarchNoise noises, float *__restrict__ xyzs, float *__restrict__ dirs,
               float *__restrict__ deltas, int32_t *__restrict__ rays) {
     const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform
     if (n >= N) return;
     const int lane = lane_id();
-    const float near = nears[n], far = fars[n];
+    float near, far;
+    if (clip) {   // the AABB clip of lnerf_near_far_from_aabb, here: one dispatch less per view (same arithmetic)
+        ray_box(rays_o[n * 3], rays_o[n * 3 + 1], rays_o[n * 3 + 2], rays_d[n * 3], rays_d[n * 3 + 1], rays_d[n * 3 + 2],
+                box, near, far);
+    } else {
+        near = nears[n]; far = fars[n];
+    }
     int count = 0;
     int64_t offset = 0;
     int budget = P.max_steps;
@@ -510,8 +523,8 @@ int lnerf_near_far_from_aabb(const float *rays_o, const float *rays_d, int64_t N
     if (N == 0) return LNERF_OK;
     LNERF_REQUIRE(rays_o && rays_d && nears && fars, "near_far_from_aabb: null pointer");
     LNERF_REQUIRE(xmin <= xmax && ymin <= ymax && zmin <= zmax, "near_far_from_aabb: inverted aabb");
-    hipLaunchKernelGGL(k_near_far, dim3(grid_for(N)), dim3(256), 0, as_stream(stream), rays_o, rays_d, N, xmin, ymin,
-                       zmin, xmax, ymax, zmax, min_near, nears, fars);
+    const RayBox box{xmin, ymin, zmin, xmax, ymax, zmax, min_near};
+    hipLaunchKernelGGL(k_near_far, dim3(grid_for(N)), dim3(256), 0, as_stream(stream), rays_o, rays_d, N, box, nears, fars);
     LNERF_CHECK_LAUNCH("near_far_from_aabb");
     return LNERF_OK;
 }
@@ -559,11 +572,11 @@ static int check_march_common(const char *who, float bound, int cascade, int gri
     return LNERF_OK;
 }
 
-int lnerf_march_rays_train(const float *rays_o, const float *rays_d, const float *nears, const float *fars, int64_t N,
-                           const uint8_t *bitfield, float bound, int cascade, int grid_size, int max_steps,
-                           float dt_gamma, const float *noises, uint32_t noise_seed, int32_t *noise_counter,
-                           int64_t capacity, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
-                           lnerf_stream_t stream) {
+static int march_train_impl(const float *rays_o, const float *rays_d, const float *nears, const float *fars,
+                            const RayBox *clip_box, int64_t N, const uint8_t *bitfield, float bound, int cascade,
+                            int grid_size, int max_steps, float dt_gamma, const float *noises, uint32_t noise_seed,
+                            int32_t *noise_counter, int64_t capacity, float *xyzs, float *dirs, float *deltas,
+                            int32_t *rays, int32_t *counter, lnerf_stream_t stream) {
     int rc = check_march_common("march_rays_train", bound, cascade, grid_size, max_steps, dt_gamma);
     if (rc) return rc;
     LNERF_REQUIRE(N >= 0 && N <= ((int64_t)1 << 24), "march_rays_train: N out of range (%lld)", (long long)N);
@@ -574,31 +587,56 @@ int lnerf_march_rays_train(const float *rays_o, const float *rays_d, const float
         (void)hipMemsetAsync(counter, 0, 4 * sizeof(int32_t), as_stream(stream));
         return LNERF_OK;
     }
-    LNERF_REQUIRE(rays_o && rays_d && nears && fars && bitfield && rays, "march_rays_train: null pointer");
+    LNERF_REQUIRE(rays_o && rays_d && (clip_box || (nears && fars)) && bitfield && rays, "march_rays_train: null pointer");
     LNERF_REQUIRE(capacity == 0 || (xyzs && dirs && deltas), "march_rays_train: null sample buffers");
     const MarchParams P = make_params(bound, cascade, grid_size, max_steps, dt_gamma);
     const dim3 block(256), grid((unsigned)div_up(N, 4));  // 4 wavefronts (rays) per workgroup
     hipStream_t s = as_stream(stream);
+    RayBox box{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int clip = clip_box ? 1 : 0;
+    if (clip_box) box = *clip_box;
     MarchNoise nz;
     nz.values = noises; nz.counter = noise_counter; nz.seed = noise_seed; nz.bias = 0;
     if (dt_gamma == 0.f)
-        hipLaunchKernelGGL((k_march_train<false, true>), grid, block, 0, s, rays_o, rays_d, nears, fars, N, bitfield, P,
-                           nz, xyzs, dirs, deltas, rays);
+        hipLaunchKernelGGL((k_march_train<false, true>), grid, block, 0, s, rays_o, rays_d, nears, fars, box, clip, N,
+                           bitfield, P, nz, xyzs, dirs, deltas, rays);
     else
-        hipLaunchKernelGGL((k_march_train<false, false>), grid, block, 0, s, rays_o, rays_d, nears, fars, N, bitfield,
-                           P, nz, xyzs, dirs, deltas, rays);
+        hipLaunchKernelGGL((k_march_train<false, false>), grid, block, 0, s, rays_o, rays_d, nears, fars, box, clip, N,
+                           bitfield, P, nz, xyzs, dirs, deltas, rays);
     LNERF_CHECK_LAUNCH("march_rays_train(count)");
     hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, s, rays, N, capacity, counter, noise_counter);
     LNERF_CHECK_LAUNCH("march_rays_train(scan)");
     nz.bias = 1;
     if (dt_gamma == 0.f)
-        hipLaunchKernelGGL((k_march_train<true, true>), grid, block, 0, s, rays_o, rays_d, nears, fars, N, bitfield, P,
-                           nz, xyzs, dirs, deltas, rays);
+        hipLaunchKernelGGL((k_march_train<true, true>), grid, block, 0, s, rays_o, rays_d, nears, fars, box, clip, N,
+                           bitfield, P, nz, xyzs, dirs, deltas, rays);
     else
-        hipLaunchKernelGGL((k_march_train<true, false>), grid, block, 0, s, rays_o, rays_d, nears, fars, N, bitfield, P,
-                           nz, xyzs, dirs, deltas, rays);
+        hipLaunchKernelGGL((k_march_train<true, false>), grid, block, 0, s, rays_o, rays_d, nears, fars, box, clip, N,
+                           bitfield, P, nz, xyzs, dirs, deltas, rays);
     LNERF_CHECK_LAUNCH("march_rays_train(write)");
     return LNERF_OK;
+}
+
+int lnerf_march_rays_train(const float *rays_o, const float *rays_d, const float *nears, const float *fars, int64_t N,
+                           const uint8_t *bitfield, float bound, int cascade, int grid_size, int max_steps,
+                           float dt_gamma, const float *noises, uint32_t noise_seed, int32_t *noise_counter,
+                           int64_t capacity, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
+                           lnerf_stream_t stream) {
+    return march_train_impl(rays_o, rays_d, nears, fars, nullptr, N, bitfield, bound, cascade, grid_size, max_steps,
+                            dt_gamma, noises, noise_seed, noise_counter, capacity, xyzs, dirs, deltas, rays, counter,
+                            stream);
+}
+
+int lnerf_march_rays_train_aabb(const float *rays_o, const float *rays_d, float xmin, float ymin, float zmin, float xmax,
+                                float ymax, float zmax, float min_near, int64_t N, const uint8_t *bitfield, float bound,
+                                int cascade, int grid_size, int max_steps, float dt_gamma, const float *noises,
+                                uint32_t noise_seed, int32_t *noise_counter, int64_t capacity, float *xyzs, float *dirs,
+                                float *deltas, int32_t *rays, int32_t *counter, lnerf_stream_t stream) {
+    LNERF_REQUIRE(xmin <= xmax && ymin <= ymax && zmin <= zmax, "march_rays_train_aabb: inverted aabb");
+    const RayBox box{xmin, ymin, zmin, xmax, ymax, zmax, min_near};
+    return march_train_impl(rays_o, rays_d, nullptr, nullptr, &box, N, bitfield, bound, cascade, grid_size, max_steps,
+                            dt_gamma, noises, noise_seed, noise_counter, capacity, xyzs, dirs, deltas, rays, counter,
+                            stream);
 }
 
 int lnerf_march_rays(int64_t n_alive, int n_step, const int32_t *rays_alive, const float *rays_t, const float *rays_o,

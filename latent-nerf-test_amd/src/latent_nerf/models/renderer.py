@@ -155,12 +155,15 @@ class NeRFRenderer(nn.Module):
             self._noise_counter = torch.zeros(1, device=dev, dtype=torch.int32)
         return (int(seed), self._noise_counter)
 
-    def _near_far(self, rays_o, rays_d):
+    def _aabb_values(self):
         aabb = self.aabb_train if self.training else self.aabb_infer
         a = [-self.bound] * 3 + [self.bound] * 3 if aabb is None else aabb
         if torch.is_tensor(a) and a.is_cuda:
             a = self._aabb_host(a)
-        return rm.near_far_from_aabb(rays_o, rays_d, a, self.min_near)
+        return a
+
+    def _near_far(self, rays_o, rays_d):
+        return rm.near_far_from_aabb(rays_o, rays_d, self._aabb_values(), self.min_near)
 
     def prepare_rays(self, rays_o, rays_d, dt_gamma=0.0, bg_color=None, perturb=False, max_steps=1024, slot=0, **kwargs):
         """The part of a TRAINING render that depends only on the rays and the occupancy bitfield -- AABB clip,
@@ -176,13 +179,16 @@ class NeRFRenderer(nn.Module):
         rays_o = rays_o.contiguous().view(-1, 3).float()
         rays_d = rays_d.contiguous().view(-1, 3).float()
         N = rays_o.shape[0]
-        nears, fars = self._near_far(rays_o, rays_d)
         bg = self._bg_tensor(bg_color, rays_d, N, self.img_dims)
         cap = self._capacity(N, max_steps)
+        a = self._aabb_values()
+        a = [float(v) for v in (a.tolist() if torch.is_tensor(a) else a)]
+        # (the AABB clip runs inside the march passes: near_far_from_aabb's arithmetic, one dispatch less)
         march = rm.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
-                                    self.grid_size, nears, fars, perturb=perturb, dt_gamma=dt_gamma,
+                                    self.grid_size, None, None, perturb=perturb, dt_gamma=dt_gamma,
                                     max_steps=max_steps, capacity=cap, out=self._march_slots[slot],
-                                    noises=kwargs.get("noises"), noise_state=self._noise_state(rays_o.device))
+                                    noises=kwargs.get("noises"), noise_state=self._noise_state(rays_o.device),
+                                    aabb=a, min_near=self.min_near)
         self._march_slots[slot] = march
         self._march = march
         if self._march_key != (N, int(max_steps)) or self._m_peak is None:

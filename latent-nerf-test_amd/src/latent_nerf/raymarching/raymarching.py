@@ -120,8 +120,11 @@ class MarchResult:
 
 
 def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, perturb=False, dt_gamma=0.0,
-                     max_steps=1024, capacity=None, noises=None, out=None, noise_state=None):
+                     max_steps=1024, capacity=None, noises=None, out=None, noise_state=None, aabb=None, min_near=0.0):
     """Occupancy-pruned march of N rays.  Returns a MarchResult.
+
+    nears / fars [N] from near_far_from_aabb -- or None with `aabb` = six host floats (+ `min_near`): the clip is
+    then done inside the march passes (lnerf_march_rays_train_aabb: same arithmetic, one dispatch less).
 
     capacity: sample buffer size (default N * min(max_steps, 256)); rays that would overflow it
     are dropped and counted in counter[2].  `out` may pass a previous MarchResult to reuse its
@@ -154,6 +157,13 @@ def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars,
         deltas = torch.empty(capacity, 2, device=dev, dtype=torch.float32)
         rays = torch.empty(N, 3, device=dev, dtype=torch.int32)
         counter = torch.empty(4, device=dev, dtype=torch.int32)
+    if nears is None and aabb is not None:
+        _b.call("lnerf_march_rays_train_aabb", _chk(rays_o, "rays_o"), _chk(rays_d, "rays_d"),
+                *[float(v) for v in aabb], float(min_near), N, _chk(density_bitfield, "density_bitfield", torch.uint8),
+                float(bound), int(C), int(H), int(max_steps), float(dt_gamma), _chk(noises, "noises", allow_none=True),
+                seed, _chk(noise_counter, "noise_counter", torch.int32, allow_none=True), int(capacity), _p(xyzs),
+                _p(dirs), _p(deltas), _p(rays), _p(counter), _stream())
+        return MarchResult(xyzs, dirs, deltas, rays, counter, capacity)
     _b.call("lnerf_march_rays_train", _chk(rays_o, "rays_o"), _chk(rays_d, "rays_d"), _chk(nears, "nears"),
             _chk(fars, "fars"), N, _chk(density_bitfield, "density_bitfield", torch.uint8), float(bound), int(C),
             int(H), int(max_steps), float(dt_gamma), _chk(noises, "noises", allow_none=True), seed,

@@ -46,7 +46,7 @@ class FusedAdam:
         self._lr = (ctypes.c_float * n)(*[e[3] for e in self.small])
         if capturable:
             dev = (self.big + self.small)[0][0].device
-            self.step_dev = torch.ones(1, device=dev, dtype=torch.int32)  # value used by the NEXT step
+            self.step_dev = torch.tensor([1, 0], device=dev, dtype=torch.int32)  # [0]: value used by the NEXT step; [1]: arrival counter of the ticking launch
         if fuse_table_update:
             if encoder is None:
                 raise ValueError("fuse_table_update needs the encoder")
@@ -112,9 +112,11 @@ class FusedAdam:
                     raise RuntimeError("FusedAdam: parameter %d has no gradient" % k)
                 self._pp[k] = p.data.data_ptr()
                 self._gp[k] = p.grad.data_ptr()
+            # (with the device counter this launch, the step's last Adam launch, also advances it: LNERF_ADAM_TICK = 2)
             _b.call("lnerf_adam_step_multi", len(self.small), self._pp, self._gp, self._mp, self._vp, self._n, self._lr,
-                    b1, b2, self.eps, self.step_no, _p(self.step_dev), float(grad_scale), 0, _stream())
-        if self.step_dev is not None:
+                    b1, b2, self.eps, self.step_no, _p(self.step_dev), float(grad_scale),
+                    2 if self.step_dev is not None else 0, _stream())
+        elif self.step_dev is not None:
             _b.call("lnerf_adam_tick", _p(self.step_dev), _stream())
         if set_to_none:
             for p, *_ in self.big + self.small:
@@ -135,4 +137,4 @@ class FusedAdam:
             m.copy_(sm)
             v.copy_(sv)
         if self.step_dev is not None:
-            self.step_dev.fill_(self.step_no + 1)
+            self.step_dev[0:1].fill_(self.step_no + 1)

@@ -99,6 +99,13 @@ def _march_both(dev, ro, rd, bits, bound, cascade, G, max_steps, dt_gamma, noise
     res = rm.march_rays_train(ro.to(dev), rd.to(dev), bound, bits.to(dev), cascade, G, nears.to(dev), fars.to(dev),
                               dt_gamma=dt_gamma, max_steps=max_steps, capacity=capacity,
                               noises=None if noises is None else noises.to(dev))
+    # the form that clips against the box inside the march passes (lnerf_march_rays_train_aabb) is the same march
+    res2 = rm.march_rays_train(ro.to(dev), rd.to(dev), bound, bits.to(dev), cascade, G, None, None,
+                               dt_gamma=dt_gamma, max_steps=max_steps, capacity=capacity,
+                               noises=None if noises is None else noises.to(dev), aabb=aabb, min_near=0.1)
+    M = int(res.counter[0])
+    assert torch.equal(res2.counter.cpu(), res.counter.cpu()) and torch.equal(res2.rays.cpu(), res.rays.cpu())
+    assert torch.equal(res2.xyzs[:M].cpu(), res.xyzs[:M].cpu()) and torch.equal(res2.deltas[:M].cpu(), res.deltas[:M].cpu())
     return ref, res
 
 

@@ -243,11 +243,11 @@ def test_graphed_step_matches_eager(dev):
         opt = FusedAdam(net.get_params(1e-3), encoder=net.encoder, capturable=True)
         gs2 = GraphedTrainStep(fwd_bwd, lambda: opt.step(), plist, world=1, warmup=1, stream=stream)
         before = net.w2.detach().clone()
-        c0 = int(opt.step_dev.item())
+        c0 = int(opt.step_dev[0].item())
         for _ in range(3):
             gs2()
         stream.synchronize()
-        assert int(opt.step_dev.item()) == c0 + 3
+        assert int(opt.step_dev[0].item()) == c0 + 3
         assert float((net.w2.detach() - before).abs().max()) > 0
         assert bool(torch.isfinite(net.encoder.embeddings).all())
     torch.cuda.synchronize()
