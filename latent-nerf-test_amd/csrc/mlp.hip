@@ -437,6 +437,11 @@ int lnerf_mlp_forward(const void *feat, int feat_dtype, int64_t level_stride, co
     return LNERF_OK;
 }
 
+#ifdef LNERF_STAMPS
+// diagnostic builds only: read (and clear) the per-phase shader-clock totals of the bf16 MLP kernels
+int lnerf_debug_mlp_stamps(unsigned long long *out32) { return lnerf::mlp_stamps_read(out32); }
+#endif
+
 size_t lnerf_mlp_backward_workspace_bytes(int out_dim) {
     (void)out_dim;
     return MLP_FRAG_BYTES + (size_t)BWD_MAX_BLOCKS * SLAB * sizeof(float);  // fragment cache, then the slabs

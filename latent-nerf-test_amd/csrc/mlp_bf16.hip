@@ -187,10 +187,39 @@ __device__ __forceinline__ f32x4 ld_bias4(const float *b, int base) {
     return (f32x4){b[base], b[base + 1], b[base + 2], b[base + 3]};
 }
 
+// Phase stamps (diagnostic builds only: -DLNERF_STAMPS, tools/mlp_stamps.py): the shader clock at the marks of ONE
+// wavefront per workgroup, summed per phase into a global table.  No memory drain at a mark: what a phase waits for
+// shows up in the phase that consumes it.
+#ifdef LNERF_STAMPS
+__device__ unsigned long long g_mlp_stamps[32];
+struct Stamps {
+    unsigned long long acc[16], prev;
+    __device__ __forceinline__ void init() {
+        for (int i = 0; i < 16; ++i) acc[i] = 0;
+        prev = __builtin_amdgcn_s_memtime();
+    }
+    __device__ __forceinline__ void mark(int k) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        acc[k] += now - prev;
+        prev = now;
+    }
+    __device__ __forceinline__ void flush(int base) {
+        if (threadIdx.x == 0)
+            for (int i = 0; i < 16; ++i) atomicAdd(&g_mlp_stamps[base + i], acc[i]);
+    }
+};
+#else
+struct Stamps {
+    __device__ __forceinline__ void init() {}
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void flush(int) {}
+};
+#endif
+
 // shared forward: xB[T] -> h1B[2][T], h2B[2][T] (packed, relu'd; T 16-sample column tiles); weights from LDS fragments
 template <int T>
 __device__ __forceinline__ void forward_hidden(const __bf16 *frag, const float *sB1, const float *sB2, int lane,
-                                               const bf16x8 xB[T], bf16x8 h1B[2][T], bf16x8 h2B[2][T]) {
+                                               const bf16x8 xB[T], bf16x8 h1B[2][T], bf16x8 h2B[2][T], Stamps &st) {
     const int q = lane >> 4;
     f32x4 acc[4][T];
 #pragma unroll
@@ -204,6 +233,7 @@ __device__ __forceinline__ void forward_hidden(const __bf16 *frag, const float *
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int t = 0; t < T; ++t) h1B[s][t] = pack_relu(acc[2 * s][t], acc[2 * s + 1][t]);
+    st.mark(1);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const f32x4 b = ld_bias4(sB2, 16 * mt + 4 * q);
@@ -220,6 +250,7 @@ __device__ __forceinline__ void forward_hidden(const __bf16 *frag, const float *
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int t = 0; t < T; ++t) h2B[s][t] = pack_relu(acc[2 * s][t], acc[2 * s + 1][t]);
+    st.mark(2);
 }
 
 // ------------------------------------------------------------------ forward
@@ -243,6 +274,8 @@ k_mlp_forward_bf16(MlpArgs a, float *__restrict__ sigmas, float *__restrict__ rg
         const int64_t m = (int64_t)blockIdx.x * 128 + w * 32 + 16 * t + c;
         xB[t] = load_x(a, m, m < M, q);
     }
+    Stamps st;
+    st.init();
     for (int64_t tile = blockIdx.x; tile * 128 < M; tile += gridDim.x) {
         const int64_t m0 = tile * 128 + w * 32;
         // the next tile's features are requested now and waited for after this tile's arithmetic
@@ -252,7 +285,8 @@ k_mlp_forward_bf16(MlpArgs a, float *__restrict__ sigmas, float *__restrict__ rg
             const int64_t m = m0 + (int64_t)gridDim.x * 128 + 16 * t + c;
             xB_n[t] = load_x(a, m, m < M, q);
         }
-        forward_hidden<2>(frag, sB1, sB2, lane, xB, h1B, h2B);
+        st.mark(0);
+        forward_hidden<2>(frag, sB1, sB2, lane, xB, h1B, h2B, st);
         const f32x4 b3 = ld_bias4(sB3, 4 * q);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -260,7 +294,16 @@ k_mlp_forward_bf16(MlpArgs a, float *__restrict__ sigmas, float *__restrict__ rg
 #pragma unroll
             for (int s = 0; s < 2; ++s) o = MFMA32(ld_frag(frag, F_W3A + s, lane), h2B[s][t], o);
             const int64_t m = m0 + 16 * t + c;  // lane holds h[4q + r] of sample m
-            if (m < M) {
+            if (a.out_dim == 5) {
+                // sigma + four latent channels: the q = 0 lane of a sample collects channel 4 from its q = 1 lane and
+                // writes ONE 16-byte row (16 lanes = 256 contiguous bytes) instead of four scattered dwords -- the
+                // store tail is where this kernel spends its time (tools/mlp_stamps.py)
+                const float r3 = __shfl_down(o[0], 16, 64);
+                if (q == 0 && m < M) {
+                    sigmas[m] = expf(o[0] + blob_of(a, m));
+                    reinterpret_cast<float4 *>(rgbs)[m] = make_float4(o[1], o[2], o[3], r3);
+                }
+            } else if (m < M) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int n = 4 * q + r;
@@ -269,15 +312,17 @@ k_mlp_forward_bf16(MlpArgs a, float *__restrict__ sigmas, float *__restrict__ rg
                 }
             }
         }
+        st.mark(3);
         xB[0] = xB_n[0];
         xB[1] = xB_n[1];
     }
+    st.flush(0);
 }
 
 // upstream gradient of one lane (outputs 4q .. 4q+3 of its T samples), requested one step ahead of its use: raw
 // loads only -- d(sigma)/d(pre-activation) = sigma is applied when the values are consumed, so nothing waits here
 template <int T>
-struct Upstream { float v[T][4], sg[T]; };
+struct Upstream { float v[T][4], sg[T], w[T]; };   // w: channel 4 as loaded by the q = 0 lane (out_dim == 5, see load_upstream)
 
 template <int T>
 __device__ __forceinline__ Upstream<T> load_upstream(const MlpArgs &a, const float *__restrict__ sigmas,
@@ -290,21 +335,30 @@ __device__ __forceinline__ Upstream<T> load_upstream(const MlpArgs &a, const flo
         const int64_t m = m0 + 16 * t + c;
         const bool in = m < M;
         u.sg[t] = 1.0f;
+        u.w[t] = 0.f;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) u.v[t][jj] = 0.f;
         if (in && q == 0) { u.v[t][0] = dsigmas[m]; u.sg[t] = sigmas[m]; }
+        if (a.out_dim == 5) {   // one 16-byte row per sample on its q = 0 lane; channel 4 reaches the q = 1 lane at the use
+            if (in && q == 0) {
+                const float4 g = reinterpret_cast<const float4 *>(drgbs)[m];
+                u.v[t][1] = g.x; u.v[t][2] = g.y; u.v[t][3] = g.z; u.w[t] = g.w;
+            }
+        } else {
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int n = 4 * q + jj;
-            if (in && n >= 1 && n < a.out_dim) u.v[t][jj] = drgbs[m * nrgb + (n - 1)];
+            for (int jj = 0; jj < 4; ++jj) {
+                const int n = 4 * q + jj;
+                if (in && n >= 1 && n < a.out_dim) u.v[t][jj] = drgbs[m * nrgb + (n - 1)];
+            }
         }
     }
     return u;
 }
 // the B fragment of dZ3^T (slot (q, jj < 4) <-> output 4q + jj) of one column tile; returns whether any value is non-zero
-__device__ __forceinline__ bool upstream_fragment(const float v[4], float sg, int q, bf16x8 &d3) {
+__device__ __forceinline__ bool upstream_fragment(const float v[4], float sg, float w, bool five, int q, bf16x8 &d3) {
     const float e15 = 3269017.3724721107f;  // exp(15)
-    const float v0 = q == 0 ? v[0] * fminf(sg, e15) : v[0];
+    const float w_up = __shfl_up(w, 16, 64);   // out_dim == 5: channel 4 from the sample's q = 0 lane
+    const float v0 = q == 0 ? v[0] * fminf(sg, e15) : ((five && q == 1) ? w_up : v[0]);
     Pk8 d;
     d.u[0] = cvt_pk(v0, v[1]);
     d.u[1] = cvt_pk(v[2], v[3]);
@@ -390,6 +444,8 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
         const int64_t m = (int64_t)blockIdx.x * STEP + wofs + 16 * t + c;
         xB[t] = load_x(a, m, m < M, q);
     }
+    Stamps st;
+    st.init();
     for (int64_t tile = blockIdx.x; tile * STEP < M; tile += gridDim.x) {
         const int64_t m0 = tile * STEP + wofs, m1 = m0 + (int64_t)gridDim.x * STEP;
         const Upstream<T> up_c = up;
@@ -401,9 +457,10 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
         for (int t = 0; t < T; ++t) xB[t] = load_x(a, m1 + 16 * t + c, m1 + 16 * t + c < M, q);
         bool live = false;
 #pragma unroll
-        for (int t = 0; t < T; ++t) live = upstream_fragment(up_c.v[t], up_c.sg[t], q, d3B[t]) || live;
+        for (int t = 0; t < T; ++t) live = upstream_fragment(up_c.v[t], up_c.sg[t], up_c.w[t], a.out_dim == 5, q, d3B[t]) || live;
         // a step whose upstream gradient is exactly zero (rays past their termination point: the compositing
         // backward writes zeros there) contributes nothing to any gradient: dfeat = 0, done
+        st.mark(0);   // inputs of the next step requested, dZ3 fragment built
         if (!__syncthreads_or(live ? 1 : 0)) {
 #pragma unroll
             for (int t = 0; t < T; ++t) {
@@ -417,9 +474,11 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
             }
             continue;  // uniform for the whole workgroup
         }
-        forward_hidden<T>(frag, sB1, sB2, lane, xC, h1B, h2B);
+        st.mark(4);   // __syncthreads_or
+        forward_hidden<T>(frag, sB1, sB2, lane, xC, h1B, h2B, st);   // marks 1, 2
         // ================= stage 1: dW3 += dZ3^T (x) H2^T
         __syncthreads();  // previous step's readers of imgA/imgD are done
+        st.mark(5);
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int row = 16 * T * w + 16 * t + c;  // this lane's sample inside the step
@@ -428,6 +487,7 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
             stage_lo(imgD, row, 4 * q, d3B[t]);   // outputs 4q .. 4q+3 (columns 0..15; zero beyond out_dim)
         }
         __syncthreads();
+        st.mark(6);   // stage-1 images written + barrier
         if (own_w3 || own_b3) {   // wave-uniform
 #pragma unroll
             for (int k = 0; k < KS; ++k) {
@@ -436,6 +496,7 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
                 if (own_b3) gB3 = MFMA32(dA, ones, gB3);
             }
         }
+        st.mark(7);   // dW3
         // ---- dA2 = W3^T dZ3 ; dZ2 = dA2 masked by H2 > 0
         {
             f32x4 acc[4][T];
@@ -450,6 +511,7 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
 #pragma unroll
                 for (int t = 0; t < T; ++t) dzB[s][t] = pack_masked(acc[2 * s][t], acc[2 * s + 1][t], h2B[s][t]);
         }
+        st.mark(8);   // dA2 chain
         // ================= stage 2: dW2 += dZ2^T (x) H1^T
         __syncthreads();
 #pragma unroll
@@ -462,6 +524,7 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
             }
         }
         __syncthreads();
+        st.mark(9);   // stage-2 barrier + images + barrier
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             const bf16x8 dA = ld_tr(imgD, k, 16 * r, lane);
@@ -469,6 +532,7 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
             for (int i = 0; i < C2; ++i) gW2[i] = MFMA32(dA, ld_tr(imgA, k, 16 * (C2 * h + i), lane), gW2[i]);
             if (own_b2) gB = MFMA32(dA, ones, gB);
         }
+        st.mark(10);  // dW2
         // ---- dA1 = W2^T dZ2 ; dZ1 = dA1 masked by H1 > 0   (dzB is overwritten by dZ1)
         {
             f32x4 acc[4][T];
@@ -488,6 +552,7 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
 #pragma unroll
                 for (int t = 0; t < T; ++t) dzB[s][t] = pack_masked(acc[2 * s][t], acc[2 * s + 1][t], h1B[s][t]);
         }
+        st.mark(11);  // dA1 chain
         // ================= stage 3: dW1 += dZ1^T (x) X^T
         __syncthreads();
 #pragma unroll
@@ -498,6 +563,7 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
             for (int s = 0; s < 2; ++s) stage_pair(imgD, row, 32 * s + 4 * q, 32 * s + 16 + 4 * q, dzB[s][t]);
         }
         __syncthreads();
+        st.mark(12);  // stage-3 barrier + images + barrier
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             const bf16x8 dA = ld_tr(imgD, k, 16 * r, lane);
@@ -505,6 +571,7 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
             for (int i = 0; i < C1; ++i) gW1[i] = MFMA32(dA, ld_tr(imgA, k, 16 * (C1 * h + i), lane), gW1[i]);
             if (own_b1) { if (NH == 1) gB1x = MFMA32(dA, ones, gB1x); else gB = MFMA32(dA, ones, gB); }
         }
+        st.mark(13);  // dW1
         // ---- dX = W1^T dZ1 -> dfeat (level-major f32): lane holds features 16mt + 4q + r of its sample
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -528,8 +595,10 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
                 }
             }
         }
+        st.mark(14);  // dX + stores issued
     }
 
+    st.flush(16);
     // ---- one slab per workgroup, every wave writes the tiles it owns (layout: mlp_shared.h)
     float *slab = slabs + (int64_t)blockIdx.x * MLP_SLAB;
 #pragma unroll
@@ -618,7 +687,7 @@ k_mlp_backward_bf16_sw(MlpArgs a, const float *__restrict__ sigmas, const float 
         bf16x8 d3B[2];
         bool live = false;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) live = upstream_fragment(up.v[t], up.sg[t], q, d3B[t]) || live;
+        for (int t = 0; t < 2; ++t) live = upstream_fragment(up.v[t], up.sg[t], up.w[t], a.out_dim == 5, q, d3B[t]) || live;
         if (!__any(live ? 1 : 0)) {
             // 32 samples whose upstream gradient is exactly zero (rays past their termination point: the compositing
             // backward writes zeros there) contribute nothing to any gradient: dfeat = 0, done
@@ -838,6 +907,15 @@ k_mlp_backward_bf16_sw(MlpArgs a, const float *__restrict__ sigmas, const float 
 }  // namespace lnerf
 
 namespace lnerf {
+
+#ifdef LNERF_STAMPS
+int mlp_stamps_read(unsigned long long *out32) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_mlp_stamps), sizeof(z)) != hipSuccess) return LNERF_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_mlp_stamps), z, sizeof(z)) != hipSuccess) return LNERF_ERR_HIP;
+    return LNERF_OK;
+}
+#endif
 
 int launch_mlp_fragments_bf16(const MlpArgs &a, void *frag_out, bool backward_too, hipStream_t stream) {
     const int n = backward_too ? F_SW : F_FWD;

@@ -40,4 +40,8 @@ int launch_mlp_forward_bf16(const MlpArgs &a, float *sigmas, float *rgbs, int bl
 int launch_mlp_backward_bf16(const MlpArgs &a, const float *sigmas, const float *dsigmas, const float *drgbs,
                              float *dfeat, float *slabs, int blocks, int variant, hipStream_t stream);
 
+#ifdef LNERF_STAMPS
+int mlp_stamps_read(unsigned long long *out32);   // diagnostic builds only (mlp_bf16.hip)
+#endif
+
 }  // namespace lnerf

@@ -75,9 +75,9 @@ struct AdamMulti {
 __global__ void __launch_bounds__(256) k_adam_multi(AdamMulti t, AdamArgs a, int32_t *tick) {
     adam_bias(a);
     if (tick) {
-        __syncthreads();   // every thread of this workgroup has taken its bias corrections from the counter
+        __syncthreads();   // every thread of this workgroup has taken its bias corrections from the counter (the loads
+                           // have returned: adam_bias consumed them) -- no fence needed, nothing else is published
         if (threadIdx.x == 0) {
-            __threadfence();
             const int total = (int)(gridDim.x * gridDim.y);
             if (atomicAdd(&tick[1], 1) == total - 1) {
                 tick[1] = 0;

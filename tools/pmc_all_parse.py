@@ -70,7 +70,7 @@ def main():
                     g["kernel_cycles"] = cyc
                     g["l1_accesses_per_clk_cu"] = e["TCP_TOTAL_CACHE_ACCESSES_sum"] / (cyc * 256.0)
             out["gather"]["%s_table_%s_out" % (tt, to)] = g
-        if k in ("k_mlp_forward_bf16", "k_mlp_backward_bf16"):
+        if k.startswith("k_mlp_forward_bf16") or (k.startswith("k_mlp_backward_bf16") and "_sw" not in k):
             m = {c: e.get(c) for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_VALU_MFMA_BF16",
                                        "SQ_BUSY_CU_CYCLES", "SQ_VALU_MFMA_COEXEC_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVES")}
             if m["SQ_VALU_MFMA_BUSY_CYCLES"] and m["SQ_BUSY_CU_CYCLES"]:
