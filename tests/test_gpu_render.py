@@ -296,6 +296,55 @@ def test_fused_table_update_is_bit_identical(dev, precision, log2_T):
 
 
 @pytest.mark.gpu
+def test_full_size_bf16_step_with_fused_adam_matches_oracle(dev):
+    """BASELINE config 2 at full size (64x64 rays, 128^3 grid, L = 16, T = 2^19; bf16 table + features + MFMA MLP,
+    8-byte scatter records, table Adam step fused into the scatter): ONE optimisation step against the oracle's
+    render_frame (same bf16 roundings) + adam_step.  First-step Adam moments are (1-b1) g and (1-b2) g^2, so they carry
+    the gradient's bf16 tolerance (5e-2 of the maximum, squared for v); the parameter moves by lr * sign(g) wherever
+    |g| is clearly non-zero, and rows no sample touched keep their bits."""
+    from src.latent_nerf.training.optimizer import FusedAdam
+    G, HW, log2_T = 128, 64, 19
+    net, cfg, lv, table, params, grid = _make(dev, G, HW, log2_T, 16, seed=11, mlp_precision="bf16", table_dtype="bf16")
+    net.train()
+    lr = 1e-2
+    opt = FusedAdam(net.get_params(lr / 10.0), encoder=net.encoder, fuse_table_update=True)   # table lr = 10 x base
+    assert net.encoder.scatter_variant == 3                                                    # 8-byte records
+    ro, rd = _rays(HW, 65.0, 20.0, 1.25)
+    N = HW * HW
+    torch.manual_seed(5)
+    bg = torch.rand(N, 4)
+    g = torch.randn(1, N, 4) * 0.3
+    t0 = net.encoder.embeddings.detach().cpu().clone()
+    out = net.render(ro.to(dev), rd.to(dev), bg_color=bg.to(dev), perturb=False)
+    opt.arm()
+    out["image"].backward(g.to(dev))
+    opt.step()
+    torch.cuda.synchronize()
+    assert net.encoder.embeddings.grad is None            # fused: the table gradient never existed in HBM
+    ref = O.render_frame(ro[0], rd[0], table, params, lv, O.packbits(grid.reshape(-1), 0.01), G=G, bg_color=bg,
+                         bf16_mlp=True, bf16_table=True)
+    ref["image"].backward(g[0])
+    M = ref["M"]
+    assert int(out["counter"][0]) == M and M > 300000 and torch.equal(out["rays"].cpu(), ref["rays"])
+    e, s = _err(out["image"][0], ref["image"])
+    assert e <= 2e-2 * max(s, 1.0), ("image", e, s)
+    gt = table.grad
+    p1, m1, v1 = O.adam_step(t0, gt, torch.zeros_like(gt), torch.zeros_like(gt), 1, lr)
+    emb = net.encoder.embeddings.detach().cpu()
+    m_got, v_got = [(e_[1].cpu(), e_[2].cpu()) for e_ in opt.big if e_[0] is net.encoder.embeddings][0]
+    gmax = float(gt.abs().max())
+    assert float((m_got - m1).abs().max()) <= 5e-2 * 0.1 * gmax, "exp_avg"
+    assert float((v_got - v1).abs().max()) <= 1.1e-1 * 0.01 * gmax * gmax, "exp_avg_sq"
+    sure = gt.abs() > 6e-2 * gmax                        # sign of g beyond the stated bf16 tolerance: the step is lr * sign(g)
+    assert int(sure.sum()) > 1000
+    assert float((emb - p1)[sure].abs().max()) < 1e-4 * lr + 1e-7
+    untouched = (gt == 0) & (m_got == 0)
+    assert int(untouched.sum()) > 0 and torch.equal(emb[untouched], t0[untouched])
+    moved = (emb != t0)
+    assert float(((emb - t0)[moved]).abs().max()) <= lr * 1.001     # |Adam step| <= lr on the first step
+
+
+@pytest.mark.gpu
 def test_fused_table_update_arming(dev):
     """Only an armed backward applies the fused update; an unarmed one yields the ordinary table gradient, and a step
     that mixes both is refused."""
