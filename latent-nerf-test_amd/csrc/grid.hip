@@ -1066,7 +1066,19 @@ k_scatter_finish(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
     if (row0 + r >= hsize) return;
     const long long *pt = partials + ((int64_t)bm.pstart[l] + (int64_t)b * Smax) * (BK_ROWS * 2);
     long long q0 = 0ll, q1 = 0ll;
-    for (int s = 0; s < S; ++s) {
+    int s = 0;
+    for (; s + 4 <= S; s += 4) {   // eight loads in flight per lane: the slice count is dynamic, an un-unrolled loop pays
+                                   // one memory round trip per slice (integer sums: the order is free)
+        long long a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a[k] = pt[(int64_t)(s + k) * (BK_ROWS * 2) + r];
+            b[k] = pt[(int64_t)(s + k) * (BK_ROWS * 2) + BK_ROWS + r];
+        }
+        q0 += (a[0] + a[1]) + (a[2] + a[3]);
+        q1 += (b[0] + b[1]) + (b[2] + b[3]);
+    }
+    for (; s < S; ++s) {
         q0 += pt[(int64_t)s * (BK_ROWS * 2) + r];
         q1 += pt[(int64_t)s * (BK_ROWS * 2) + BK_ROWS + r];
     }

@@ -233,69 +233,65 @@ k_march_train(const float *__restrict__ rays_o, const float *__restrict__ rays_d
 
 // Single-workgroup exclusive scan of the per-ray counts (N is a few thousand per view).
 // Also counts live rays and drops rays that would overflow `capacity`.
+// Every thread owns K = ceil(N / 1024) CONSECUTIVE rays: a local sum, ONE block-wide scan of the 1024 sums, then the
+// thread walks its rays again with its base offset -- two barriers for any N (a chunk-of-1024 loop met at three barriers
+// per chunk; the kernel is latency from end to end).
 __global__ void __launch_bounds__(1024) k_march_scan(int32_t *__restrict__ rays, int64_t N, int64_t capacity,
                                                      int32_t *__restrict__ counter, int32_t *__restrict__ noise_counter) {
-    __shared__ int wave_tot[16];
-    __shared__ int wave_live[16];
-    __shared__ long long carry_s;
-    __shared__ int live_s, drop_s;
+    __shared__ long long wave_tot[16];
+    __shared__ int wave_live[16], wave_drop[16];
+    __shared__ long long wave_best[16];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) { carry_s = 0; live_s = 0; drop_s = 0; }
     // the count pass has drawn this call's jitter; advance the generator (the write pass undoes the step: bias 1)
     if (tid == 0 && noise_counter) *noise_counter += 1;
+    const int64_t K = (N + 1023) / 1024;
+    const int64_t n0 = (int64_t)tid * K, n1 = (n0 + K < N) ? n0 + K : N;
+    long long mine = 0;
+    for (int64_t n = n0; n < n1; ++n) mine += rays[n * 3 + 2];
+    // inclusive scan of `mine` over the workgroup
+    long long inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const long long u = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += u;
+    }
+    if (lane == 63) wave_tot[wid] = inc;
     __syncthreads();
-    for (int64_t base = 0; base < N; base += 1024) {
-        const int64_t n = base + tid;
-        const int c = (n < N) ? rays[n * 3 + 2] : 0;
-        const int inc = wave_inclusive_sum_i(c);
-        if (lane == 63) wave_tot[wid] = inc;
-        __syncthreads();
-        int wave_off = 0;
-        for (int w = 0; w < wid; ++w) wave_off += wave_tot[w];
-        const long long carry = carry_s;
-        const long long off = carry + wave_off + inc - c;
-        int cc = c;
+    long long off = inc - mine;
+    for (int w = 0; w < wid; ++w) off += wave_tot[w];
+    int live = 0, drop = 0;
+    long long best = 0;
+    for (int64_t n = n0; n < n1; ++n) {
+        const int c = rays[n * 3 + 2];
         const bool dropped = (c > 0) && (off + c > capacity);
-        if (dropped) cc = 0;
-        if (n < N) {
-            rays[n * 3 + 1] = (int32_t)(dropped ? 0 : off);
-            rays[n * 3 + 2] = cc;
-        }
-        const unsigned long long lm = __ballot(cc > 0);
-        const unsigned long long dm = __ballot(dropped);
-        if (lane == 0) {
-            wave_live[wid] = __popcll(lm);
-            atomicAdd(&drop_s, __popcll(dm));
-        }
-        __syncthreads();
-        if (tid == 0) {
-            long long tot = 0;
-            int lv = 0;
-            for (int w = 0; w < 16; ++w) { tot += wave_tot[w]; lv += wave_live[w]; }
-            carry_s = carry + tot;
-            live_s += lv;
-        }
-        __syncthreads();
+        rays[n * 3 + 1] = (int32_t)(dropped ? 0 : off);
+        if (dropped) rays[n * 3 + 2] = 0;
+        if (c > 0 && !dropped) { ++live; best = off + c; }   // (empty rays carry a meaningless offset)
+        drop += dropped ? 1 : 0;
+        off += c;
     }
-    __syncthreads();
-    // M: all samples when nothing was dropped, else the end of the last kept span
-    __shared__ int best_s;
-    if (tid == 0) best_s = 0;
-    __syncthreads();
-    if (drop_s > 0) {  // uniform
-        int loc = 0;
-        for (int64_t n = tid; n < N; n += 1024) {
-            const int c = rays[n * 3 + 2];
-            if (c > 0) loc = max(loc, rays[n * 3 + 1] + c);  // empty rays carry a meaningless offset
-        }
-        atomicMax(&best_s, loc);
-        __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        live += __shfl_xor(live, o, 64);
+        drop += __shfl_xor(drop, o, 64);
+        const long long u = __shfl_xor(best, o, 64);
+        best = u > best ? u : best;
     }
+    if (lane == 0) { wave_live[wid] = live; wave_drop[wid] = drop; wave_best[wid] = best; }
+    __syncthreads();
     if (tid == 0) {
-        const long long total = carry_s;
-        counter[0] = drop_s > 0 ? best_s : (int32_t)(total > capacity ? capacity : total);
-        counter[1] = live_s;
-        counter[2] = drop_s;
+        long long total = 0, bmax = 0;
+        int lv = 0, dr = 0;
+        for (int w = 0; w < 16; ++w) {
+            total += wave_tot[w];
+            lv += wave_live[w];
+            dr += wave_drop[w];
+            bmax = wave_best[w] > bmax ? wave_best[w] : bmax;
+        }
+        // M: all samples when nothing was dropped, else the end of the last kept span
+        counter[0] = dr > 0 ? (int32_t)bmax : (int32_t)(total > capacity ? capacity : total);
+        counter[1] = lv;
+        counter[2] = dr;
         counter[3] = 0;
     }
 }
