@@ -391,6 +391,38 @@ def test_mlp_forward_backward_bf16(dev, M, feat_bf16):
     _close(rgb[:M], c32, 5e-2, 2e-2, "latent bf16 vs f32")
 
 
+def test_mlp_backward_operand_swap_variant_matches_the_default(dev):
+    """`mlp_bwd_variant` 1 (operand-swap form: the activations the weight gradients need are recomputed with the two
+    MFMA operands swapped, no LDS transposes, no barriers) against the default backward on the same inputs: the data
+    chain is the same arithmetic (dfeat bit-identical), the weight gradients differ by summation order only."""
+    from src.latent_nerf.models.network_grid import _SigmaLatentMLP
+    from src.latent_nerf.raymarching import backend as B
+    M = 70001
+    feat, xyz, p = _mlp_inputs(M, seed=5)
+    lm0 = feat.reshape(M, 16, 2).permute(1, 0, 2).contiguous().to(dev).to(torch.bfloat16)
+    m_dev = torch.tensor([M], dtype=torch.int32, device=dev)
+    gs, gc = (torch.randn(M) * 0.1).to(dev), torch.randn(M, 4).to(dev)
+    gs[1000:5000] = 0      # a stretch of dead samples (skipped steps)
+    gc[1000:5000] = 0
+    res = {}
+    try:
+        for var in (0, 1):
+            B.call("lnerf_set_tuning", b"mlp_bwd_variant", var)
+            lm = lm0.clone().requires_grad_()
+            pg = {k: v.clone().to(dev).requires_grad_() for k, v in p.items()}
+            sig, rgb = _SigmaLatentMLP.apply(lm, xyz.to(dev), pg["w1"], pg["b1"], pg["w2"], pg["b2"], pg["w3"], pg["b3"],
+                                             M, m_dev, M, 5.0, 0.2, B.BF16, None)
+            torch.autograd.backward([sig, rgb], [gs, gc])
+            res[var] = (lm.grad.clone(), {k: pg[k].grad.clone() for k in pg})
+    finally:
+        B.call("lnerf_set_tuning", b"mlp_bwd_variant", 0)
+    assert torch.equal(res[0][0], res[1][0])
+    assert float(res[0][0][:, 1000:5000].abs().max()) == 0.0
+    for k in res[0][1]:
+        a, b = res[0][1][k], res[1][1][k]
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-9, k
+
+
 def test_mlp_trunc_exp_clamp_and_rgb_mode_shapes(dev):
     from src.latent_nerf.models.network_grid import _SigmaLatentMLP
     from src.latent_nerf.raymarching import backend as B

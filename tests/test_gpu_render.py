@@ -253,6 +253,70 @@ def test_graphed_step_matches_eager(dev):
     torch.cuda.synchronize()
 
 
+def test_prepared_rays_and_two_step_graph(dev):
+    """prepare_rays() + render(prepared=...) is the same render as render(rays) (bitwise, both sample-buffer sets), and a
+    captured graph of TWO steps whose marches alternate between the sets on a side stream (bench.py --prefetch-rays)
+    replays: parameters finite and moving, device step counter + 2 per replay, jitter counter + 2 per replay."""
+    from src.latent_nerf.training.graph_step import GraphedTrainStep
+    from src.latent_nerf.training.optimizer import FusedAdam
+    G, HW = 64, 32
+    net, cfg, lv, table, params, grid = _make(dev, G, HW, 14, 16, seed=9, mlp_precision="bf16", table_dtype="bf16")
+    net.train()
+    ro, rd = _rays(HW, 62.0, 15.0, 1.3)
+    ro, rd = ro.to(dev), rd.to(dev)
+    bg = torch.rand(HW * HW, 4, device=dev)
+    g = torch.randn(1, HW * HW, 4, device=dev) * 0.3
+    plist = list(net.parameters())
+    stream = torch.cuda.Stream()
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        ref = net.render(ro, rd, bg_color=bg, perturb=False)
+        ref["image"].backward(gradient=g)
+        want = (ref["image"].detach().clone(), [p.grad.detach().clone() for p in plist], int(ref["counter"][0]))
+        for slot in (0, 1):
+            for p in plist:
+                p.grad = None
+            prep = net.prepare_rays(ro, rd, bg_color=bg, perturb=False, slot=slot)
+            out = net.render(None, None, prepared=prep)
+            out["image"].backward(gradient=g)
+            assert int(out["counter"][0]) == want[2] and torch.equal(out["image"], want[0])
+            for p, w in zip(plist, want[1]):
+                assert torch.equal(p.grad, w)
+        for p in plist:
+            p.grad = None
+        opt = FusedAdam(net.get_params(1e-3), encoder=net.encoder, capturable=True, fuse_table_update=True)
+        state = {}
+
+        def fwd_bwd():
+            main = torch.cuda.current_stream()
+            if "prep" not in state:
+                state["prep"], state["slot"] = net.prepare_rays(ro, rd, bg_color=bg, perturb=True, slot=0), 0
+            cur, slot = state["prep"], state["slot"]
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                nxt = net.prepare_rays(ro, rd, bg_color=bg, perturb=True, slot=1 - slot)
+            out = net.render(None, None, prepared=cur)
+            opt.arm()
+            out["image"].backward(gradient=g)
+            main.wait_stream(side)
+            state["prep"], state["slot"] = nxt, 1 - slot
+            return out
+
+        gs = GraphedTrainStep(fwd_bwd, lambda: opt.step(), plist, world=1, warmup=2, stream=stream, steps_per_graph=2)
+        assert gs.steps_per_call == 2
+        before = net.encoder.embeddings.detach().clone()
+        c0, j0 = int(opt.step_dev[0].item()), int(net._noise_counter[0].item())
+        for _ in range(3):
+            gs()
+        stream.synchronize()
+        assert int(opt.step_dev[0].item()) == c0 + 6
+        assert int(net._noise_counter[0].item()) == j0 + 6
+        assert bool(torch.isfinite(net.encoder.embeddings).all()) and bool(torch.isfinite(net.w2).all())
+        assert float((net.encoder.embeddings.detach() - before).abs().max()) > 0
+    torch.cuda.synchronize()
+
+
 def _run_steps(dev, fuse, precision, log2_T, steps=3):
     from src.latent_nerf.training.optimizer import FusedAdam
     G, HW = 64, 32
