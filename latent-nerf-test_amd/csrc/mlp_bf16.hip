@@ -93,11 +93,10 @@ __device__ __forceinline__ bf16x8 ld_frag(const __bf16 *frag, int f, int lane) {
 }
 
 // B fragment of X^T for one 16-sample column tile: lane (q, c) holds features 8q..8q+7 (levels 4q..4q+3)
-__device__ __forceinline__ bf16x8 load_x(const MlpArgs &a, int64_t m, bool in, int q) {
-    bf16x8 x;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = (__bf16)0.f;
-    if (!in) return x;
+// `m` is CLAMPED into the valid samples by the callers (no exec-masked branch around the loads): a row past the end
+// reads the last sample's features, which nothing consumes -- its outputs are not stored (forward) and its upstream
+// gradient is zero (backward).
+__device__ __forceinline__ bf16x8 load_x(const MlpArgs &a, int64_t m, int q) {
     if (a.feat_bf16) {
         const uint32_t *f = reinterpret_cast<const uint32_t *>(a.feat);
         uint32_t w[4];
@@ -105,6 +104,7 @@ __device__ __forceinline__ bf16x8 load_x(const MlpArgs &a, int64_t m, bool in, i
         for (int k = 0; k < 4; ++k) w[k] = f[(int64_t)(4 * q + k) * a.level_stride + m];
         return *reinterpret_cast<bf16x8 *>(w);
     }
+    bf16x8 x;
     const float2 *f = reinterpret_cast<const float2 *>(a.feat);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -114,6 +114,7 @@ __device__ __forceinline__ bf16x8 load_x(const MlpArgs &a, int64_t m, bool in, i
     }
     return x;
 }
+__device__ __forceinline__ int64_t clamp_row(int64_t m, int64_t M) { return m < M ? m : (M > 0 ? M - 1 : 0); }
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -272,7 +273,7 @@ k_mlp_forward_bf16(MlpArgs a, float *__restrict__ sigmas, float *__restrict__ rg
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int64_t m = (int64_t)blockIdx.x * 128 + w * 32 + 16 * t + c;
-        xB[t] = load_x(a, m, m < M, q);
+        xB[t] = load_x(a, clamp_row(m, M), q);
     }
     Stamps st;
     st.init();
@@ -283,7 +284,7 @@ k_mlp_forward_bf16(MlpArgs a, float *__restrict__ sigmas, float *__restrict__ rg
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int64_t m = m0 + (int64_t)gridDim.x * 128 + 16 * t + c;
-            xB_n[t] = load_x(a, m, m < M, q);
+            xB_n[t] = load_x(a, clamp_row(m, M), q);
         }
         st.mark(0);
         forward_hidden<2>(frag, sB1, sB2, lane, xB, h1B, h2B, st);
@@ -322,7 +323,7 @@ k_mlp_forward_bf16(MlpArgs a, float *__restrict__ sigmas, float *__restrict__ rg
 // upstream gradient of one lane (outputs 4q .. 4q+3 of its T samples), requested one step ahead of its use: raw
 // loads only -- d(sigma)/d(pre-activation) = sigma is applied when the values are consumed, so nothing waits here
 template <int T>
-struct Upstream { float v[T][4], sg[T], w[T]; };   // w: channel 4 as loaded by the q = 0 lane (out_dim == 5, see load_upstream)
+struct Upstream { float v[T][4], sg[T]; };
 
 template <int T>
 __device__ __forceinline__ Upstream<T> load_upstream(const MlpArgs &a, const float *__restrict__ sigmas,
@@ -334,17 +335,24 @@ __device__ __forceinline__ Upstream<T> load_upstream(const MlpArgs &a, const flo
     for (int t = 0; t < T; ++t) {
         const int64_t m = m0 + 16 * t + c;
         const bool in = m < M;
-        u.sg[t] = 1.0f;
-        u.w[t] = 0.f;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) u.v[t][jj] = 0.f;
-        if (in && q == 0) { u.v[t][0] = dsigmas[m]; u.sg[t] = sigmas[m]; }
-        if (a.out_dim == 5) {   // one 16-byte row per sample on its q = 0 lane; channel 4 reaches the q = 1 lane at the use
-            if (in && q == 0) {
-                const float4 g = reinterpret_cast<const float4 *>(drgbs)[m];
-                u.v[t][1] = g.x; u.v[t][2] = g.y; u.v[t][3] = g.z; u.w[t] = g.w;
-            }
+        const int64_t mc = clamp_row(m, M);
+        if (a.out_dim == 5) {
+            // sigma + four latent channels: every lane reads its sample's dsigma, sigma and the 16-byte row of latent
+            // gradients (the four q groups of a sample read the same addresses: one access), then keeps its share --
+            // no exec-masked branches around the loads, three loads per tile
+            const float ds = dsigmas[mc], sg = sigmas[mc];
+            const float4 g = reinterpret_cast<const float4 *>(drgbs)[mc];
+            const bool q0 = in && q == 0, q1 = in && q == 1;
+            u.sg[t] = sg;
+            u.v[t][0] = q0 ? ds : (q1 ? g.w : 0.f);
+            u.v[t][1] = q0 ? g.x : 0.f;
+            u.v[t][2] = q0 ? g.y : 0.f;
+            u.v[t][3] = q0 ? g.z : 0.f;
         } else {
+            u.sg[t] = 1.0f;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) u.v[t][jj] = 0.f;
+            if (in && q == 0) { u.v[t][0] = dsigmas[m]; u.sg[t] = sigmas[m]; }
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int n = 4 * q + jj;
@@ -355,10 +363,9 @@ __device__ __forceinline__ Upstream<T> load_upstream(const MlpArgs &a, const flo
     return u;
 }
 // the B fragment of dZ3^T (slot (q, jj < 4) <-> output 4q + jj) of one column tile; returns whether any value is non-zero
-__device__ __forceinline__ bool upstream_fragment(const float v[4], float sg, float w, bool five, int q, bf16x8 &d3) {
+__device__ __forceinline__ bool upstream_fragment(const float v[4], float sg, int q, bf16x8 &d3) {
     const float e15 = 3269017.3724721107f;  // exp(15)
-    const float w_up = __shfl_up(w, 16, 64);   // out_dim == 5: channel 4 from the sample's q = 0 lane
-    const float v0 = q == 0 ? v[0] * fminf(sg, e15) : ((five && q == 1) ? w_up : v[0]);
+    const float v0 = q == 0 ? v[0] * fminf(sg, e15) : v[0];
     Pk8 d;
     d.u[0] = cvt_pk(v0, v[1]);
     d.u[1] = cvt_pk(v[2], v[3]);
@@ -442,7 +449,7 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         const int64_t m = (int64_t)blockIdx.x * STEP + wofs + 16 * t + c;
-        xB[t] = load_x(a, m, m < M, q);
+        xB[t] = load_x(a, clamp_row(m, M), q);
     }
     Stamps st;
     st.init();
@@ -454,26 +461,15 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
         for (int t = 0; t < T; ++t) xC[t] = xB[t];
         up = load_upstream<T>(a, sigmas, dsigmas, drgbs, m1, M, q, c);
 #pragma unroll
-        for (int t = 0; t < T; ++t) xB[t] = load_x(a, m1 + 16 * t + c, m1 + 16 * t + c < M, q);
+        for (int t = 0; t < T; ++t) xB[t] = load_x(a, clamp_row(m1 + 16 * t + c, M), q);
         bool live = false;
 #pragma unroll
-        for (int t = 0; t < T; ++t) live = upstream_fragment(up_c.v[t], up_c.sg[t], up_c.w[t], a.out_dim == 5, q, d3B[t]) || live;
-        // a step whose upstream gradient is exactly zero (rays past their termination point: the compositing
-        // backward writes zeros there) contributes nothing to any gradient: dfeat = 0, done
-        st.mark(0);   // inputs of the next step requested, dZ3 fragment built
-        if (!__syncthreads_or(live ? 1 : 0)) {
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-                const int64_t m = m0 + 16 * t + c;
-                if (m < M) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        reinterpret_cast<float2 *>(dfeat)[(int64_t)(4 * q + k) * a.level_stride + m] =
-                            make_float2(0.f, 0.f);
-                }
-            }
-            continue;  // uniform for the whole workgroup
-        }
+        for (int t = 0; t < T; ++t) live = upstream_fragment(up_c.v[t], up_c.sg[t], q, d3B[t]) || live;
+        // (A step whose upstream gradient is exactly zero -- rays past their termination point, 8 % of the bench's
+        // samples -- used to be skipped behind a __syncthreads_or.  The skip made every accumulator live across a branch:
+        // ~130 register copies per step at the merge, more than the skipped arithmetic was worth; a dead step now flows
+        // through and produces its zeros: dfeat = +0, nothing added to any weight gradient.)
+        (void)live;
         st.mark(4);   // __syncthreads_or
         forward_hidden<T>(frag, sB1, sB2, lane, xC, h1B, h2B, st);   // marks 1, 2
         // ================= stage 1: dW3 += dZ3^T (x) H2^T
@@ -674,7 +670,7 @@ k_mlp_backward_bf16_sw(MlpArgs a, const float *__restrict__ sigmas, const float 
     Upstream<2> up = load_upstream<2>(a, sigmas, dsigmas, drgbs, m0, M, q, c);
     bf16x8 xB[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) xB[t] = load_x(a, m0 + 16 * t + c, m0 + 16 * t + c < M, q);
+    for (int t = 0; t < 2; ++t) xB[t] = load_x(a, clamp_row(m0 + 16 * t + c, M), q);
 
     while (m0 < M) {   // wave-uniform
         asm volatile("" ::: "memory");   // the weight fragments are re-read from LDS every step, not hoisted into ~130 registers
@@ -682,12 +678,12 @@ k_mlp_backward_bf16_sw(MlpArgs a, const float *__restrict__ sigmas, const float 
         const Upstream<2> up_n = load_upstream<2>(a, sigmas, dsigmas, drgbs, m1, M, q, c);
         bf16x8 xB_n[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) xB_n[t] = load_x(a, m1 + 16 * t + c, m1 + 16 * t + c < M, q);
+        for (int t = 0; t < 2; ++t) xB_n[t] = load_x(a, clamp_row(m1 + 16 * t + c, M), q);
 
         bf16x8 d3B[2];
         bool live = false;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) live = upstream_fragment(up.v[t], up.sg[t], up.w[t], a.out_dim == 5, q, d3B[t]) || live;
+        for (int t = 0; t < 2; ++t) live = upstream_fragment(up.v[t], up.sg[t], q, d3B[t]) || live;
         if (!__any(live ? 1 : 0)) {
             // 32 samples whose upstream gradient is exactly zero (rays past their termination point: the compositing
             // backward writes zeros there) contribute nothing to any gradient: dfeat = 0, done
