@@ -131,10 +131,14 @@ __device__ __forceinline__ uint32_t relu_pk(uint32_t v) {
     const s16x2 z = {0, 0};
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), z));
 }
-// 0xFFFF in every half of `act` (a relu'd pair: +0 or positive) that is non-zero
+// 0xFFFF in every half of `act` (a relu'd pair: +0 or positive) that is non-zero: 0 - a has its sign bit set exactly
+// for a in 1 .. 0x7FFF, an arithmetic shift spreads it (v_pk_sub_i16 + v_pk_ashrrev_i16; a min/sub form was turned
+// into two compares, two selects and a permute per pair by the compiler)
 __device__ __forceinline__ uint32_t live_pk(uint32_t act) {
-    const u16x2 one = {1, 1}, z = {0, 0};
-    return __builtin_bit_cast(uint32_t, z - __builtin_elementwise_min(__builtin_bit_cast(u16x2, act), one));
+    asm("" : "+v"(act));   // (opaque to the optimiser: knowing act >= 0 it rewrites the two packed ops into selects again)
+    const s16x2 z = {0, 0};
+    const s16x2 n = z - __builtin_bit_cast(s16x2, act);
+    return __builtin_bit_cast(uint32_t, n >> 15);
 }
 union Pk8 {
     bf16x8 v;
