@@ -68,7 +68,7 @@ const char *lnerf_build_info(void);
  *   "gather_dedup_max_res":    levels with resolution <= value fetch a cell's 8 vertices once per run of
  *                              lanes (consecutive samples of a ray) in that cell (default 512; 0 = off).
  *   "mlp_fwd_blocks":          persistent workgroups of the bf16 MLP forward (default 768).
- *   "mlp_fwd_wps":             wavefronts per SIMD the bf16 forward runs with, 2 (default) or 4.
+ *   "mlp_fwd_wps":             wavefronts per SIMD the bf16 forward is compiled for, 3 (default), 2 or 4.
  *   "gather_wgs_per_xcd":      workgroups per XCD of the XCD-owned-level gather variant (variant 2).
  *   "mlp_bwd_blocks":          persistent workgroups of the MLP backward (default and maximum 512 = slab count).
  */

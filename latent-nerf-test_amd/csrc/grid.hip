@@ -1331,7 +1331,7 @@ int lnerf_set_tuning(const char *key, int value) {
         return LNERF_OK;
     }
     if (strcmp(key, "mlp_fwd_wps") == 0) {
-        LNERF_REQUIRE(value == 2 || value == 4, "set_tuning: mlp_fwd_wps must be 2 or 4");
+        LNERF_REQUIRE(value >= 2 && value <= 4, "set_tuning: mlp_fwd_wps must be 2, 3 or 4");
         g_mlp_fwd_wps = value;
         return LNERF_OK;
     }

@@ -383,7 +383,8 @@ k_mlp_reduce_slabs(const float *__restrict__ slabs, int n_slabs, int out_dim, in
 }
 
 int g_mlp_fwd_blocks = 768;   // 3 per CU: measured 24.5 us vs 28.1 (512) and 29.8 (1024) at the bench step
-int g_mlp_fwd_wps = 2;   // wavefronts per SIMD the bf16 forward is compiled for (2 or 4)
+int g_mlp_fwd_wps = 3;   // wavefronts per SIMD the bf16 forward is compiled for: 3 (768 workgroups = 3 per CU; the
+                         // register allocation is held at <= 168 so that they are co-resident), 2 or 4
 int g_mlp_bwd_variant = 0;  // bf16 backward: 0 = shared staging images (barriers), 1 / 2 = operand-swap form at 1 / 2 waves per SIMD
 int g_mlp_bwd_blocks = MLP_BWD_MAX_BLOCKS;  // persistent workgroups of the backward (<= MLP_BWD_MAX_BLOCKS slabs)
 
@@ -391,6 +392,7 @@ static int mlp_common_checks(const char *who, const void *feat, int feat_dtype, 
                              const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
                              const float *b3, int out_dim, float blob_std, int64_t m_host, int precision) {
     LNERF_REQUIRE(m_host >= 0 && level_stride >= m_host, "%s: need 0 <= m_host <= level_stride", who);
+    LNERF_REQUIRE(level_stride <= ((int64_t)1 << 24), "%s: level_stride must be <= 2^24 samples (32-bit byte offsets)", who);
     LNERF_REQUIRE(out_dim >= 2 && out_dim <= 8, "%s: out_dim must be in [2,8] (got %d)", who, out_dim);
     LNERF_REQUIRE(feat_dtype == LNERF_F32 || feat_dtype == LNERF_BF16, "%s: bad feat dtype", who);
     LNERF_REQUIRE(precision == LNERF_F32 || precision == LNERF_BF16, "%s: bad precision tag", who);

@@ -98,10 +98,14 @@ __device__ __forceinline__ bf16x8 ld_frag(const __bf16 *frag, int f, int lane) {
 // gradient is zero (backward).
 __device__ __forceinline__ bf16x8 load_x(const MlpArgs &a, int64_t m, int q) {
     if (a.feat_bf16) {
-        const uint32_t *f = reinterpret_cast<const uint32_t *>(a.feat);
+        // 32-bit byte offsets from the (uniform) base: `global_load_dword v, v_off, s[base]` instead of three 64-bit
+        // VALU operations per address (the launcher checks 16 * level_stride * 8 < 2^32)
+        const char *f = reinterpret_cast<const char *>(a.feat);
+        const uint32_t ls = (uint32_t)a.level_stride;
         uint32_t w[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) w[k] = f[(int64_t)(4 * q + k) * a.level_stride + m];
+        for (int k = 0; k < 4; ++k)
+            w[k] = *reinterpret_cast<const uint32_t *>(f + (size_t)((((uint32_t)(4 * q + k)) * ls + (uint32_t)m) << 2));
         return *reinterpret_cast<bf16x8 *>(w);
     }
     bf16x8 x;
@@ -293,11 +297,16 @@ k_mlp_forward_bf16(MlpArgs a, float *__restrict__ sigmas, float *__restrict__ rg
         st.mark(0);
         forward_hidden<2>(frag, sB1, sB2, lane, xB, h1B, h2B, st);
         const f32x4 b3 = ld_bias4(sB3, 4 * q);
+        // (the loop-invariant fragments of layers 1 and 2 live in registers; layer 3's two are re-read from LDS every
+        // tile through an index the optimiser cannot see through: hoisted as well they cost the third wave per SIMD)
+        int lane3 = lane;
+        asm("" : "+v"(lane3) : "s"((int)tile));   // no side effects (the other fragment reads stay hoisted), varies per tile
+        const bf16x8 w3a = ld_frag(frag, F_W3A, lane3), w3b = ld_frag(frag, F_W3A + 1, lane3);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x4 o = b3;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) o = MFMA32(ld_frag(frag, F_W3A + s, lane), h2B[s][t], o);
+            o = MFMA32(w3a, h2B[0][t], o);
+            o = MFMA32(w3b, h2B[1][t], o);
             const int64_t m = m0 + 16 * t + c;  // lane holds h[4q + r] of sample m
             if (a.out_dim == 5) {
                 // sigma + four latent channels: the q = 0 lane of a sample collects channel 4 from its q = 1 lane and
@@ -589,9 +598,10 @@ k_mlp_backward_bf16(MlpArgs a, const float *__restrict__ sigmas, const float *__
                 const int64_t m = m0 + 16 * t + c;
                 if (m < M) {
                     const int lv = 8 * mt + 2 * q;  // features 16mt+4q+{0,1} = level lv, {2,3} = level lv+1
-                    reinterpret_cast<float2 *>(dfeat)[(int64_t)lv * a.level_stride + m] = make_float2(ax[t][0], ax[t][1]);
-                    reinterpret_cast<float2 *>(dfeat)[(int64_t)(lv + 1) * a.level_stride + m] =
-                        make_float2(ax[t][2], ax[t][3]);
+                    char *df = reinterpret_cast<char *>(dfeat);
+                    const uint32_t ls = (uint32_t)a.level_stride, o0 = (((uint32_t)lv) * ls + (uint32_t)m) << 3;
+                    *reinterpret_cast<float2 *>(df + (size_t)o0) = make_float2(ax[t][0], ax[t][1]);
+                    *reinterpret_cast<float2 *>(df + (size_t)(o0 + (ls << 3))) = make_float2(ax[t][2], ax[t][3]);
                 }
             }
         }
@@ -926,6 +936,7 @@ int launch_mlp_fragments_bf16(const MlpArgs &a, void *frag_out, bool backward_to
 
 int launch_mlp_forward_bf16(const MlpArgs &a, float *sigmas, float *rgbs, int blocks, int wps, hipStream_t stream) {
     if (wps >= 4) hipLaunchKernelGGL(k_mlp_forward_bf16<4>, dim3((unsigned)blocks), dim3(256), 0, stream, a, sigmas, rgbs);
+    else if (wps == 3) hipLaunchKernelGGL(k_mlp_forward_bf16<3>, dim3((unsigned)blocks), dim3(256), 0, stream, a, sigmas, rgbs);
     else hipLaunchKernelGGL(k_mlp_forward_bf16<2>, dim3((unsigned)blocks), dim3(256), 0, stream, a, sigmas, rgbs);
     LNERF_CHECK_LAUNCH("mlp_forward(bf16)");
     return LNERF_OK;
