@@ -210,6 +210,8 @@ int lnerf_grid_encode_backward_adam(const float *xyzs, float bound, const void *
  * Weights are PyTorch nn.Linear layout: w1 [64,32], b1 [64], w2 [64,64], b2 [64], w3 [out_dim,64],
  * b3 [out_dim], all f32.  sigma = exp(h0 + blob_scale*exp(-|x|^2/(2 blob_std^2))), rgbs = h[1:].
  * precision: LNERF_F32 -> exact-f32 MFMA (v_mfma_f32_16x16x4_f32), LNERF_BF16 -> bf16 MFMA, f32 acc.
+ * level_stride <= 2^24 samples (32-bit byte offsets inside the kernels); with out_dim == 5 the bf16 path moves the
+ * latent rows (rgbs, drgbs: [*, 4] f32) 16 bytes at a time: those buffers must be 16-byte aligned.
  * workspace (optional, 16-byte aligned, >= 36 KiB; the buffer of lnerf_mlp_backward_workspace_bytes() serves): with
  * it the bf16 path builds its weight fragments (the backward's too) once per launch instead of once per workgroup. */
 int lnerf_mlp_forward(const void *feat, int feat_dtype, int64_t level_stride, const float *xyzs, const float *w1,

@@ -416,6 +416,8 @@ int lnerf_mlp_forward(const void *feat, int feat_dtype, int64_t level_stride, co
     if (rc) return rc;
     if (m_host == 0) return LNERF_OK;
     LNERF_REQUIRE(sigmas && rgbs, "mlp_forward: null output");
+    LNERF_REQUIRE(precision != LNERF_BF16 || out_dim != 5 || ((uintptr_t)rgbs & 15) == 0,
+                  "mlp_forward: rgbs must be 16-byte aligned (one row per store)");
     MlpArgs a{feat, feat_dtype == LNERF_BF16, level_stride, xyzs, w1, b1, w2, b2, w3, b3, out_dim, blob_scale,
               2.0f * blob_std * blob_std, m_host, m_dev, nullptr};
     if (precision == LNERF_BF16) {
@@ -467,6 +469,8 @@ int lnerf_mlp_backward(const void *feat, int feat_dtype, int64_t level_stride, c
                   "mlp_backward: workspace too small (%zu < %zu)", workspace_bytes,
                   lnerf_mlp_backward_workspace_bytes(out_dim));
     LNERF_REQUIRE(((uintptr_t)workspace & 15) == 0, "mlp_backward: workspace must be 16-byte aligned");
+    LNERF_REQUIRE(precision != LNERF_BF16 || out_dim != 5 || ((uintptr_t)drgbs & 15) == 0,
+                  "mlp_backward: drgbs must be 16-byte aligned (one row per load)");
     MlpArgs a{feat, feat_dtype == LNERF_BF16, level_stride, xyzs, w1, b1, w2, b2, w3, b3, out_dim, blob_scale,
               2.0f * blob_std * blob_std, m_host, m_dev, nullptr};
     int64_t blocks = div_up(m_host, precision == LNERF_BF16 ? 128 : 64);

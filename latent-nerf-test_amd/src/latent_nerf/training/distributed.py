@@ -87,6 +87,7 @@ class GradSync:
             raise ValueError("transport must be float32 or bfloat16")
         self.transport = transport
         self._flat = None
+        self._flat_views = []
         self._wire = {}
         self._sinks = {}
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -95,7 +96,26 @@ class GradSync:
         n = sum(p.numel() for p in self.small)
         if self._flat is None or self._flat.numel() != n or self._flat.device != self.small[0].device:
             self._flat = torch.empty(n, device=self.small[0].device, dtype=torch.float32)
+            self._flat_views, o = [], 0
+            for p in self.small:   # one view per small parameter, in bucket order
+                self._flat_views.append(self._flat[o:o + p.numel()].view(p.shape))
+                o += p.numel()
         return self._flat
+
+    def _pack_small(self):
+        """The small parameters' gradients into the flat bucket: ONE multi-tensor copy (a copy per parameter is a
+        dependent ~5 us dispatch each, twice per step)."""
+        flat = self._flat_buffer()
+        grads = []
+        for p in self.small:
+            if p.grad is None:
+                raise RuntimeError("GradSync: a parameter has no gradient on this rank")
+            grads.append(p.grad)
+        torch._foreach_copy_(self._flat_views, grads)
+        return flat
+
+    def _unpack_small(self):
+        torch._foreach_copy_([p.grad for p in self.small], self._flat_views)
 
     def _wire_buffer(self, p):
         buf = self._wire.get(id(p))
@@ -124,10 +144,14 @@ class GradSync:
         return sink
 
     def reduced(self):
-        """{parameter: tensor holding the reduced gradient} of the big buckets after allreduce(copy_back=False): the
-        bf16 wire buffers (FusedAdam.step(grads=...) reads them directly), else the `.grad` tensors themselves."""
-        return {p: self._wire.get(id(p), p.grad) if self.transport != torch.float32 and self.world > 1 else p.grad
-                for p in self.big}
+        """{parameter: tensor holding the reduced gradient} after allreduce(copy_back=False) / allreduce_pipelined():
+        big buckets -- the bf16 wire buffers (FusedAdam.step(grads=...) reads them directly), else the `.grad` tensors
+        themselves; small parameters -- their views of the flat bucket (no copy back into `.grad`)."""
+        out = {p: self._wire.get(id(p), p.grad) if self.transport != torch.float32 and self.world > 1 else p.grad
+               for p in self.big}
+        if self.world > 1 and self.small and self._flat is not None:
+            out.update({p: v for p, v in zip(self.small, self._flat_views)})
+        return out
 
     def allreduce(self, copy_back=True):
         """After this call every `.grad` holds the SUM over ranks (scale by 1/world in the optimiser).  With the bf16
@@ -153,18 +177,10 @@ class GradSync:
                 wire.copy_(p.grad)  # f32 -> bf16 on the device
                 pending.append((dist.all_reduce(wire, group=self.group, async_op=True), wire, p))
         if self.small:
-            flat = self._flat_buffer()
-            o = 0
-            for p in self.small:
-                if p.grad is None:
-                    raise RuntimeError("GradSync: a parameter has no gradient on this rank")
-                flat[o:o + p.numel()].copy_(p.grad.reshape(-1))
-                o += p.numel()
+            flat = self._pack_small()
             dist.all_reduce(flat, group=self.group)
-            o = 0
-            for p in self.small:
-                p.grad.copy_(flat[o:o + p.numel()].view_as(p.grad))
-                o += p.numel()
+            if copy_back:
+                self._unpack_small()   # (copy_back=False: the sums stay in the flat bucket, see reduced())
         for h, wire, p in pending:
             h.wait()
             if wire is not None and copy_back:
@@ -190,32 +206,24 @@ class GradSync:
             work = dist.all_reduce(rows, group=self.group, async_op=True) if self.world > 1 else None
             groups.append((offs[lo], offs[hi], work))
         sink.written += 1     # (`pending` stays: a replayed hipGraph bins again without running any Python)
-        small_work, flat = None, None
+        small_work = None
         if self.small:
-            flat = self._flat_buffer()
-            o = 0
-            for p in self.small:
-                if p.grad is None:
-                    raise RuntimeError("GradSync: a parameter has no gradient on this rank")
-                flat[o:o + p.numel()].copy_(p.grad.reshape(-1))
-                o += p.numel()
+            flat = self._pack_small()
             if self.world > 1:
                 small_work = dist.all_reduce(flat, group=self.group, async_op=True)
-        return PendingExchange(groups, self.small, flat, small_work)
+        return PendingExchange(groups, self, small_work)
 
 
 class PendingExchange:
-    def __init__(self, table_groups, small, flat, small_work):
+    def __init__(self, table_groups, sync, small_work):
         self.table_groups = table_groups
-        self._small, self._flat, self._work = small, flat, small_work
+        self._sync, self._work = sync, small_work
 
-    def finish_small(self):
-        """Waits for the flat bucket and hands the sums back to the `.grad` tensors of the small parameters."""
+    def finish_small(self, copy_back=False):
+        """Orders the current stream behind the flat bucket's all-reduce.  The sums stay in the bucket
+        (GradSync.reduced() hands the optimiser views of it); copy_back=True also writes them into the `.grad`s."""
         if self._work is not None:
             self._work.wait()
-        if self._flat is not None:
-            o = 0
-            for p in self._small:
-                p.grad.copy_(self._flat[o:o + p.numel()].view_as(p.grad))
-                o += p.numel()
-        self._work = self._flat = None
+        if copy_back and self._sync.small:
+            self._sync._unpack_small()
+        self._work = None

@@ -108,10 +108,13 @@ class FusedAdam:
                         self.step_no, _p(self.step_dev), float(grad_scale), 0, _stream())
         if self.small:
             for k, (p, m, v, lr) in enumerate(self.small):
-                if p.grad is None:
+                g = p.grad if grads is None else grads.get(p, p.grad)
+                if g is None:
                     raise RuntimeError("FusedAdam: parameter %d has no gradient" % k)
+                if g.dtype != torch.float32 or g.numel() != p.numel() or not g.is_contiguous():
+                    raise ValueError("FusedAdam: the gradient of a small parameter must be a contiguous f32 tensor")
                 self._pp[k] = p.data.data_ptr()
-                self._gp[k] = p.grad.data_ptr()
+                self._gp[k] = g.data_ptr()
             # (with the device counter this launch, the step's last Adam launch, also advances it: LNERF_ADAM_TICK = 2)
             _b.call("lnerf_adam_step_multi", len(self.small), self._pp, self._gp, self._mp, self._vp, self._n, self._lr,
                     b1, b2, self.eps, self.step_no, _p(self.step_dev), float(grad_scale),

@@ -79,6 +79,12 @@ def _worker(rank, world, port, out, transport="f32"):
             table.grad = None                      # a sinked table has no .grad
             sync2.allreduce(copy_back=False)
             assert sync2.reduced()[table] is sink.wire
+            # copy_back=False leaves the small `.grad`s alone: their sums sit in the flat bucket, reduced() hands out views
+            for p, l in zip(small, local[1:]):
+                assert torch.equal(p.grad, l)
+                red_p = sync2.reduced()[p]
+                assert red_p.shape == p.shape and red_p.data_ptr() != p.grad.data_ptr()
+                p.grad.copy_(red_p)                # (what FusedAdam.step(grads=reduced()) reads directly)
             got = [torch.empty_like(sink.wire) for _ in range(world)]
             dist.all_gather(got, sink.wire)
             assert all(torch.equal(got[0], w) for w in got)                      # same sums on every rank
