@@ -6,6 +6,7 @@ not installed here, so the same two input forms are read with argparse + yaml; t
 themselves stay pyrallis-compatible."""
 import argparse
 import dataclasses
+import sys
 from enum import Enum
 from pathlib import Path
 from typing import get_type_hints
@@ -95,3 +96,24 @@ def to_plain_dict(cfg):
             return str(v)
         return v
     return conv(dataclasses.asdict(cfg))
+
+
+def make_section(name, spec, namespace=None, doc=None):
+    """A config section as a dataclass from a table of (field, type, default, help) rows -- the table keeps a
+    section's CLI contract (names, types, defaults) and its help text in one place; `section_help(cls)` returns the
+    help strings for `--help` output."""
+    fields = []
+    for fname, ftype, default, _help in spec:
+        if isinstance(default, (list, dict, set)):
+            fields.append((fname, ftype, dataclasses.field(default_factory=lambda d=default: type(d)(d))))
+        else:
+            fields.append((fname, ftype, dataclasses.field(default=default)))
+    cls = dataclasses.make_dataclass(name, fields, namespace=dict(namespace or {}))
+    cls.__module__ = sys._getframe(1).f_globals.get("__name__", cls.__module__)   # picklable / honest repr
+    cls.__doc__ = doc or name
+    cls.__field_help__ = {row[0]: row[3] for row in spec}
+    return cls
+
+
+def section_help(cls):
+    return dict(getattr(cls, "__field_help__", {}))
