@@ -88,8 +88,9 @@ def parse():
                     help="dtype of the table-gradient all-reduce at N > 1 (auto: follows --precision)")
     ap.add_argument("--prefetch-rays", type=int, default=0,
                     help="1: rays + march of step k+1 on a side stream while step k runs (two steps per captured graph). "
-                         "Measured on MI355X / ROCm 7.2: 0.4725 vs 0.4721 ms per step -- the replayed graph does not run "
-                         "the side branch concurrently -- hence off by default (profiles/r02_exp_ray_prefetch.jsonl)")
+                         "Measured on MI355X / ROCm 7.2: 0.4725 vs 0.4721 ms per step -- the branch does overlap the gather, "
+                         "but the cross-queue hand-offs at the fork and the join cost what it hides (DESIGN.md section 5) -- "
+                         "hence off by default (profiles/r02_exp_ray_prefetch.jsonl)")
     ap.add_argument("--tune", default="", help="lnerf_set_tuning overrides for an experiment: key=value,key=value "
                     "(recorded in the output line; the default run sets none)")
     ap.add_argument("--exchange-groups", type=int, default=4,
