@@ -192,7 +192,49 @@ k_march_train(const float *__restrict__ rays_o, const float *__restrict__ rays_d
         if (!UNIFORM_DT) {  // lane l starts at lattice point l
             for (int i = 0; i < lane; ++i) t = t + clampf(t * P.dt_gamma, P.dt_min, P.dt_max);
         }
-        for (int base = 0; base < (1 << 22); base += 64) {  // bound: a non-finite `far` must not spin
+        if (UNIFORM_DT) {
+            // Closed-form lattice: FOUR chunks of 64 lattice points per round, their occupancy bytes requested together
+            // -- the pass is a chain of dependent L2 round trips (one per chunk, ~16 per ray), this makes it ~4.  Chunks
+            // past the ray's end read a clamped (valid) cell and are ignored; the decisions and their order are those
+            // of the one-chunk loop below.
+            const float dt = P.dt_min;
+            bool done = false;
+            for (int base = 0; base < (1 << 22) && !done; base += 256) {  // bound: a non-finite `far` must not spin
+                float tj[4], xj[4], yj[4], zj[4];
+                bool vj[4], oj[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float tt = (float)(base + 64 * j + lane) * dt;
+                    tt = tt + t0;
+                    tj[j] = tt;
+                    vj[j] = tt < far;
+                    float x = dx * tt, y = dy * tt, z = dz * tt;
+                    x = x + ox; y = y + oy; z = z + oz;
+                    xj[j] = clampf(x, -P.bound, P.bound);
+                    yj[j] = clampf(y, -P.bound, P.bound);
+                    zj[j] = clampf(z, -P.bound, P.bound);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) oj[j] = cell_occupied(xj[j], yj[j], zj[j], dt, P, bitfield);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (done) break;
+                    if (__ballot(vj[j]) == 0ull) { done = true; break; }  // lattice is monotone: nothing further is valid
+                    const bool occ = vj[j] && oj[j];
+                    const unsigned long long mask = __ballot(occ);
+                    const int rank = count + mbcnt(mask);
+                    if (WRITE && occ && rank < budget) {
+                        const int64_t s = offset + rank;
+                        xyzs[s * 3] = xj[j]; xyzs[s * 3 + 1] = yj[j]; xyzs[s * 3 + 2] = zj[j];
+                        dirs[s * 3] = dx; dirs[s * 3 + 1] = dy; dirs[s * 3 + 2] = dz;
+                        deltas[s * 2] = dt; deltas[s * 2 + 1] = tj[j];
+                    }
+                    count += __popcll(mask);
+                    if (count >= budget) { count = budget; done = true; }
+                }
+            }
+        }
+        for (int base = 0; !UNIFORM_DT && base < (1 << 22); base += 64) {  // bound: a non-finite `far` must not spin
             float dt;
             if (UNIFORM_DT) {
                 dt = P.dt_min;
