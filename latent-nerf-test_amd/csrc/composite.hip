@@ -8,6 +8,35 @@
 
 namespace lnerf {
 
+// one lane's sample of a 64-sample chunk (zeros past the end of the span)
+template <int C>
+struct Chunk {
+    float sigma, dt, t, rgb[C];
+};
+template <int C>
+__device__ __forceinline__ Chunk<C> load_chunk(const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                                               const float *__restrict__ deltas, int64_t off, int cnt, int base, int lane) {
+    Chunk<C> k;
+    k.sigma = 0.f; k.dt = 0.f; k.t = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) k.rgb[c] = 0.f;
+    const int i = base + lane;
+    if (i < cnt) {
+        const int64_t s = off + i;
+        const float2 d = reinterpret_cast<const float2 *>(deltas)[s];
+        k.dt = d.x; k.t = d.y;
+        k.sigma = sigmas[s];
+        if (C == 4) {
+            const float4 v = reinterpret_cast<const float4 *>(rgbs)[s];
+            k.rgb[0] = v.x; k.rgb[1] = v.y; k.rgb[2] = v.z; k.rgb[C - 1] = v.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) k.rgb[c] = rgbs[s * C + c];
+        }
+    }
+    return k;
+}
+
 template <int C>
 __global__ void __launch_bounds__(256)
 k_composite_train_fwd(const float *__restrict__ sigmas, const float *__restrict__ rgbs, const float *__restrict__ deltas,
@@ -23,13 +52,16 @@ k_composite_train_fwd(const float *__restrict__ sigmas, const float *__restrict_
 #pragma unroll
     for (int c = 0; c < C; ++c) a_c[c] = 0.f;
     float carry = 0.f;
+    // The chunks of a ray are a chain through `carry`, but their INPUTS are not: the next chunk's sigma, (dt, t) and
+    // latents are requested before this chunk is processed (the kernel is a few dependent memory round trips long,
+    // nothing else), each as one load (8-byte delta pair, 16-byte latent row).
+    Chunk<C> cur = load_chunk<C>(sigmas, rgbs, deltas, off, cnt, 0, lane);
     for (int base = 0; base < cnt; base += 64) {
-        const int i = base + lane;
-        const bool valid = i < cnt;
-        const int64_t s = off + (valid ? i : 0);
-        const float dt = valid ? deltas[s * 2] : 0.f;
-        const float t = valid ? deltas[s * 2 + 1] : 0.f;
-        const float tau = valid ? sigmas[s] * dt : 0.f;
+        Chunk<C> nxt = cur;
+        if (base + 64 < cnt) nxt = load_chunk<C>(sigmas, rgbs, deltas, off, cnt, base + 64, lane);
+        const bool valid = base + lane < cnt;
+        const float dt = cur.dt, t = cur.t;
+        const float tau = cur.sigma * dt;     // (invalid lanes carry zeros)
         const float inc = wave_inclusive_sum(tau);
         const float excl = (inc - tau) + carry;
         const float T = expf(-excl);
@@ -39,10 +71,11 @@ k_composite_train_fwd(const float *__restrict__ sigmas, const float *__restrict_
         a_d = fmaf(w, t, a_d);
         if (w != 0.f) {
 #pragma unroll
-            for (int c = 0; c < C; ++c) a_c[c] = fmaf(w, rgbs[s * C + c], a_c[c]);
+            for (int c = 0; c < C; ++c) a_c[c] = fmaf(w, cur.rgb[c], a_c[c]);
         }
         carry += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inc), 63));
         if (expf(-carry) < T_thresh) break;  // every later sample starts below the threshold
+        cur = nxt;
     }
     a_ws = wave_sum(a_ws);
     a_d = wave_sum(a_d);
@@ -57,6 +90,18 @@ k_composite_train_fwd(const float *__restrict__ sigmas, const float *__restrict_
             if (bg) v = fmaf(1.0f - a_ws, bg[id * C + c], v);
             image[id * C + c] = v;
         }
+    }
+}
+
+// d_rgbs[s][c] = di[c] * w (di == nullptr: zeros), one 16-byte store for the four latent channels
+template <int C>
+__device__ __forceinline__ void store_row(float *__restrict__ d_rgbs, int64_t s, const float *di, float w) {
+    if (C == 4) {
+        reinterpret_cast<float4 *>(d_rgbs)[s] = di ? make_float4(di[0] * w, di[1] * w, di[2] * w, di[C - 1] * w)
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) d_rgbs[s * C + c] = di ? di[c] * w : 0.f;
     }
 }
 
@@ -93,6 +138,7 @@ k_composite_train_bwd(const float *__restrict__ g_ws, const float *__restrict__ 
     }
     float carry_tau = 0.f, carry_p = 0.f;
     bool stopped = false;  // wave-uniform
+    Chunk<C> cur = load_chunk<C>(sigmas, rgbs, deltas, off, cnt, 0, lane);
     for (int base = 0; base < cnt; base += 64) {
         const int i = base + lane;
         const bool valid = i < cnt;
@@ -100,14 +146,14 @@ k_composite_train_bwd(const float *__restrict__ g_ws, const float *__restrict__ 
         if (stopped) {  // zero-fill the tail of the span
             if (valid) {
                 d_sigmas[s] = 0.f;
-#pragma unroll
-                for (int c = 0; c < C; ++c) d_rgbs[s * C + c] = 0.f;
+                store_row<C>(d_rgbs, s, nullptr, 0.f);
             }
             continue;
         }
-        const float dt = valid ? deltas[s * 2] : 0.f;
-        const float t = valid ? deltas[s * 2 + 1] : 0.f;
-        const float tau = valid ? sigmas[s] * dt : 0.f;
+        Chunk<C> nxt = cur;   // the next chunk's inputs, requested before this chunk's arithmetic (see the forward)
+        if (base + 64 < cnt) nxt = load_chunk<C>(sigmas, rgbs, deltas, off, cnt, base + 64, lane);
+        const float dt = cur.dt, t = cur.t;
+        const float tau = cur.sigma * dt;
         const float inc = wave_inclusive_sum(tau);
         const float excl = (inc - tau) + carry_tau;
         const float T = expf(-excl);
@@ -116,24 +162,20 @@ k_composite_train_bwd(const float *__restrict__ g_ws, const float *__restrict__ 
         const bool keep = valid && T >= T_thresh;
         const float w = keep ? alpha * T : 0.f;
         float g = fmaf(ddp, t, dws);
-        float rgb[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            rgb[c] = valid ? rgbs[s * C + c] : 0.f;
-            g = fmaf(di[c], rgb[c] - bgc[c], g);
-        }
+        for (int c = 0; c < C; ++c) g = fmaf(di[c], cur.rgb[c] - bgc[c], g);
         const float gw = g * w;
         const float pinc = wave_inclusive_sum(gw) + carry_p;  // inclusive prefix of g_k w_k
         if (valid) {
             // dL/dtau_i = g_i T_{i+1} - sum_{k>i} g_k w_k
             const float dtau = keep ? fmaf(g, T * e, -(total - pinc)) : 0.f;
             d_sigmas[s] = dt * dtau;
-#pragma unroll
-            for (int c = 0; c < C; ++c) d_rgbs[s * C + c] = di[c] * w;
+            store_row<C>(d_rgbs, s, di, w);
         }
         carry_tau += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inc), 63));
         carry_p = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pinc), 63));
         if (expf(-carry_tau) < T_thresh) stopped = true;
+        cur = nxt;
     }
 }
 
@@ -150,6 +192,8 @@ int lnerf_composite_rays_train_forward(const float *sigmas, const float *rgbs, c
     LNERF_REQUIRE(C == 3 || C == 4, "composite_rays_train_forward: C must be 3 or 4 (got %d)", C);
     if (N == 0) return LNERF_OK;
     LNERF_REQUIRE(rays && weights_sum && depth && image, "composite_rays_train_forward: null pointer");
+    LNERF_REQUIRE(((uintptr_t)deltas & 7) == 0 && (C != 4 || ((uintptr_t)rgbs & 15) == 0),
+                  "composite_rays_train_forward: deltas must be 8-byte and (C = 4) rgbs 16-byte aligned");
     const dim3 grid((unsigned)div_up(N, 4)), block(256);
     if (C == 4)
         hipLaunchKernelGGL(k_composite_train_fwd<4>, grid, block, 0, as_stream(stream), sigmas, rgbs, deltas, rays, N,
@@ -172,6 +216,8 @@ int lnerf_composite_rays_train_backward(const float *grad_weights_sum, const flo
     if (N == 0) return LNERF_OK;
     LNERF_REQUIRE(grad_image && rays && weights_sum && depth && image && grad_sigmas && grad_rgbs,
                   "composite_rays_train_backward: null pointer");
+    LNERF_REQUIRE(((uintptr_t)deltas & 7) == 0 && (C != 4 || (((uintptr_t)rgbs | (uintptr_t)grad_rgbs) & 15) == 0),
+                  "composite_rays_train_backward: deltas must be 8-byte and (C = 4) rgbs / grad_rgbs 16-byte aligned");
     const dim3 grid((unsigned)div_up(N, 4)), block(256);
     if (C == 4)
         hipLaunchKernelGGL(k_composite_train_bwd<4>, grid, block, 0, as_stream(stream), grad_weights_sum, grad_depth,
