@@ -159,6 +159,12 @@ int lnerf_grid_encode_forward(const float *xyzs, float bound, const void *table,
  *              to 26-bit floats, 17 mantissa bits): a third less record traffic, relative rounding
  *              2^-18 per addend; same workspace. */
 size_t lnerf_grid_encode_backward_workspace_bytes(int num_levels, const int32_t *offsets_host, int64_t m_host);
+/* The first lnerf_grid_scatter_clear_bytes() bytes of that workspace (bucket cursors, level maxima) are cleared by every
+ * bucketed scatter call with a fill dispatch of its own -- ~5 us in a replayed graph for a few KiB.  A caller that
+ * launches something right before the scatter anyway can clear them there (lnerf_mlp_backward takes such a region)
+ * and pass `variant | LNERF_SCATTER_CLEARED`. */
+#define LNERF_SCATTER_CLEARED 0x100
+size_t lnerf_grid_scatter_clear_bytes(int num_levels, const int32_t *offsets_host, int64_t m_host);
 int lnerf_grid_encode_backward(const float *xyzs, float bound, const void *dfeat, int dfeat_dtype, int num_levels,
                                int level_dim, const int32_t *offsets_host, const float *scales_host,
                                const int32_t *res_host, int64_t m_host, const int32_t *m_dev, int64_t level_stride,
@@ -224,7 +230,9 @@ int lnerf_mlp_forward(const void *feat, int feat_dtype, int64_t level_stride, co
  * reduction launch that sums them in a fixed order.
  * precision: LNERF_F32 or LNERF_BF16; LNERF_BF16 | LNERF_MLP_FRAGMENTS_READY says that the head of `workspace`
  * still holds the fragments lnerf_mlp_forward built from these very weights (same workspace, no weight update in
- * between), so the backward does not rebuild them. */
+ * between), so the backward does not rebuild them.
+ * clear_ptr / clear_bytes (may be NULL / 0; 4-byte granular): a small region the slab-reduction launch also zeroes
+ * -- e.g. the cursors of the scatter that follows (LNERF_SCATTER_CLEARED): one dispatch less per step. */
 #define LNERF_MLP_FRAGMENTS_READY 0x100
 size_t lnerf_mlp_backward_workspace_bytes(int out_dim);
 int lnerf_mlp_backward(const void *feat, int feat_dtype, int64_t level_stride, const float *xyzs, const float *w1,
@@ -232,7 +240,7 @@ int lnerf_mlp_backward(const void *feat, int feat_dtype, int64_t level_stride, c
                        float blob_scale, float blob_std, int64_t m_host, const int32_t *m_dev, const float *sigmas,
                        const float *dsigmas, const float *drgbs, float *dfeat, float *dw1, float *db1, float *dw2,
                        float *db2, float *dw3, float *db3, int accumulate, void *workspace, size_t workspace_bytes,
-                       int precision, lnerf_stream_t stream);
+                       int precision, void *clear_ptr, size_t clear_bytes, lnerf_stream_t stream);
 
 /* ---- H8/H9: `raymarching.composite_rays_train_forward/backward`.  One wavefront per ray,
  * log-space prefix scan of sigma*dt across lanes.  C = colour channels (3 or 4).

@@ -1363,6 +1363,18 @@ int lnerf_debug_bin_stamps(unsigned long long *out16) {
 }
 #endif
 
+size_t lnerf_grid_scatter_clear_bytes(int num_levels, const int32_t *offsets_host, int64_t m_host) {
+    if (num_levels < 1 || num_levels > LNERF_MAX_LEVELS || !offsets_host || m_host < 0) return 0;
+    GridMeta meta;
+    meta.num_levels = num_levels;
+    for (int l = 0; l <= num_levels; ++l) meta.offsets[l] = offsets_host[l];
+    for (int l = 0; l < num_levels; ++l) meta.res[l] = 0;
+    BucketMeta bm;
+    ScatterPlan plan;
+    if (fill_bucket_meta(meta, m_host, bm, plan) != 0) return 0;
+    return plan.cursor_bytes;
+}
+
 size_t lnerf_grid_encode_backward_workspace_bytes(int num_levels, const int32_t *offsets_host, int64_t m_host) {
     if (num_levels < 1 || num_levels > LNERF_MAX_LEVELS || !offsets_host || m_host < 0) return 0;
     GridMeta meta;
@@ -1383,6 +1395,10 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
                             const int32_t *res_host, int64_t m_host, const int32_t *m_dev, int64_t level_stride,
                             float *dtable, int variant, void *workspace, size_t workspace_bytes,
                             lnerf_stream_t stream, FusedUpdate *fu, int phases = 3, int lv_lo = 0, int lv_hi = -1) {
+    // LNERF_SCATTER_CLEARED: the caller zeroed the head of the workspace (lnerf_grid_scatter_clear_bytes()) with
+    // something it was launching anyway -- the fill dispatch of this call is skipped
+    const bool cleared = (variant & LNERF_SCATTER_CLEARED) != 0;
+    variant &= ~LNERF_SCATTER_CLEARED;
     GridMeta meta;
     int rc = fill_meta("grid_encode_backward", meta, num_levels, level_dim, offsets_host, scales_host, res_host);
     if (rc) return rc;
@@ -1422,7 +1438,7 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
     void *rec = (char *)workspace + cbytes;
     long long *partials = (long long *)((char *)workspace + cbytes + plan.rec_bytes);
     const bool packed = variant == 3;
-    if ((phases & 1) && hipMemsetAsync(cursor, 0, cbytes, s) != hipSuccess) {
+    if ((phases & 1) && !cleared && hipMemsetAsync(cursor, 0, cbytes, s) != hipSuccess) {
         set_error("grid_encode_backward: hipMemsetAsync failed");
         return LNERF_ERR_HIP;
     }

@@ -357,7 +357,9 @@ constexpr int RED_P = 16, RED_G = 16;
 __global__ void __launch_bounds__(256)
 k_mlp_reduce_slabs(const float *__restrict__ slabs, int n_slabs, int out_dim, int accumulate,
                    float *__restrict__ dw1, float *__restrict__ db1, float *__restrict__ dw2, float *__restrict__ db2,
-                   float *__restrict__ dw3, float *__restrict__ db3) {
+                   float *__restrict__ dw3, float *__restrict__ db3, uint32_t *__restrict__ clear, int clear_words) {
+    // (a caller-named region zeroed on the side: the fill the next launch would otherwise need a dispatch for)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < clear_words; i += gridDim.x * 256) clear[i] = 0u;
     __shared__ float part[RED_G][RED_P];
     const int pi = threadIdx.x & (RED_P - 1), sg = threadIdx.x / RED_P;
     const int p = blockIdx.x * RED_P + pi;
@@ -456,7 +458,7 @@ int lnerf_mlp_backward(const void *feat, int feat_dtype, int64_t level_stride, c
                        float blob_scale, float blob_std, int64_t m_host, const int32_t *m_dev, const float *sigmas,
                        const float *dsigmas, const float *drgbs, float *dfeat, float *dw1, float *db1, float *dw2,
                        float *db2, float *dw3, float *db3, int accumulate, void *workspace, size_t workspace_bytes,
-                       int precision, lnerf_stream_t stream) {
+                       int precision, void *clear_ptr, size_t clear_bytes, lnerf_stream_t stream) {
     const bool fragments_ready = (precision & LNERF_MLP_FRAGMENTS_READY) != 0;
     precision &= ~LNERF_MLP_FRAGMENTS_READY;
     int rc = mlp_common_checks("mlp_backward", feat, feat_dtype, level_stride, xyzs, w1, b1, w2, b2, w3, b3, out_dim,
@@ -469,6 +471,8 @@ int lnerf_mlp_backward(const void *feat, int feat_dtype, int64_t level_stride, c
                   "mlp_backward: workspace too small (%zu < %zu)", workspace_bytes,
                   lnerf_mlp_backward_workspace_bytes(out_dim));
     LNERF_REQUIRE(((uintptr_t)workspace & 15) == 0, "mlp_backward: workspace must be 16-byte aligned");
+    LNERF_REQUIRE((clear_bytes == 0 || clear_ptr) && (clear_bytes & 3) == 0 && ((uintptr_t)clear_ptr & 3) == 0 &&
+                  clear_bytes <= ((size_t)1 << 24), "mlp_backward: bad clear region");
     LNERF_REQUIRE(precision != LNERF_BF16 || out_dim != 5 || ((uintptr_t)drgbs & 15) == 0,
                   "mlp_backward: drgbs must be 16-byte aligned (one row per load)");
     MlpArgs a{feat, feat_dtype == LNERF_BF16, level_stride, xyzs, w1, b1, w2, b2, w3, b3, out_dim, blob_scale,
@@ -490,7 +494,8 @@ int lnerf_mlp_backward(const void *feat, int feat_dtype, int64_t level_stride, c
         LNERF_CHECK_LAUNCH("mlp_backward");
     }
     hipLaunchKernelGGL(k_mlp_reduce_slabs, dim3((unsigned)div_up(SLAB, RED_P)), dim3(256), 0, s,
-                       (const float *)slabs, (int)blocks, out_dim, accumulate, dw1, db1, dw2, db2, dw3, db3);
+                       (const float *)slabs, (int)blocks, out_dim, accumulate, dw1, db1, dw2, db2, dw3, db3,
+                       (uint32_t *)clear_ptr, (int)(clear_bytes / 4));
     LNERF_CHECK_LAUNCH("mlp_backward(reduce)");
     return LNERF_OK;
 }

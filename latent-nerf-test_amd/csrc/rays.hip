@@ -225,9 +225,10 @@ k_march_train(const float *__restrict__ rays_o, const float *__restrict__ rays_d
                     const int rank = count + mbcnt(mask);
                     if (WRITE && occ && rank < budget) {
                         const int64_t s = offset + rank;
-                        xyzs[s * 3] = xj[j]; xyzs[s * 3 + 1] = yj[j]; xyzs[s * 3 + 2] = zj[j];
-                        dirs[s * 3] = dx; dirs[s * 3 + 1] = dy; dirs[s * 3 + 2] = dz;
-                        deltas[s * 2] = dt; deltas[s * 2 + 1] = tj[j];
+                        // one 12-byte store per position / direction, one 8-byte store per (dt, t) pair
+                        *reinterpret_cast<float3 *>(xyzs + s * 3) = make_float3(xj[j], yj[j], zj[j]);
+                        *reinterpret_cast<float3 *>(dirs + s * 3) = make_float3(dx, dy, dz);
+                        *reinterpret_cast<float2 *>(deltas + s * 2) = make_float2(dt, tj[j]);
                     }
                     count += __popcll(mask);
                     if (count >= budget) { count = budget; done = true; }

@@ -81,6 +81,20 @@ def scatter_workspace(levels: GridLevels, m_host, device):
     return ws
 
 
+_clear_bytes = {}
+
+
+def scatter_clear_bytes(levels: GridLevels, m_host):
+    """Bytes at the head of the scatter workspace that a call clears (lnerf_grid_scatter_clear_bytes); a caller that
+    zeroes them itself passes `variant | backend.SCATTER_CLEARED`."""
+    key = (tuple(levels.offsets), int(m_host))
+    n = _clear_bytes.get(key)
+    if n is None:
+        n = int(_b.get_lib().lnerf_grid_scatter_clear_bytes(levels.num_levels, levels.c_offsets, int(m_host)))
+        _clear_bytes[key] = n
+    return n
+
+
 def grid_encode_backward(xyzs, bound, dfeat, levels: GridLevels, m_host, m_dev, level_stride, dtable, variant=2):
     """dtable (f32 [rows,2]) += scatter of dfeat (level-major, f32).
     variant 0/1: global float atomics; 2: two-pass bucketed scatter (LDS reduction); 3: the same with packed

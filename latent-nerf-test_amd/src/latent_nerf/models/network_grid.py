@@ -56,7 +56,7 @@ class _SigmaLatentMLP(torch.autograd.Function):
         _b.call("lnerf_mlp_backward", _p(feat), fdt, int(level_stride), _p(xyzs), _p(w1), _p(b1), _p(w2), _p(b2),
                 _p(w3), _p(b3), out_dim, float(blob_scale), float(blob_std), int(m_host),
                 _p(m_dev) if has_mdev else None, _p(sigmas), _chk(dsigmas, "dsigmas"), _chk(drgbs, "drgbs"),
-                _p(dfeat), *[_p(g) for g in grads], 0, _p(workspace), workspace.numel(), precision, _stream())
+                _p(dfeat), *[_p(g) for g in grads], 0, _p(workspace), workspace.numel(), precision, None, 0, _stream())
         return (dfeat, None, *grads, None, None, None, None, None, None, None)
 
 
@@ -112,20 +112,26 @@ class _HashMLPField(torch.autograd.Function):
             # version check on the saved weights guarantees they have not changed since
             precision |= _b.MLP_FRAGMENTS_READY
         fdt = _b.F32 if feat.dtype == torch.float32 else _b.BF16
+        # the bucketed scatter that follows needs its cursors cleared: the MLP's slab-reduction launch does it on the
+        # side (one dispatch less per step than the scatter's own fill)
+        sv, clear_ptr, clear_bytes = encoder.scatter_variant, None, 0
+        if sv >= 2 and m_host > 0:
+            wst = E.scatter_workspace(encoder.levels, m_host, dev)
+            clear_bytes = E.scatter_clear_bytes(encoder.levels, m_host)
+            clear_ptr, sv = _p(wst), sv | _b.SCATTER_CLEARED
         _b.call("lnerf_mlp_backward", _p(feat), fdt, int(level_stride), _p(xyzs), _p(w1), _p(b1), _p(w2), _p(b2),
                 _p(w3), _p(b3), out_dim, float(blob_scale), float(blob_std), int(m_host), _p(m_dev), _p(sigmas),
                 _chk(dsigmas, "dsigmas"), _chk(drgbs, "drgbs"), _p(dfeat), *[_p(g) for g in grads], 0, _p(workspace),
-                workspace.numel(), precision, _stream())
+                workspace.numel(), precision, clear_ptr, clear_bytes, _stream())
         if encoder.fused_update is not None and encoder.fused_update.take():  # armed: the scatter applies the table's Adam step
-            E.grid_encode_backward_adam(xyzs, bound, dfeat, encoder, m_host, m_dev, level_stride, encoder.scatter_variant)
+            E.grid_encode_backward_adam(xyzs, bound, dfeat, encoder, m_host, m_dev, level_stride, sv)
             dtable = None
         elif encoder.grad_sink is not None:  # data parallel: the gradient goes straight into the bf16 wire buffer
-            E.grid_encode_backward_bf16(xyzs, bound, dfeat, encoder, m_host, m_dev, level_stride, encoder.scatter_variant)
+            E.grid_encode_backward_bf16(xyzs, bound, dfeat, encoder, m_host, m_dev, level_stride, sv)
             dtable = None
         else:
             dtable = torch.zeros(tshape, device=dev, dtype=torch.float32)
-            E.grid_encode_backward(xyzs, bound, dfeat, encoder.levels, m_host, m_dev, level_stride, dtable,
-                                   encoder.scatter_variant)
+            E.grid_encode_backward(xyzs, bound, dfeat, encoder.levels, m_host, m_dev, level_stride, dtable, sv)
         return (None, dtable, None, *grads, None, None, None, None, None, None, None, None, None)
 
 

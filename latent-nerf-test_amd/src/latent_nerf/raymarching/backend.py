@@ -15,6 +15,7 @@ HEADER_PATH = os.path.join(REPO_ROOT, "include", "lnerf_hip.h")
 LNERF_OK = 0
 F32, BF16 = 0, 1
 MLP_FRAGMENTS_READY = 0x100   # flag on lnerf_mlp_backward's precision tag (include/lnerf_hip.h)
+SCATTER_CLEARED = 0x100       # flag on the scatter's variant: the caller cleared the cursors (lnerf_grid_scatter_clear_bytes)
 
 
 class LnerfLibraryError(RuntimeError):
@@ -62,8 +63,9 @@ _SIGNATURES = {
                                         _F, _F, _F, _I, _P, _F, _P],
     "lnerf_mlp_forward": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _L, _P, _P, _P, _I, _P, _Z, _P],
     "lnerf_mlp_backward_workspace_bytes": [_I],
+    "lnerf_grid_scatter_clear_bytes": [_I, _P, _L],
     "lnerf_mlp_backward": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _L, _P, _P, _P, _P, _P, _P, _P, _P,
-                           _P, _P, _P, _I, _P, _Z, _I, _P],
+                           _P, _P, _P, _I, _P, _Z, _I, _P, _Z, _P],
     "lnerf_composite_rays_train_forward": [_P, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P, _P],
     "lnerf_composite_rays_train_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P],
     "lnerf_occ_cell_points": [_P, _L, _I, _I, _F, _P, _P, _P],
@@ -88,6 +90,7 @@ _RESTYPES = {
     "lnerf_last_error": _c.c_char_p,
     "lnerf_build_info": _c.c_char_p,
     "lnerf_mlp_backward_workspace_bytes": _Z,
+    "lnerf_grid_scatter_clear_bytes": _Z,
     "lnerf_grid_encode_backward_workspace_bytes": _Z,
 }
 
