@@ -147,8 +147,8 @@ def make_step(net, pose, intr, bg, grad, opt, world, transport=torch.float32, pe
 
     def fwd_bwd(flip=True):
         if not prefetch:
-            rays_o, rays_d = rm.get_rays(pose, intr, H, W)
-            out = net.render(rays_o, rays_d, bg_color=bg, perturb=perturb)
+            # (ray generation runs inside the march's count pass: NeRFRenderer.render(camera=...))
+            out = net.render(None, None, camera=(pose, intr, H, W), bg_color=bg, perturb=perturb)
             opt.arm()                        # N = 1: the scatter applies the table's Adam step (no-op otherwise)
             out["image"].backward(gradient=grad)
             return out

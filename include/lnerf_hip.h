@@ -122,6 +122,15 @@ int lnerf_march_rays_train_aabb(const float *rays_o, const float *rays_d, float 
                                 int cascade, int grid_size, int max_steps, float dt_gamma, const float *noises,
                                 uint32_t noise_seed, int32_t *noise_counter, int64_t capacity, float *xyzs, float *dirs,
                                 float *deltas, int32_t *rays, int32_t *counter, lnerf_stream_t stream);
+/* ... and with the ray generation of lnerf_get_rays folded into the count pass as well (same arithmetic): the rays of B
+ * views of H x W pixels are generated, written to rays_o_out / rays_d_out [B*H*W, 3] (the caller's background and
+ * direction-dependent heads read them there) and marched.  One more dispatch off the step. */
+int lnerf_march_rays_train_pose(const float *c2w, int B, int H, int W, float fx, float fy, float cx, float cy,
+                                float *rays_o_out, float *rays_d_out, float xmin, float ymin, float zmin, float xmax,
+                                float ymax, float zmax, float min_near, const uint8_t *bitfield, float bound, int cascade,
+                                int grid_size, int max_steps, float dt_gamma, const float *noises, uint32_t noise_seed,
+                                int32_t *noise_counter, int64_t capacity, float *xyzs, float *dirs, float *deltas,
+                                int32_t *rays, int32_t *counter, lnerf_stream_t stream);
 
 /* ---- H4 (inference): `raymarching.march_rays` / `composite_rays` and the live-ray compaction
  * the upstream renderer does on the host (`rays_alive = rays_alive[rays_alive >= 0]`). */

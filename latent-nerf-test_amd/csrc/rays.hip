@@ -4,31 +4,46 @@
 #include "common.h"
 
 #include <math.h>
+#include <string.h>
 
 namespace lnerf {
 
 // ------------------------------------------------------------------ H1
+// pixel g of a batch of B views -> ray (origin, unit direction): camera-to-world columns are right / down / forward / eye
+__device__ __forceinline__ void pixel_ray(const float *__restrict__ c2w, int H, int W, float fx, float fy, float cx,
+                                          float cy, int64_t g, float o[3], float d[3]) {
+    const int b = (int)(g / ((int64_t)H * W));
+    const int p = (int)(g - (int64_t)b * H * W);
+    const int j = p / W, i = p - j * W;
+    const float *m = c2w + (int64_t)b * 16;
+    const float xs = ((float)i + 0.5f - cx) / fx;
+    const float ys = ((float)j + 0.5f - cy) / fy;
+    const float inv = 1.0f / sqrtf(xs * xs + ys * ys + 1.0f);
+    const float d0 = xs * inv, d1 = ys * inv, d2 = inv;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        d[r] = d0 * m[r * 4 + 0] + d1 * m[r * 4 + 1] + d2 * m[r * 4 + 2];
+        o[r] = m[r * 4 + 3];
+    }
+}
 __global__ void __launch_bounds__(256) k_get_rays(const float *__restrict__ c2w, int B, int H, int W, float fx,
                                                   float fy, float cx, float cy, float *__restrict__ rays_o,
                                                   float *__restrict__ rays_d) {
     const int64_t total = (int64_t)B * H * W;
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
-        const int b = (int)(g / ((int64_t)H * W));
-        const int p = (int)(g - (int64_t)b * H * W);
-        const int j = p / W, i = p - j * W;
-        const float *m = c2w + (int64_t)b * 16;
-        const float xs = ((float)i + 0.5f - cx) / fx;
-        const float ys = ((float)j + 0.5f - cy) / fy;
-        const float inv = 1.0f / sqrtf(xs * xs + ys * ys + 1.0f);
-        const float d0 = xs * inv, d1 = ys * inv, d2 = inv;
-        float *o = rays_o + g * 3, *d = rays_d + g * 3;
+        float o[3], d[3];
+        pixel_ray(c2w, H, W, fx, fy, cx, cy, g, o, d);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            d[r] = d0 * m[r * 4 + 0] + d1 * m[r * 4 + 1] + d2 * m[r * 4 + 2];
-            o[r] = m[r * 4 + 3];
-        }
+        for (int r = 0; r < 3; ++r) { rays_o[g * 3 + r] = o[r]; rays_d[g * 3 + r] = d[r]; }
     }
 }
+// ray generation folded into the march's count pass (lnerf_march_rays_train_pose): camera + the buffers the rays go to
+struct RayGen {
+    const float *c2w;
+    int on, H, W;
+    float fx, fy, cx, cy;
+    float *ro, *rd;
+};
 
 // ------------------------------------------------------------------ H2
 struct RayBox {   // axis-aligned box + minimum near distance (by value)
@@ -162,16 +177,28 @@ __device__ __forceinline__ float march_noise(const MarchNoise &nz, int64_t n) {
 template <bool WRITE, bool UNIFORM_DT>
 __global__ void __launch_bounds__(256)
 k_march_train(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ nears,
-              const float *__restrict__ fars, RayBox box, int clip, int64_t N, const uint8_t *__restrict__ bitfield, MarchParams P,
+              const float *__restrict__ fars, RayBox box, int clip, RayGen gen, int64_t N, const uint8_t *__restrict__ bitfield, MarchParams P,
               MarchNoise noises, float *__restrict__ xyzs, float *__restrict__ dirs,
               float *__restrict__ deltas, int32_t *__restrict__ rays) {
     const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform
     if (n >= N) return;
     const int lane = lane_id();
+    // the ray: generated here by the count pass of the `_pose` form (k_get_rays' arithmetic; written out for the write
+    // pass and the caller), else read
+    float ro[3], rd[3];
+    if (!WRITE && gen.on) {
+        pixel_ray(gen.c2w, gen.H, gen.W, gen.fx, gen.fy, gen.cx, gen.cy, n, ro, rd);
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { gen.ro[n * 3 + r] = ro[r]; gen.rd[n * 3 + r] = rd[r]; }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { ro[r] = rays_o[n * 3 + r]; rd[r] = rays_d[n * 3 + r]; }
+    }
     float near, far;
     if (clip) {   // the AABB clip of lnerf_near_far_from_aabb, here: one dispatch less per view (same arithmetic)
-        ray_box(rays_o[n * 3], rays_o[n * 3 + 1], rays_o[n * 3 + 2], rays_d[n * 3], rays_d[n * 3 + 1], rays_d[n * 3 + 2],
-                box, near, far);
+        ray_box(ro[0], ro[1], ro[2], rd[0], rd[1], rd[2], box, near, far);
     } else {
         near = nears[n]; far = fars[n];
     }
@@ -183,8 +210,8 @@ k_march_train(const float *__restrict__ rays_o, const float *__restrict__ rays_d
         budget = rays[n * 3 + 2];  // 0 if the ray was dropped for capacity
     }
     if (near < far && budget > 0) {
-        const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
-        const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+        const float ox = ro[0], oy = ro[1], oz = ro[2];
+        const float dx = rd[0], dy = rd[1], dz = rd[2];
         const float dt0 = clampf(near * P.dt_gamma, P.dt_min, P.dt_max);
         const float noise = march_noise(noises, n);
         const float t0 = near + dt0 * noise;
@@ -612,7 +639,7 @@ static int check_march_common(const char *who, float bound, int cascade, int gri
 }
 
 static int march_train_impl(const float *rays_o, const float *rays_d, const float *nears, const float *fars,
-                            const RayBox *clip_box, int64_t N, const uint8_t *bitfield, float bound, int cascade,
+                            const RayBox *clip_box, const RayGen *raygen, int64_t N, const uint8_t *bitfield, float bound, int cascade,
                             int grid_size, int max_steps, float dt_gamma, const float *noises, uint32_t noise_seed,
                             int32_t *noise_counter, int64_t capacity, float *xyzs, float *dirs, float *deltas,
                             int32_t *rays, int32_t *counter, lnerf_stream_t stream) {
@@ -634,23 +661,26 @@ static int march_train_impl(const float *rays_o, const float *rays_d, const floa
     RayBox box{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int clip = clip_box ? 1 : 0;
     if (clip_box) box = *clip_box;
+    RayGen gen;
+    memset(&gen, 0, sizeof(gen));
+    if (raygen) gen = *raygen;
     MarchNoise nz;
     nz.values = noises; nz.counter = noise_counter; nz.seed = noise_seed; nz.bias = 0;
     if (dt_gamma == 0.f)
-        hipLaunchKernelGGL((k_march_train<false, true>), grid, block, 0, s, rays_o, rays_d, nears, fars, box, clip, N,
+        hipLaunchKernelGGL((k_march_train<false, true>), grid, block, 0, s, rays_o, rays_d, nears, fars, box, clip, gen, N,
                            bitfield, P, nz, xyzs, dirs, deltas, rays);
     else
-        hipLaunchKernelGGL((k_march_train<false, false>), grid, block, 0, s, rays_o, rays_d, nears, fars, box, clip, N,
+        hipLaunchKernelGGL((k_march_train<false, false>), grid, block, 0, s, rays_o, rays_d, nears, fars, box, clip, gen, N,
                            bitfield, P, nz, xyzs, dirs, deltas, rays);
     LNERF_CHECK_LAUNCH("march_rays_train(count)");
     hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, s, rays, N, capacity, counter, noise_counter);
     LNERF_CHECK_LAUNCH("march_rays_train(scan)");
     nz.bias = 1;
     if (dt_gamma == 0.f)
-        hipLaunchKernelGGL((k_march_train<true, true>), grid, block, 0, s, rays_o, rays_d, nears, fars, box, clip, N,
+        hipLaunchKernelGGL((k_march_train<true, true>), grid, block, 0, s, rays_o, rays_d, nears, fars, box, clip, gen, N,
                            bitfield, P, nz, xyzs, dirs, deltas, rays);
     else
-        hipLaunchKernelGGL((k_march_train<true, false>), grid, block, 0, s, rays_o, rays_d, nears, fars, box, clip, N,
+        hipLaunchKernelGGL((k_march_train<true, false>), grid, block, 0, s, rays_o, rays_d, nears, fars, box, clip, gen, N,
                            bitfield, P, nz, xyzs, dirs, deltas, rays);
     LNERF_CHECK_LAUNCH("march_rays_train(write)");
     return LNERF_OK;
@@ -661,7 +691,7 @@ int lnerf_march_rays_train(const float *rays_o, const float *rays_d, const float
                            float dt_gamma, const float *noises, uint32_t noise_seed, int32_t *noise_counter,
                            int64_t capacity, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
                            lnerf_stream_t stream) {
-    return march_train_impl(rays_o, rays_d, nears, fars, nullptr, N, bitfield, bound, cascade, grid_size, max_steps,
+    return march_train_impl(rays_o, rays_d, nears, fars, nullptr, nullptr, N, bitfield, bound, cascade, grid_size, max_steps,
                             dt_gamma, noises, noise_seed, noise_counter, capacity, xyzs, dirs, deltas, rays, counter,
                             stream);
 }
@@ -673,9 +703,27 @@ int lnerf_march_rays_train_aabb(const float *rays_o, const float *rays_d, float 
                                 float *deltas, int32_t *rays, int32_t *counter, lnerf_stream_t stream) {
     LNERF_REQUIRE(xmin <= xmax && ymin <= ymax && zmin <= zmax, "march_rays_train_aabb: inverted aabb");
     const RayBox box{xmin, ymin, zmin, xmax, ymax, zmax, min_near};
-    return march_train_impl(rays_o, rays_d, nullptr, nullptr, &box, N, bitfield, bound, cascade, grid_size, max_steps,
+    return march_train_impl(rays_o, rays_d, nullptr, nullptr, &box, nullptr, N, bitfield, bound, cascade, grid_size, max_steps,
                             dt_gamma, noises, noise_seed, noise_counter, capacity, xyzs, dirs, deltas, rays, counter,
                             stream);
+}
+
+int lnerf_march_rays_train_pose(const float *c2w, int B, int H, int W, float fx, float fy, float cx, float cy,
+                                float *rays_o_out, float *rays_d_out, float xmin, float ymin, float zmin, float xmax,
+                                float ymax, float zmax, float min_near, const uint8_t *bitfield, float bound, int cascade,
+                                int grid_size, int max_steps, float dt_gamma, const float *noises, uint32_t noise_seed,
+                                int32_t *noise_counter, int64_t capacity, float *xyzs, float *dirs, float *deltas,
+                                int32_t *rays, int32_t *counter, lnerf_stream_t stream) {
+    LNERF_REQUIRE(B >= 0 && H >= 1 && W >= 1 && fx != 0.f && fy != 0.f, "march_rays_train_pose: bad camera");
+    LNERF_REQUIRE(xmin <= xmax && ymin <= ymax && zmin <= zmax, "march_rays_train_pose: inverted aabb");
+    LNERF_REQUIRE(B == 0 || (c2w && rays_o_out && rays_d_out), "march_rays_train_pose: null pointer");
+    const RayBox box{xmin, ymin, zmin, xmax, ymax, zmax, min_near};
+    RayGen gen;
+    gen.c2w = c2w; gen.on = 1; gen.H = H; gen.W = W; gen.fx = fx; gen.fy = fy; gen.cx = cx; gen.cy = cy;
+    gen.ro = rays_o_out; gen.rd = rays_d_out;
+    return march_train_impl(rays_o_out, rays_d_out, nullptr, nullptr, &box, &gen, (int64_t)B * H * W, bitfield, bound,
+                            cascade, grid_size, max_steps, dt_gamma, noises, noise_seed, noise_counter, capacity, xyzs,
+                            dirs, deltas, rays, counter, stream);
 }
 
 int lnerf_march_rays(int64_t n_alive, int n_step, const int32_t *rays_alive, const float *rays_t, const float *rays_o,

@@ -70,6 +70,7 @@ class NeRFRenderer(nn.Module):
         self.local_step = 0
         self._march = None            # the most recent training march
         self._march_slots = [None, None]  # two sample-buffer sets: prepare_rays(slot=...) alternates them when pipelined
+        self._ray_slots = [None, None]    # ray buffers of the camera form of prepare_rays
         self._march_key = None
         self._budget = None       # ((N, max_steps), capacity) derived from observed marches
         self._m_peak = None       # device int32 [1]: largest M since the last budget update
@@ -165,7 +166,8 @@ class NeRFRenderer(nn.Module):
     def _near_far(self, rays_o, rays_d):
         return rm.near_far_from_aabb(rays_o, rays_d, self._aabb_values(), self.min_near)
 
-    def prepare_rays(self, rays_o, rays_d, dt_gamma=0.0, bg_color=None, perturb=False, max_steps=1024, slot=0, **kwargs):
+    def prepare_rays(self, rays_o, rays_d, dt_gamma=0.0, bg_color=None, perturb=False, max_steps=1024, slot=0,
+                     camera=None, **kwargs):
         """The part of a TRAINING render that depends only on the rays and the occupancy bitfield -- AABB clip,
         background, occupancy-pruned march -- done ahead of time into sample-buffer set `slot` (0 or 1).  Returns
         a PreparedRays that `render(..., prepared=p)` / `run_cuda(..., prepared=p)` shades.  A training loop that
@@ -175,11 +177,29 @@ class NeRFRenderer(nn.Module):
         update_extra_state() prepare again)."""
         if not self.training:
             raise RuntimeError("prepare_rays is the training-mode march; inference marches adaptively inside run_cuda")
-        prefix = rays_o.shape[:-1]
-        rays_o = rays_o.contiguous().view(-1, 3).float()
-        rays_d = rays_d.contiguous().view(-1, 3).float()
+        if camera is not None:
+            # camera = (poses [B,4,4], (fx, fy, cx, cy), H, W) instead of rays: they are generated inside the march's
+            # count pass (one dispatch less than get_rays + render) into buffers of this sample-buffer set
+            poses, _intr, him, wim = camera
+            B = 1 if poses.dim() == 2 else poses.shape[0]
+            camera = (poses.view(B, 4, 4).float(), _intr, int(him), int(wim))
+            key = (B * him * wim, str(poses.device))
+            bufs = self._ray_slots[slot]
+            if bufs is None or bufs[0] != key:
+                bufs = (key, torch.empty(B * him * wim, 3, device=poses.device), torch.empty(B * him * wim, 3, device=poses.device))
+                self._ray_slots[slot] = bufs
+            else:   # rewritten through raw pointers: a stale backward that saved them (background net) must fail loudly
+                torch.autograd.graph.increment_version(bufs[1])
+                torch.autograd.graph.increment_version(bufs[2])
+            rays_o, rays_d = bufs[1], bufs[2]
+            prefix = (B, him * wim)
+        else:
+            prefix = rays_o.shape[:-1]
+            rays_o = rays_o.contiguous().view(-1, 3).float()
+            rays_d = rays_d.contiguous().view(-1, 3).float()
         N = rays_o.shape[0]
-        bg = self._bg_tensor(bg_color, rays_d, N, self.img_dims)
+        if camera is None or self.bg_radius <= 0:
+            bg = self._bg_tensor(bg_color, rays_d, N, self.img_dims)
         cap = self._capacity(N, max_steps)
         a = self._aabb_values()
         a = [float(v) for v in (a.tolist() if torch.is_tensor(a) else a)]
@@ -188,7 +208,9 @@ class NeRFRenderer(nn.Module):
                                     self.grid_size, None, None, perturb=perturb, dt_gamma=dt_gamma,
                                     max_steps=max_steps, capacity=cap, out=self._march_slots[slot],
                                     noises=kwargs.get("noises"), noise_state=self._noise_state(rays_o.device),
-                                    aabb=a, min_near=self.min_near)
+                                    aabb=a, min_near=self.min_near, camera=camera)
+        if camera is not None and self.bg_radius > 0:
+            bg = self._bg_tensor(bg_color, rays_d, N, self.img_dims)   # the background net reads the generated directions
         self._march_slots[slot] = march
         self._march = march
         if self._march_key != (N, int(max_steps)) or self._m_peak is None:
@@ -209,7 +231,7 @@ class NeRFRenderer(nn.Module):
         if self.training:
             if prepared is None:
                 prepared = self.prepare_rays(rays_o, rays_d, dt_gamma=dt_gamma, bg_color=bg_color, perturb=perturb,
-                                             max_steps=max_steps, **kwargs)
+                                             max_steps=max_steps, **kwargs)   # (kwargs may carry camera=...)
             march, bg, prefix, N, cap = prepared.march, prepared.bg, prepared.prefix, prepared.N, prepared.cap
             self.local_step += 1
             m_dev = march.counter[0:1]
@@ -379,8 +401,13 @@ class NeRFRenderer(nn.Module):
         if not self.cuda_ray:   # the uniform sampler takes its sample counts from the config (render.num_steps / upsample_steps)
             kwargs.setdefault("num_steps", self.cfg.num_steps)
             kwargs.setdefault("upsample_steps", self.cfg.upsample_steps)
-        if kwargs.get("prepared") is not None:
+        if kwargs.get("prepared") is not None or (kwargs.get("camera") is not None and self.cuda_ray and self.training):
+            # a PreparedRays, or camera=(poses, intrinsics, H, W): the rays are generated inside the march
             return self.run_cuda(None, None, **kwargs)
+        camera = kwargs.pop("camera", None)
+        if camera is not None and rays_o is None:   # inference / uniform sampler: plain ray generation first
+            poses, intr, him, wim = camera
+            rays_o, rays_d = rm.get_rays(poses, intr, int(him), int(wim))
         B, N = rays_o.shape[:2]
         if staged and not self.cuda_ray:
             dev = rays_o.device

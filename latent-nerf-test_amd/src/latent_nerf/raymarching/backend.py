@@ -50,6 +50,8 @@ _SIGNATURES = {
     "lnerf_march_rays_train": [_P, _P, _P, _P, _L, _P, _F, _I, _I, _I, _F, _P, _U, _P, _L, _P, _P, _P, _P, _P, _P],
     "lnerf_march_rays_train_aabb": [_P, _P, _F, _F, _F, _F, _F, _F, _F, _L, _P, _F, _I, _I, _I, _F, _P, _U, _P, _L, _P, _P,
                                     _P, _P, _P, _P],
+    "lnerf_march_rays_train_pose": [_P, _I, _I, _I, _F, _F, _F, _F, _P, _P, _F, _F, _F, _F, _F, _F, _F, _P, _F, _I, _I, _I,
+                                    _F, _P, _U, _P, _L, _P, _P, _P, _P, _P, _P],
     "lnerf_march_rays": [_L, _I, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _F, _P, _P, _P, _P],
     "lnerf_composite_rays": [_L, _I, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _P],
     "lnerf_compact_rays": [_P, _L, _P, _P, _P],

@@ -120,8 +120,13 @@ class MarchResult:
 
 
 def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, perturb=False, dt_gamma=0.0,
-                     max_steps=1024, capacity=None, noises=None, out=None, noise_state=None, aabb=None, min_near=0.0):
+                     max_steps=1024, capacity=None, noises=None, out=None, noise_state=None, aabb=None, min_near=0.0,
+                     camera=None):
     """Occupancy-pruned march of N rays.  Returns a MarchResult.
+
+    camera = (poses [B,4,4], (fx, fy, cx, cy), H_img, W_img) with rays_o / rays_d = PREALLOCATED [B*H*W, 3] outputs (and
+    `aabb`): the rays are generated inside the march's count pass (lnerf_march_rays_train_pose: get_rays' arithmetic)
+    and written to those tensors.
 
     nears / fars [N] from near_far_from_aabb -- or None with `aabb` = six host floats (+ `min_near`): the clip is
     then done inside the march passes (lnerf_march_rays_train_aabb: same arithmetic, one dispatch less).
@@ -157,6 +162,21 @@ def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars,
         deltas = torch.empty(capacity, 2, device=dev, dtype=torch.float32)
         rays = torch.empty(N, 3, device=dev, dtype=torch.int32)
         counter = torch.empty(4, device=dev, dtype=torch.int32)
+    if camera is not None:
+        if aabb is None or nears is not None:
+            raise ValueError("march_rays_train(camera=...) needs aabb= and no nears/fars")
+        poses, intr, him, wim = camera
+        poses = poses.contiguous()
+        fx, fy, cx, cy = [float(v) for v in intr]
+        if poses.shape[0] * him * wim != N:
+            raise ValueError("camera describes %d rays, the ray buffers hold %d" % (poses.shape[0] * him * wim, N))
+        _b.call("lnerf_march_rays_train_pose", _chk(poses, "poses"), int(poses.shape[0]), int(him), int(wim), fx, fy, cx,
+                cy, _chk(rays_o, "rays_o"), _chk(rays_d, "rays_d"), *[float(v) for v in aabb], float(min_near),
+                _chk(density_bitfield, "density_bitfield", torch.uint8), float(bound), int(C), int(H), int(max_steps),
+                float(dt_gamma), _chk(noises, "noises", allow_none=True), seed,
+                _chk(noise_counter, "noise_counter", torch.int32, allow_none=True), int(capacity), _p(xyzs), _p(dirs),
+                _p(deltas), _p(rays), _p(counter), _stream())
+        return MarchResult(xyzs, dirs, deltas, rays, counter, capacity)
     if nears is None and aabb is not None:
         _b.call("lnerf_march_rays_train_aabb", _chk(rays_o, "rays_o"), _chk(rays_d, "rays_d"),
                 *[float(v) for v in aabb], float(min_near), N, _chk(density_bitfield, "density_bitfield", torch.uint8),

@@ -253,6 +253,41 @@ def test_graphed_step_matches_eager(dev):
     torch.cuda.synchronize()
 
 
+def test_camera_form_generates_the_same_rays_and_render(dev):
+    """render(camera=(pose, intrinsics, H, W)) -- rays generated inside the march's count pass
+    (lnerf_march_rays_train_pose) -- is the render of get_rays' rays, bit for bit: rays, spans, samples, image, gradients."""
+    from src.latent_nerf.raymarching import raymarching as rm
+    G, HW = 64, 32
+    net, cfg, lv, table, params, grid = _make(dev, G, HW, 14, 16, seed=12)
+    net.train()
+    f = HW / (2 * math.tan(math.radians(55) / 2))
+    intr = (f, f, HW / 2, HW / 2)
+    pose = O.pose_from_angles(math.radians(58.0), math.radians(33.0), 1.3).to(dev)
+    bg = torch.rand(HW * HW, 4, device=dev)
+    g = torch.randn(1, HW * HW, 4, device=dev) * 0.3
+    plist = list(net.parameters())
+    ro, rd = rm.get_rays(pose, intr, HW, HW)
+    ref = net.render(ro, rd, bg_color=bg, perturb=False)
+    ref["image"].backward(gradient=g)
+    want = (ref["image"].detach().clone(), ref["rays"].clone(), int(ref["counter"][0]), ref["xyzs"][:int(ref["counter"][0])].clone(),
+            [p.grad.detach().clone() for p in plist])
+    for p in plist:
+        p.grad = None
+    out = net.render(None, None, camera=(pose, intr, HW, HW), bg_color=bg, perturb=False)
+    out["image"].backward(gradient=g)
+    assert torch.equal(net._ray_slots[0][1].view_as(ro), ro) and torch.equal(net._ray_slots[0][2].view_as(rd), rd)
+    assert int(out["counter"][0]) == want[2] and torch.equal(out["rays"], want[1])
+    assert torch.equal(out["xyzs"][:want[2]], want[3]) and torch.equal(out["image"], want[0])
+    for p, w in zip(plist, want[4]):
+        assert torch.equal(p.grad, w)
+    # inference through the same keyword: plain ray generation first
+    net.eval()
+    with torch.no_grad():
+        a = net.render(None, None, camera=(pose, intr, HW, HW), bg_color=bg)
+        b = net.render(ro, rd, bg_color=bg)
+    assert torch.equal(a["image"], b["image"])
+
+
 def test_prepared_rays_and_two_step_graph(dev):
     """prepare_rays() + render(prepared=...) is the same render as render(rays) (bitwise, both sample-buffer sets), and a
     captured graph of TWO steps whose marches alternate between the sets on a side stream (bench.py --prefetch-rays)

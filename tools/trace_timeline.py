@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-step timeline from a rocprofv3 kernel trace (tools/run_trace.sh): finds the steady-state steps (delimited by the
-ray-generation kernel), and prints for each kernel of a step its mean duration and the mean idle gap BEFORE it.
+ray-generation kernel (or the march count pass)), and prints for each kernel of a step its mean duration and the mean idle gap BEFORE it.
 
     python tools/trace_timeline.py gpurun_out/<name>_kernel_trace.csv [--json out.json]
 """
@@ -20,7 +20,10 @@ def main():
     for r in csv.DictReader(open(sys.argv[1])):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
     rows.sort()
+    # a step starts with ray generation, or (camera form: rays generated inside the march) with the march's count pass
     starts = [i for i, r in enumerate(rows) if r[2].startswith("k_get_rays")]
+    if len(starts) < 4:
+        starts = [i for i, r in enumerate(rows) if r[2].startswith("k_march_train<false")]
     steps = []
     for a, b in zip(starts[:-1], starts[1:]):
         steps.append(rows[a:b])
