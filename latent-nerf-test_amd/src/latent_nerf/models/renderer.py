@@ -403,6 +403,7 @@ class NeRFRenderer(nn.Module):
             kwargs.setdefault("upsample_steps", self.cfg.upsample_steps)
         if kwargs.get("prepared") is not None or (kwargs.get("camera") is not None and self.cuda_ray and self.training):
             # a PreparedRays, or camera=(poses, intrinsics, H, W): the rays are generated inside the march
+            kwargs.pop("force_all_rays", None)
             return self.run_cuda(None, None, **kwargs)
         camera = kwargs.pop("camera", None)
         if camera is not None and rays_o is None:   # inference / uniform sampler: plain ray generation first

@@ -42,8 +42,14 @@ class NeRFDataset:
         p = self.sample_pose(index, generator)
         pose = pose_from_angles(p["theta"], p["phi"], p["radius"])[None].to(self.device)
         intr = intrinsics_from_fov(p["fov"], self.H, self.W)
-        rays_o, rays_d = rm.get_rays(pose, intr, self.H, self.W)
-        p.update(H=self.H, W=self.W, rays_o=rays_o, rays_d=rays_d, pose=pose)
+        p.update(H=self.H, W=self.W, pose=pose, camera=(pose, intr, self.H, self.W))
+        if self.training:
+            # training views hand the CAMERA to the renderer: the rays are generated inside the march's count pass
+            # (NeRFRenderer.render(camera=...), one dispatch less per view); evaluation keeps explicit rays
+            p.update(rays_o=None, rays_d=None)
+        else:
+            rays_o, rays_d = rm.get_rays(pose, intr, self.H, self.W)
+            p.update(rays_o=rays_o, rays_d=rays_d)
         return p
 
     def __iter__(self):

@@ -132,7 +132,7 @@ class Trainer:
         """Render one view and inject the guidance gradient.  Returns (pred latents [1,C,H,W], loss scalar)."""
         H, W = data["H"], data["W"]
         out = self.nerf.render(data["rays_o"], data["rays_d"], staged=False, perturb=True, bg_color=None,
-                               force_all_rays=True)
+                               force_all_rays=True, camera=data.get("camera") if data["rays_o"] is None else None)
         pred = out["image"].reshape(1, H, W, -1).permute(0, 3, 1, 2).contiguous()
         dirs = data["dir"]
         text_z = self.text_z[int(dirs[0])] if isinstance(self.text_z, list) else self.text_z

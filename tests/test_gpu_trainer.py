@@ -148,7 +148,8 @@ def test_mesh_winding_distance_and_shape_guidance(dev, tmp_path):
     assert 0.08 < frac < 0.14   # sphere of radius 0.6 in the [-1,1]^3 cube: 4/3 pi 0.6^3 / 8 = 0.113
     tr.nerf.train()
     data = tr.dataloaders["train"].collate(0)
-    out = tr.nerf.render(data["rays_o"], data["rays_d"], perturb=True)
+    assert data["rays_o"] is None     # training views hand over the camera; the rays are generated inside the march
+    out = tr.nerf.render(None, None, camera=data["camera"], perturb=True)
     loss = tr.shape_loss(out["xyzs"], out["sigmas"], out["counter"])
     loss.backward()
     assert float(loss) > 0 and float(tr.nerf.w3.grad.abs().sum()) > 0
