@@ -476,7 +476,8 @@ def main():
 
     breakdown = None
     if args.breakdown and rank == 0:
-        names = ["lnerf_get_rays", "lnerf_near_far_from_aabb", "lnerf_march_rays_train", "lnerf_grid_encode_forward",
+        names = ["lnerf_get_rays", "lnerf_near_far_from_aabb", "lnerf_march_rays_train", "lnerf_march_rays_train_aabb",
+                 "lnerf_march_rays_train_pose", "lnerf_grid_encode_forward",
                  "lnerf_mlp_forward", "lnerf_composite_rays_train_forward", "lnerf_composite_rays_train_backward",
                  "lnerf_mlp_backward", scatter_call, "lnerf_adam_step", "lnerf_adam_step_multi"]
         bt = KernelTimer(names)
