@@ -272,6 +272,15 @@ int lnerf_composite_rays_train_backward(const float *grad_weights_sum, const flo
  * its new densities, the mean is summed in a fixed order. */
 int lnerf_occ_cell_points(const uint32_t *indices, int64_t n, int cascade_level, int grid_size, float bound,
                           const float *noise, float *xyzs, lnerf_stream_t stream);
+/* Steady-state cell sampling of the refresh, on the device: indices [2*n_rand] = n_rand uniformly random cells followed by
+ * n_rand cells drawn uniformly from the occupied ones (grid > 0; all uniform when none is), xyzs [2*n_rand, 3] = a
+ * jittered point in each (the formula of lnerf_occ_cell_points).  Random numbers: u = hash(i, seed, step, k), restated in
+ * oracle/nerf_oracle.py `occ_sample`.  The occupied list is built in ascending cell order and its length never visits
+ * the host (the upstream form synchronises on torch.nonzero).  scratch: lnerf_occ_sample_scratch_bytes(n_cells). */
+size_t lnerf_occ_sample_scratch_bytes(int64_t n_cells);
+int lnerf_occ_sample(const float *grid_level, int64_t n_cells, int cascade_level, int grid_size, float bound,
+                     int64_t n_rand, uint32_t seed, uint32_t step, int32_t *scratch, uint32_t *indices, float *xyzs,
+                     lnerf_stream_t stream);
 /* grid[idx] = max(grid[idx] * decay, max of the new_sigmas listed for idx) for every listed cell with a new density
  * >= 0 (cells holding a negative value are never updated).  indices == NULL means cells 0..n-1.  scratch_cells: one
  * uint32 per cell of the level, all zero on entry; left all zero. */

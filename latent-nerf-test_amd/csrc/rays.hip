@@ -493,6 +493,95 @@ k_occ_cell_points(const uint32_t *__restrict__ indices, int64_t n, float mip_bou
     }
 }
 
+// ---- steady-state sampling of the refresh, on the device (lnerf_occ_sample): n_rand uniformly random cells + n_rand
+// cells drawn uniformly from the OCCUPIED ones, jittered points inside them.  The upstream form (torch.nonzero of the
+// grid, two randint, an index, a cat, a rand) is six launches and a host synchronisation on the size of the occupied
+// list; here the list is compacted in ascending cell order by two launches (deterministic: replicas of a data-parallel
+// run draw the same cells), its length stays on the device, and one launch draws cells and points from a counter-based
+// generator u = hash(i, seed, step, k) -- restated in oracle/nerf_oracle.py occ_sample.
+constexpr int OCC_BLOCK_CELLS = 4096;   // cells per workgroup of the compaction (256 threads x 16)
+__host__ __device__ __forceinline__ uint32_t occ_hash(uint32_t i, uint32_t seed, uint32_t step, uint32_t k) {
+    uint32_t x = i * 0x9E3779B1u + seed;
+    x ^= step * 0x85EBCA77u + k * 0xC2B2AE3Du;
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+__global__ void __launch_bounds__(256) k_occ_count(const float *__restrict__ grid, int64_t n_cells, int32_t *__restrict__ counts) {
+    __shared__ int wsum[4];
+    const int64_t base = (int64_t)blockIdx.x * OCC_BLOCK_CELLS;
+    int c = 0;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const int64_t i = base + k * 256 + threadIdx.x;
+        c += (i < n_cells && grid[i] > 0.f) ? 1 : 0;
+    }
+    c = wave_inclusive_sum_i(c);
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+}
+__global__ void __launch_bounds__(256) k_occ_fill(const float *__restrict__ grid, int64_t n_cells,
+                                                  const int32_t *__restrict__ counts, int n_blocks,
+                                                  int32_t *__restrict__ list, int32_t *__restrict__ total_dev) {
+    __shared__ int s_part[4], s_wave[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // cells in earlier workgroups (and, by workgroup 0, the total)
+    int part = 0;
+    for (int b = tid; b < (int)blockIdx.x; b += 256) part += counts[b];
+    part = wave_inclusive_sum_i(part);
+    if (lane == 63) s_part[w] = part;
+    __syncthreads();
+    int offset = ((s_part[0] + s_part[1]) + s_part[2]) + s_part[3];
+    if (blockIdx.x == 0) {
+        int all = 0;
+        for (int b = tid; b < n_blocks; b += 256) all += counts[b];
+        all = wave_inclusive_sum_i(all);
+        __syncthreads();
+        if (lane == 63) s_wave[w] = all;
+        __syncthreads();
+        if (tid == 0) *total_dev = ((s_wave[0] + s_wave[1]) + s_wave[2]) + s_wave[3];
+        __syncthreads();
+    }
+    const int64_t base = (int64_t)blockIdx.x * OCC_BLOCK_CELLS;
+    for (int k = 0; k < 16; ++k) {   // ascending cell order: 256 consecutive cells per round
+        const int64_t i = base + k * 256 + tid;
+        const bool occ = i < n_cells && grid[i] > 0.f;
+        const unsigned long long m = __ballot(occ);
+        if (lane == 0) s_wave[w] = __popcll(m);
+        __syncthreads();
+        int before = 0;
+        for (int ww = 0; ww < w; ++ww) before += s_wave[ww];
+        const int round_total = ((s_wave[0] + s_wave[1]) + s_wave[2]) + s_wave[3];
+        if (occ) list[offset + before + mbcnt(m)] = (int32_t)i;
+        offset += round_total;
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256)
+k_occ_draw(const int32_t *__restrict__ list, const int32_t *__restrict__ total_dev, int64_t n_cells, int64_t n_rand,
+           uint32_t seed, uint32_t step, float mip_bound, int G, uint32_t *__restrict__ indices, float *__restrict__ xyzs) {
+    const int total = *total_dev;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n_rand; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t h = occ_hash((uint32_t)i, seed, step, 0u);
+        uint32_t idx = (uint32_t)(((unsigned long long)h * (unsigned long long)n_cells) >> 32);   // uniform cell
+        if (i >= n_rand && total > 0) idx = (uint32_t)list[(int)(((unsigned long long)h * (unsigned long long)total) >> 32)];
+        indices[i] = idx;
+        const float nx = (float)(occ_hash((uint32_t)i, seed, step, 1u) >> 8) * (1.0f / 16777216.0f);
+        const float ny = (float)(occ_hash((uint32_t)i, seed, step, 2u) >> 8) * (1.0f / 16777216.0f);
+        const float nz = (float)(occ_hash((uint32_t)i, seed, step, 3u) >> 8) * (1.0f / 16777216.0f);
+        const float cx = (float)compact_bits(idx), cy = (float)compact_bits(idx >> 1), cz = (float)compact_bits(idx >> 2);
+        const float s = 2.0f / (float)G;
+        float ux = cx + nx, uy = cy + ny, uz = cz + nz;
+        ux = ux * s; uy = uy * s; uz = uz * s;
+        ux = ux - 1.0f; uy = uy - 1.0f; uz = uz - 1.0f;
+        xyzs[i * 3] = ux * mip_bound;
+        xyzs[i * 3 + 1] = uy * mip_bound;
+        xyzs[i * 3 + 2] = uz * mip_bound;
+    }
+}
+
 // Occupancy refresh, order-independent form (replicas of a data-parallel run must stay bit-identical, and the sampled
 // index list may name a cell more than once): pass 1 takes the MAXIMUM of the new densities per cell into a scratch
 // grid (non-negative floats order as unsigned integers: atomicMax on the bits), pass 2 applies
@@ -780,6 +869,33 @@ int lnerf_occ_cell_points(const uint32_t *indices, int64_t n, int cascade_level,
                        grid_size, noise, xyzs);
     LNERF_CHECK_LAUNCH("occ_cell_points");
     return LNERF_OK;
+}
+
+int lnerf_occ_sample(const float *grid_level, int64_t n_cells, int cascade_level, int grid_size, float bound,
+                     int64_t n_rand, uint32_t seed, uint32_t step, int32_t *scratch, uint32_t *indices, float *xyzs,
+                     lnerf_stream_t stream) {
+    LNERF_REQUIRE(n_cells > 0 && n_cells <= ((int64_t)1 << 31) && n_rand >= 0 && 2 * n_rand < ((int64_t)1 << 31),
+                  "occ_sample: sizes out of range");
+    LNERF_REQUIRE(cascade_level >= 0 && cascade_level < 8 && grid_size > 0 && bound > 0.f, "occ_sample: bad arguments");
+    if (n_rand == 0) return LNERF_OK;
+    LNERF_REQUIRE(grid_level && scratch && indices && xyzs, "occ_sample: null pointer");
+    const int n_blocks = (int)div_up(n_cells, (int64_t)OCC_BLOCK_CELLS);
+    int32_t *counts = scratch, *total = scratch + n_blocks, *list = scratch + n_blocks + 1;   // [n_blocks | 1 | n_cells]
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(k_occ_count, dim3((unsigned)n_blocks), dim3(256), 0, s, grid_level, n_cells, counts);
+    LNERF_CHECK_LAUNCH("occ_sample(count)");
+    hipLaunchKernelGGL(k_occ_fill, dim3((unsigned)n_blocks), dim3(256), 0, s, grid_level, n_cells, counts, n_blocks, list, total);
+    LNERF_CHECK_LAUNCH("occ_sample(fill)");
+    const float mip_bound = fminf((float)(1 << cascade_level), bound);
+    hipLaunchKernelGGL(k_occ_draw, dim3(grid_for(2 * n_rand)), dim3(256), 0, s, list, total, n_cells, n_rand, seed, step,
+                       mip_bound, grid_size, indices, xyzs);
+    LNERF_CHECK_LAUNCH("occ_sample(draw)");
+    return LNERF_OK;
+}
+
+size_t lnerf_occ_sample_scratch_bytes(int64_t n_cells) {
+    if (n_cells <= 0) return 0;
+    return (size_t)(div_up(n_cells, (int64_t)OCC_BLOCK_CELLS) + 1 + n_cells) * sizeof(int32_t);
 }
 
 int lnerf_occ_update(float *grid_level, const uint32_t *indices, int64_t n, const float *new_sigmas, float decay,

@@ -21,6 +21,9 @@ class RenderConfig:
     upsample_steps: int = 0
     # Refresh the occupancy grid every N training steps
     update_extra_interval: int = 16
+    # steady-state refreshes draw their cells on the device (lnerf_occ_sample: no host synchronisation); False = the
+    # torch.nonzero / randint form
+    occ_device_sampling: bool = True
     # Rays per launch at inference
     max_ray_batch: int = 4096
     # Occupancy threshold

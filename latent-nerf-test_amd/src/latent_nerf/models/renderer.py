@@ -79,6 +79,8 @@ class NeRFRenderer(nn.Module):
         self._occ_scratch = None
         self._occ_cells = None
         self._occ_gen = None
+        self._occ_seed = 0x0CC0
+        self._occ_sample_ws = None
 
     # subclasses provide the field -------------------------------------------------------
     def forward(self, x, d=None):
@@ -342,6 +344,8 @@ class NeRFRenderer(nn.Module):
         if seed is not None or self._occ_gen is None or self._occ_gen.device != dev:
             self._occ_gen = torch.Generator(device=dev)
             self._occ_gen.manual_seed(0x0CC0 + (0 if seed is None else int(seed)))
+            if seed is not None:
+                self._occ_seed = 0x0CC0 + int(seed)     # the device-side sampler's seed (steady-state refreshes)
         return self._occ_gen
 
     @torch.no_grad()
@@ -361,6 +365,25 @@ class NeRFRenderer(nn.Module):
         if self._occ_cells is None or self._occ_cells.device != dev:
             self._occ_cells = torch.zeros(G3, device=dev, dtype=torch.int32)   # scratch of lnerf_occ_update, zero between calls
         for cas in range(self.cascade):
+            if self.iter_density >= 16 and getattr(self.cfg, "occ_device_sampling", True):
+                # steady state: G^3/4 random + G^3/4 occupied cells, drawn on the device (lnerf_occ_sample): no
+                # torch.nonzero, hence no host synchronisation, and 3 launches instead of 7; a function of
+                # (grid, seed, refresh number) alone, so data-parallel replicas draw the same cells
+                n_rand = G3 // 4
+                if self._occ_sample_ws is None or self._occ_sample_ws[0].device != dev:
+                    nb = _b.get_lib().lnerf_occ_sample_scratch_bytes(G3)
+                    self._occ_sample_ws = (torch.empty(nb, device=dev, dtype=torch.uint8),
+                                           torch.empty(2 * n_rand, device=dev, dtype=torch.int32),
+                                           torch.empty(2 * n_rand, 3, device=dev))
+                scratch, idx, xyzs = self._occ_sample_ws
+                level = self.density_grid[cas]
+                _b.call("lnerf_occ_sample", _p(level), G3, cas, G, self.bound, n_rand, self._occ_seed & 0xFFFFFFFF,
+                        (self.iter_density * 8 + cas) & 0xFFFFFFFF, _p(scratch), _p(idx), _p(xyzs), _stream())
+                sigmas, _ = self.field(xyzs, 2 * n_rand)
+                sigmas = (sigmas * self.density_scale).contiguous()
+                _b.call("lnerf_occ_update", _p(level), _p(idx), 2 * n_rand, _p(sigmas), float(decay), _p(self._occ_cells),
+                        _stream())
+                continue
             if self.iter_density < 16:
                 indices = None
                 n = G3

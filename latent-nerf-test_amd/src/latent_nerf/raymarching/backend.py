@@ -66,6 +66,8 @@ _SIGNATURES = {
     "lnerf_mlp_forward": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _L, _P, _P, _P, _I, _P, _Z, _P],
     "lnerf_mlp_backward_workspace_bytes": [_I],
     "lnerf_grid_scatter_clear_bytes": [_I, _P, _L],
+    "lnerf_occ_sample_scratch_bytes": [_L],
+    "lnerf_occ_sample": [_P, _L, _I, _I, _F, _L, _U, _U, _P, _P, _P, _P],
     "lnerf_mlp_backward": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _L, _P, _P, _P, _P, _P, _P, _P, _P,
                            _P, _P, _P, _I, _P, _Z, _I, _P, _Z, _P],
     "lnerf_composite_rays_train_forward": [_P, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P, _P],
@@ -93,6 +95,7 @@ _RESTYPES = {
     "lnerf_build_info": _c.c_char_p,
     "lnerf_mlp_backward_workspace_bytes": _Z,
     "lnerf_grid_scatter_clear_bytes": _Z,
+    "lnerf_occ_sample_scratch_bytes": _Z,
     "lnerf_grid_encode_backward_workspace_bytes": _Z,
 }
 

@@ -532,6 +532,39 @@ def occupancy_cell_points(indices: torch.Tensor, cascade_level: int, G: int, bou
     return u * b
 
 
+def occ_hash(i, seed: int, step: int, k: int):
+    """32-bit hash of lnerf_occ_sample (csrc/rays.hip occ_hash; our own definition): numpy uint64 arithmetic masked to
+    32 bits."""
+    import numpy as np
+    M32 = np.uint64(0xFFFFFFFF)
+    x = (np.asarray(i, dtype=np.uint64) * np.uint64(0x9E3779B1) + np.uint64(seed & 0xFFFFFFFF)) & M32
+    x ^= ((np.uint64(step & 0xFFFFFFFF) * np.uint64(0x85EBCA77)) + (np.uint64(k) * np.uint64(0xC2B2AE3D))) & M32
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7FEB352D)) & M32
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846CA68B)) & M32
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def occ_sample(grid_level: torch.Tensor, cascade_level: int, G: int, bound: float, n_rand: int, seed: int, step: int):
+    """Steady-state cell sampling of the occupancy refresh (lnerf_occ_sample): indices [2*n_rand] = n_rand uniform cells
+    then n_rand cells drawn uniformly from the occupied ones (ascending list of cells with grid > 0; all uniform when
+    the list is empty), and a jittered point in every cell (occ_cell_points' formula).  Draws: u = occ_hash(i, seed,
+    step, k); a 32-bit value h picks element (h * n) >> 32 of n."""
+    import numpy as np
+    n_cells = grid_level.numel()
+    i = np.arange(2 * n_rand, dtype=np.uint64)
+    h = occ_hash(i, seed, step, 0)
+    idx = (h * np.uint64(n_cells)) >> np.uint64(32)
+    occ = torch.nonzero(grid_level > 0).squeeze(-1).numpy().astype(np.uint64)
+    if occ.size > 0:
+        pick = (h[n_rand:] * np.uint64(occ.size)) >> np.uint64(32)
+        idx[n_rand:] = occ[pick.astype(np.int64)]
+    noise = np.stack([(occ_hash(i, seed, step, k) >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+                      for k in (1, 2, 3)], axis=-1)
+    indices = torch.from_numpy(idx.astype(np.int64))
+    return indices, occupancy_cell_points(indices, cascade_level, G, bound, torch.from_numpy(noise))
+
+
 def update_density_grid(grid: torch.Tensor, indices: torch.Tensor, cascade_level: int,
                         new_sigma: torch.Tensor, decay: float = 0.95) -> torch.Tensor:
     """grid[c, idx] = max(grid[c, idx]*decay, s) for the sampled cells where both the old value and the new density

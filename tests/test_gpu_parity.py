@@ -391,6 +391,32 @@ def test_mlp_forward_backward_bf16(dev, M, feat_bf16):
     _close(rgb[:M], c32, 5e-2, 2e-2, "latent bf16 vs f32")
 
 
+def test_occ_sample_matches_oracle(dev):
+    """lnerf_occ_sample (device-side steady-state sampling of the occupancy refresh): the cell indices and the jittered
+    points against the oracle's restatement, bit for bit; with an empty grid every draw is uniform."""
+    from src.latent_nerf.raymarching import backend as B
+    G = 32
+    G3 = G ** 3
+    torch.manual_seed(4)
+    grid = torch.where(torch.rand(G3) < 0.07, torch.rand(G3) + 0.01, torch.zeros(G3))
+    grid[5] = -1.0                                     # invalid cells are not "occupied"
+    n_rand = G3 // 4
+    nb = B.get_lib().lnerf_occ_sample_scratch_bytes(G3)
+    for cas, bound, level in ((0, 1.0, grid), (1, 2.0, grid), (0, 1.0, torch.zeros(G3))):
+        scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+        idx = torch.empty(2 * n_rand, dtype=torch.int32, device=dev)
+        xyz = torch.empty(2 * n_rand, 3, device=dev)
+        lv = level.to(dev)
+        B.call("lnerf_occ_sample", lv.data_ptr(), G3, cas, G, bound, n_rand, 0x5EED, 37, scratch.data_ptr(),
+               idx.data_ptr(), xyz.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        ref_idx, ref_xyz = O.occ_sample(level, cas, G, bound, n_rand, 0x5EED, 37)
+        assert torch.equal(idx.cpu().long(), ref_idx)
+        assert torch.equal(xyz.cpu(), ref_xyz)
+        if float(level.max()) > 0:
+            assert bool((level[ref_idx[n_rand:]] > 0).all())       # the second half sits in occupied cells
+            assert 0.2 < float((ref_idx[:n_rand].float() / G3).mean()) < 0.8
+
+
 def test_mlp_backward_operand_swap_variant_matches_the_default(dev):
     """`mlp_bwd_variant` 1 (operand-swap form: the activations the weight gradients need are recomputed with the two
     MFMA operands swapped, no LDS transposes, no barriers) against the default backward on the same inputs: the data
