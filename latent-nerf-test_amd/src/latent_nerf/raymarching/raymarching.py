@@ -20,7 +20,14 @@ from . import backend as _b
 _NULL = None
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """The current stream's handle.  torch.cuda.current_stream() builds a Stream object through four Python layers
+    (~13 us; five calls per training step); the raw getter is what torch's own extension launchers use."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
