@@ -440,7 +440,21 @@ __device__ unsigned long long g_bin_stamps[16];
         if (threadIdx.x == 0)                                                                     \
             for (int k__ = 0; k__ < 10; ++k__) atomicAdd(&g_bin_stamps[k__], stamp_acc__[k__]);   \
     } while (0)
+#define RED_STAMP(k) BIN_STAMP(k)
+#define RED_STAMP_INIT()                                                                          \
+    unsigned long long stamp_acc__[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};        \
+    unsigned long long stamp_prev__ = __builtin_amdgcn_s_memtime()
+#define RED_STAMP_FLUSH()                                                                         \
+    do {                                                                                          \
+        if (threadIdx.x == 0) {                                                                   \
+            for (int k__ = 10; k__ < 14; ++k__) atomicAdd(&g_bin_stamps[k__], stamp_acc__[k__]);  \
+            atomicAdd(&g_bin_stamps[15], 1ull);                                                   \
+        }                                                                                         \
+    } while (0)
 #else
+#define RED_STAMP(k) do { } while (0)
+#define RED_STAMP_INIT() do { } while (0)
+#define RED_STAMP_FLUSH() do { } while (0)
 #define BIN_STAMP(k) do { } while (0)
 #define BIN_STAMP_INIT() do { } while (0)
 #define BIN_STAMP_FLUSH() do { } while (0)
@@ -928,6 +942,7 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
     constexpr int FB = FixBits<REC>::kBits;
     const FixScale fs = fix_scale<FB>(gmax[l]);  // from the bound of |value| of the LEVEL (found by pass 1)
     const int tid = threadIdx.x;
+    RED_STAMP_INIT();
     const int hsize = meta.offsets[l + 1] - meta.offsets[l];
     const int row0 = b << BK_SHIFT;
     int rows = hsize - row0;
@@ -936,6 +951,7 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
     if (have) {
         for (int i = tid; i < BK_ROWS * 2; i += RT) acc[i] = 0ll;
         __syncthreads();
+        RED_STAMP(10);
         const REC *rp = recs + bm.rstart[l] + (long long)b * cap;
         unsigned long long *ua = reinterpret_cast<unsigned long long *>(acc);
         auto add = [&](const REC &r) {
@@ -951,7 +967,9 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
             add(r0); add(r1); add(r2); add(r3);
         }
         for (; i < hi; i += RT) add(rp[i]);
+        RED_STAMP(11);
         __syncthreads();
+        RED_STAMP(12);
     }
     if (!direct) {  // sliced bucket: hand the exact sums to k_scatter_finish
         long long *pt = partials + ((int64_t)bm.pstart[l] + (int64_t)b * Smax + s) * (BK_ROWS * 2);
@@ -1020,6 +1038,8 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
                     sh2[q] = w;
                 }
             }
+            RED_STAMP(13);
+            RED_STAMP_FLUSH();
             return;
         }
         for (int r = tid; r < rows; r += RT) {
