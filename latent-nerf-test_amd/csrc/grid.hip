@@ -134,9 +134,9 @@ __device__ __forceinline__ TileMap tile_map(int variant, int L) {
 struct RunInfo {
     int start;
     bool tail;
+    unsigned long long heads;  // wave-uniform: bit i = lane i starts a run (bit 0 always set)
 };
-__device__ __forceinline__ RunInfo wave_cell_runs(uint32_t gx, uint32_t gy, uint32_t gz, bool valid) {
-    const int lane = lane_id();
+__device__ __forceinline__ RunInfo wave_cell_runs(uint32_t gx, uint32_t gy, uint32_t gz, bool valid, int lane) {
     const int px = lane_prev_i((int)gx, -1), py = lane_prev_i((int)gy, -1), pz = lane_prev_i((int)gz, -1);
     const int pv = lane_prev_i((int)valid, 0);
     const bool head = (lane == 0) || px != (int)gx || py != (int)gy || pz != (int)gz || !valid || !pv;
@@ -144,6 +144,7 @@ __device__ __forceinline__ RunInfo wave_cell_runs(uint32_t gx, uint32_t gy, uint
     RunInfo r;
     r.start = 63 - __clzll((long long)(H & (~0ull >> (63 - lane))));
     r.tail = (lane == 63) || ((H >> (lane + 1)) & 1ull);
+    r.heads = H;
     return r;
 }
 
@@ -258,7 +259,7 @@ k_grid_forward(const float *__restrict__ xyzs, float bound, const TT *__restrict
         bool fetch = valid;
         int src = lane;
         if (dedup) {
-            const RunInfo ri = wave_cell_runs(p.gx, p.gy, p.gz, valid);
+            const RunInfo ri = wave_cell_runs(p.gx, p.gy, p.gz, valid, lane);
             src = ri.start;
             fetch = valid && ri.start == lane;
         }
@@ -518,24 +519,34 @@ __device__ __forceinline__ unsigned int wave_max_u32(unsigned int v) {
     return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// inclusive wave scans of 8 value pairs at once, one fused DPP add per value and step.  The 16 chains are
-// independent, so consecutive DPP reads never hit the VALU-write -> DPP-read hazard inside the block; the leading and
-// trailing s_nop cover the instructions the compiler places around it (inline asm is opaque to its hazard pass).
-__device__ __forceinline__ void wave_inclusive_sum_x16(float (&a)[8], float (&b)[8]) {
-#define LNERF_DPP_STEP(ctrl)                                                                                        \
-    asm volatile("s_nop 1" ::: );                                                                                   \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                 \
-        asm volatile("v_add_f32_dpp %0, %0, %0 " ctrl : "+v"(a[i]));                                                \
-        asm volatile("v_add_f32_dpp %0, %0, %0 " ctrl : "+v"(b[i]));                                                \
+// Sums over RUNS of lanes (RunInfo), valid on every lane as the sum from the run's first lane up to the lane itself:
+// a segmented Hillis-Steele scan, one fused DPP multiply-add per value and step -- the addend of a lane whose source
+// lies before its run's first lane is multiplied by 0.  Unlike "wave prefix sum minus the prefix before the run" it
+// needs no lane permutes, no subtraction (and has none of its cancellation), and a wave whose longest run is short
+// skips the long-distance steps: all conditions are wave-uniform scalar tests on the run-head mask.
+__device__ __forceinline__ void wave_run_sums_x16(float (&a)[8], float (&b)[8], const RunInfo &r, int lane) {
+    const int d = lane - r.start;  // lanes of the run before this one
+    const unsigned long long H = r.heads;
+    const unsigned long long H2 = H | (H << 1), H4 = H2 | (H2 << 2), H8 = H4 | (H4 << 4);
+#define LNERF_SEG_STEP(ctrl, cond)                                                                                  \
+    {                                                                                                               \
+        const float f = (cond) ? 1.0f : 0.0f;                                                                       \
+        asm volatile("s_nop 1" ::: );                                                                               \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                             \
+            asm volatile("v_fmac_f32_dpp %0, %0, %1 " ctrl : "+v"(a[i]) : "v"(f));                                  \
+            asm volatile("v_fmac_f32_dpp %0, %0, %1 " ctrl : "+v"(b[i]) : "v"(f));                                  \
+        }                                                                                                           \
+        asm volatile("s_nop 1" ::: );                                                                               \
     }
-    LNERF_DPP_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-    LNERF_DPP_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-    LNERF_DPP_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-    LNERF_DPP_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-    LNERF_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
-    LNERF_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
-    asm volatile("s_nop 1" ::: );
-#undef LNERF_DPP_STEP
+    if (H != ~0ull) LNERF_SEG_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0", d >= 1)
+    if (H2 != ~0ull) LNERF_SEG_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0", d >= 2)
+    if (H4 != ~0ull) LNERF_SEG_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0", d >= 4)
+    if (H8 != ~0ull) LNERF_SEG_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0", d >= 8)
+    // runs that continue over a row of 16 lanes: the previous row's last lane holds the run's sum so far
+    if ((H & 0x0001000000010000ull) != 0x0001000000010000ull)
+        LNERF_SEG_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf", d > (lane & 15))
+    if (!((H >> 32) & 1ull)) LNERF_SEG_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf", r.start < 32)
+#undef LNERF_SEG_STEP
 }
 
 // what the binning pass needs to know about a level (read from the kernel arguments in the kernel body only: the
@@ -578,7 +589,9 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restri
     const int tstep = gridDim.x / L;
     const float two_b = 2.0f * bound;
     const bool pow2_bound = (__float_as_uint(two_b) & 0x007FFFFFu) == 0u;
-    const float inv_two_b = 1.0f / two_b;  // exact when the bound is a power of two (the only case it is used in)
+    // (exact when the bound is a power of two, the only case it is used in; wave-uniform, kept in a scalar register)
+    float inv_two_b;
+    asm("v_readfirstlane_b32 %0, %1" : "=s"(inv_two_b) : "v"(1.0f / two_b));
     for (int i = tid; i < 2 * BK_MAX_PER_LEVEL; i += BIN_T) (&s_cnt[0][0])[i] = 0;
     if (tid < LNERF_MAX_LEVELS) s_lmax[tid] = 0u;
     if (tid < 2) s_ovf[tid] = 0;
@@ -630,7 +643,7 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restri
         LevelPos p;
         p.gx = p.gy = p.gz = 0u; p.fx = p.fy = p.fz = 0.f;
         RunInfo ri;
-        ri.start = lane; ri.tail = true;
+        ri.start = lane; ri.tail = true; ri.heads = ~0ull;
         uint32_t row[8];
         bool emit = false;
         if (wave_live) {
@@ -646,8 +659,12 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restri
             }
             corner_rows(p.gx, p.gy, p.gz, lv.res, lv.hsize, row);
             if (lv.compact) {  // wave-uniform: coarse level, merge runs of samples in the same cell first
-                ri = wave_cell_runs(p.gx, p.gy, p.gz, valid);
-                const unsigned long long seg = (nzmask >> ri.start) & ((2ull << (lane - ri.start)) - 1ull);
+                // (the lane number is made opaque per item: the 64-bit lane masks derived from it are cheaper to
+                // recompute than to keep -- hoisted out of the item loop they were spilled to scratch)
+                int lane_v = lane;
+                asm volatile("" : "+v"(lane_v));
+                ri = wave_cell_runs(p.gx, p.gy, p.gz, valid, lane_v);
+                const unsigned long long seg = (nzmask >> ri.start) & ((2ull << (lane_v - ri.start)) - 1ull);
                 emit = valid && ri.tail && (!skip_zero || seg != 0ull);
             } else {
                 emit = valid && (!skip_zero || nzg);
@@ -675,14 +692,7 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restri
             const bool odd = ((__float_as_uint(gg.x) & 0x7F800000u) == 0x7F800000u) ||
                              ((__float_as_uint(gg.y) & 0x7F800000u) == 0x7F800000u);  // NaN / inf in the gradient
             if (lv.compact) {
-                wave_inclusive_sum_x16(v0, v1);   // run sum = P[tail] - P[start - 1]
-                const int prev = (ri.start - 1) << 2;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const float a = __int_as_float(__builtin_amdgcn_ds_bpermute(prev, __float_as_int(v0[c])));
-                    const float b = __int_as_float(__builtin_amdgcn_ds_bpermute(prev, __float_as_int(v1[c])));
-                    if (ri.start > 0) { v0[c] -= a; v1[c] -= b; }
-                }
+                wave_run_sums_x16(v0, v1, ri, lane);          // the run's tail lane holds the run sum
                 mx *= 64.0f;                             // ... and a run sums at most 64 samples
             }
             const bool any_odd = __ballot(odd) != 0ull;
