@@ -36,8 +36,9 @@ __device__ __forceinline__ void corner_rows(uint32_t gx, uint32_t gy, uint32_t g
     const uint32_t stride = res + 1;
     const uint64_t cube = (uint64_t)stride * stride * stride;
     if (cube <= (uint64_t)hsize) {  // wave-uniform
+        // (a dense level has stride^3 <= hsize < 2^31: all factors below 2^24 -- full-rate 24-bit multiplies)
         const uint32_t s2 = stride * stride;
-        const uint32_t base = gx + gy * stride + gz * s2;
+        const uint32_t base = gx + __umul24(gy, stride) + __umul24(gz, s2);
 #pragma unroll
         for (int c = 0; c < 8; ++c) row[c] = base + (c & 1) + ((c >> 1) & 1) * stride + ((c >> 2) & 1) * s2;
         return;
@@ -386,7 +387,7 @@ struct alignas(8) Rec8 {
     static constexpr bool kPacked = true;
     static __device__ __forceinline__ uint32_t f26(float v) {
         uint32_t u = __float_as_uint(v);
-        if ((u & 0x7F800000u) != 0x7F800000u) u += 0x1Fu + ((u >> 6) & 1u);  // finite: round to nearest even
+        if ((u & 0x7F800000u) != 0x7F800000u) u += 0x20u;  // finite: round to nearest, ties away from zero
         return u >> 6;
     }
     static __device__ __forceinline__ Rec8 make(uint32_t row, float a, float b) {
@@ -401,6 +402,16 @@ struct alignas(8) Rec8 {
     __device__ __forceinline__ float b() const { return __uint_as_float((hi >> 6) << 6); }
 };
 static_assert(BK_SHIFT == 12, "Rec8 stores 12 row bits");
+
+// Distance between two buckets' cursors (and two levels' maxima) in int32 words: one 128-byte line each.  Device-scope
+// atomics execute at the memory side, and those that hit ONE line are served one after the other whatever word they
+// name: with the cursors packed (32 to a line, a level's 128 on 4 lines) the binning pass's 1.3 M reservations per
+// launch queued on 64 lines -- same-box A/B of the bench step: scatter 0.274 -> 0.254 ms with a line per cursor
+// (64-byte spacing: no change; 256-byte: same as 128).
+#ifndef LNERF_CUR_STRIDE
+#define LNERF_CUR_STRIDE 32
+#endif
+constexpr int CUR_STRIDE = LNERF_CUR_STRIDE;
 
 struct BucketMeta {
     int nb[LNERF_MAX_LEVELS];            // buckets per level
@@ -483,10 +494,10 @@ constexpr int BIN_WAVES = BIN_T / 64;
 // one or two cursor words -- one word takes ~88 returning atomics per microsecond; more: the per-wave histogram)
 constexpr int BIN_DIRECT_MIN = 8, BIN_DIRECT_NB = 64;
 
-// fast f32 -> 26-bit float (round to nearest even), valid for finite values
+// fast f32 -> 26-bit float (round to nearest, ties away from zero: one add on the sign-magnitude bits; symmetric in
+// the sign, and a tie is one value in 64), valid for finite values
 __device__ __forceinline__ uint32_t f26_round(float v) {
-    const uint32_t u = __float_as_uint(v);
-    return u + 0x1Fu + ((u >> 6) & 1u);  // (low 6 bits are dropped by the packing)
+    return __float_as_uint(v) + 0x20u;  // (low 6 bits are dropped by the packing)
 }
 template <typename REC, bool CAREFUL> struct PackRec;
 template <bool CAREFUL> struct PackRec<Rec12, CAREFUL> {
@@ -641,13 +652,12 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restri
         const unsigned long long nzmask = __ballot(nzg);
         const bool wave_live = !skip_zero || nzmask != 0ull;
         LevelPos p;
-        p.gx = p.gy = p.gz = 0u; p.fx = p.fy = p.fz = 0.f;
         RunInfo ri;
         ri.start = lane; ri.tail = true; ri.heads = ~0ull;
         uint32_t row[8];
         bool emit = false;
         if (wave_live) {
-            if (valid) {
+            {   // (lanes past the end hold zeros from the fetch: same arithmetic, nothing emitted)
                 float px = n_x + bound, py = n_y + bound, pz = n_z + bound;
                 if (pow2_bound) { px *= inv_two_b; py *= inv_two_b; pz *= inv_two_b; }   // == the division, exactly
                 else { px /= two_b; py /= two_b; pz /= two_b; }
@@ -669,9 +679,10 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restri
             } else {
                 emit = valid && (!skip_zero || nzg);
             }
-        } else {
+        } else {  // nothing is emitted: rows and position are never looked at (defined without an instruction)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) row[c] = 0u;
+            for (int c = 0; c < 8; ++c) asm("" : "=v"(row[c]));
+            asm("" : "=v"(p.gx), "=v"(p.gy), "=v"(p.gz), "=v"(p.fx), "=v"(p.fy), "=v"(p.fz));
         }
         // ---- D (a lambda: placed behind the reservations on hashed levels): the values w * g (run sums on coarse
         // levels), packed into records; the bound of |value| goes to the level's LDS maximum
@@ -749,7 +760,7 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restri
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane < nb) {
                 const int n = hist[lane];
-                if (n) my_base = atomicAdd(&cursor[lv.b0 + lane], n);  // the wave's span in bucket `lane`
+                if (n) my_base = atomicAdd(&cursor[(lv.b0 + lane) * CUR_STRIDE], n);  // the wave's span in bucket `lane`
             }
         } else {
             // ================= hashed level ==================================================================
@@ -771,7 +782,7 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restri
             // ---- C: ONE returning global atomic per touched bucket reserves its span
             if (tid < nb) {
                 const int c = s_cnt[cur][tid];
-                if (c) my_base = atomicAdd(&cursor[lv.b0 + tid], c);
+                if (c) my_base = atomicAdd(&cursor[(lv.b0 + tid) * CUR_STRIDE], c);
             }
         }
         // the next item's inputs follow the reservations into the memory queue; both are consumed after the arithmetic
@@ -865,7 +876,7 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restri
         l = l_next; tile = tile_next; have = have_next;
     }
     __syncthreads();
-    if (tid < L && s_lmax[tid] != 0u) atomicMax(&gmax[tid], s_lmax[tid]);  // one value per LEVEL and workgroup
+    if (tid < L && s_lmax[tid] != 0u) atomicMax(&gmax[tid * CUR_STRIDE], s_lmax[tid]);  // one value per LEVEL and workgroup
     BIN_STAMP_FLUSH();
 }
 #undef LNERF_BIN_LEVEL
@@ -940,7 +951,7 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
     const int local = wg - bm.wgstart[l];
     const int b = local / Smax, s = local - b * Smax;
     const int cap = bm.cap[l];
-    const int n_raw = cursor[bm.bstart[l] + b];  // > cap: the excess records went to dtable with global atomics
+    const int n_raw = cursor[(bm.bstart[l] + b) * CUR_STRIDE];  // > cap: the excess records went to dtable with global atomics
     const int n = n_raw < cap ? n_raw : cap;
     const int S = active_slices(n, Smax);
     if (s >= S) return;    // uniform per workgroup
@@ -950,7 +961,7 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
     const bool have = hi > lo;  // uniform
     if (!have && !fuse) return;  // (a fused bucket without records still owes its rows the Adam step, g = 0)
     constexpr int FB = FixBits<REC>::kBits;
-    const FixScale fs = fix_scale<FB>(gmax[l]);  // from the bound of |value| of the LEVEL (found by pass 1)
+    const FixScale fs = fix_scale<FB>(gmax[l * CUR_STRIDE]);  // from the bound of |value| of the LEVEL (found by pass 1)
     const int tid = threadIdx.x;
     RED_STAMP_INIT();
     const int hsize = meta.offsets[l + 1] - meta.offsets[l];
@@ -1086,7 +1097,7 @@ k_scatter_finish(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
     if (l < lv_lo || l >= lv_hi) return;  // a launch over a level range (pipelined data-parallel exchange)
     const int b = fb - bm.fstart[l];
     const int Smax = bm.slices[l], cap = bm.cap[l];
-    const int n_raw = cursor[bm.bstart[l] + b];
+    const int n_raw = cursor[(bm.bstart[l] + b) * CUR_STRIDE];
     const int n = n_raw < cap ? n_raw : cap;
     const int S = active_slices(n, Smax);
     if (S <= 1) return;  // the bucket was finished by its single pass-2 workgroup
@@ -1112,7 +1123,7 @@ k_scatter_finish(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
         q0 += pt[(int64_t)s * (BK_ROWS * 2) + r];
         q1 += pt[(int64_t)s * (BK_ROWS * 2) + BK_ROWS + r];
     }
-    const FixScale fs = fix_scale<FB>(gmax[l]);
+    const FixScale fs = fix_scale<FB>(gmax[l * CUR_STRIDE]);
     float g0 = ((float)q0 * fs.un_a) * fs.un_b, g1 = ((float)q1 * fs.un_a) * fs.un_b;
     const int64_t R = (int64_t)meta.offsets[l] + row0 + r;
     float2 *d2 = reinterpret_cast<float2 *>(dtable) + R;
@@ -1165,9 +1176,9 @@ static int g_skip_zero = 1;
 // threads per workgroup of the reduce pass (512 or 1024; two 64 KiB workgroups fit a CU either way)
 static int g_reduce_threads = 1024;
 
-// device header of the workspace: bucket cursors (int32) followed by the per-level maxima (uint32)
+// device header of the workspace: bucket cursors (int32) followed by the per-level maxima (uint32), CUR_STRIDE apart
 static size_t cursor_bytes(int n_buckets) {
-    return ((size_t)(n_buckets + LNERF_MAX_LEVELS) * sizeof(int32_t) + 4095) / 4096 * 4096;
+    return ((size_t)(n_buckets + LNERF_MAX_LEVELS) * CUR_STRIDE * sizeof(int32_t) + 4095) / 4096 * 4096;
 }
 
 struct ScatterPlan {
@@ -1464,7 +1475,7 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
     LNERF_REQUIRE(((uintptr_t)workspace & 15) == 0 && ((uintptr_t)dtable & 15) == 0,
                   "grid_encode_backward: workspace/dtable must be 16-byte aligned");
     int32_t *cursor = (int32_t *)workspace;
-    unsigned int *gmax = (unsigned int *)workspace + nbk;
+    unsigned int *gmax = (unsigned int *)workspace + (size_t)nbk * CUR_STRIDE;
     void *rec = (char *)workspace + cbytes;
     long long *partials = (long long *)((char *)workspace + cbytes + plan.rec_bytes);
     const bool packed = variant == 3;
