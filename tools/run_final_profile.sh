@@ -9,7 +9,7 @@ timeout -k 10 300 python3 bench.py --breakdown > gpurun_out/${NAME}_bench_defaul
 rc=$?; cat gpurun_out/${NAME}_bench_default.json; [ $rc -ne 0 ] && { tail -5 gpurun_out/${NAME}_bench.err; exit $rc; }
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/${NAME}_prof
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${NAME}_prof -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $R/gpurun_out/${NAME}_prof.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${NAME}_prof -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras > $R/gpurun_out/${NAME}_prof.log 2>&1
 rc=$?; echo "rocprof rc=$rc"; [ $rc -ne 0 ] && exit $rc
 cp $R/gpurun_out/${NAME}_prof/*/*kernel_stats.csv $R/gpurun_out/${NAME}_kernel_stats.csv
 head -14 $R/gpurun_out/${NAME}_kernel_stats.csv | cut -c1-150
