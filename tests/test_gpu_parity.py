@@ -252,6 +252,38 @@ def test_bucketed_scatter_is_bitwise_reproducible(dev, variant):
 
 
 @pytest.mark.parametrize("variant", [2, 3])
+@pytest.mark.parametrize("step", [0.0009, 0.0034, 0.02])
+def test_bucketed_scatter_merges_runs_along_rays(dev, variant, step):
+    """Samples ordered along rays (what the march produces): consecutive lanes of a wavefront sit in the same cell for
+    runs of 1 ... 64 lanes depending on level and step, the runs cross the 16- and 32-lane rows of the segmented scan
+    at arbitrary places, and stretches of exactly-zero gradients (samples behind a ray's termination) fall inside and
+    across runs.  The merged sums must equal the oracle's autograd."""
+    from src.latent_nerf.models import encoding as E
+    levels = E.GridLevels()
+    lv = O.make_grid_levels()
+    g = torch.Generator().manual_seed(21)
+    n_rays, per_ray = 300, 97                       # 97: rays do not start on wavefront boundaries
+    o = (torch.rand(n_rays, 1, 3, generator=g) * 2 - 1) * 0.6
+    d = torch.nn.functional.normalize(torch.randn(n_rays, 1, 3, generator=g), dim=-1)
+    d[::7] = torch.tensor([1.0, 0.0, 0.0])          # axis-parallel rays: the longest runs
+    t = torch.arange(per_ray).view(1, per_ray, 1) * step
+    x = (o + d * t).clamp(-0.999, 0.999).reshape(-1, 3)
+    M = x.shape[0]
+    grad = torch.randn(M, 32, generator=g)
+    dead = (torch.arange(M) % per_ray) >= torch.randint(20, per_ray + 1, (n_rays,), generator=g).repeat_interleave(per_ray)
+    grad[dead] = 0.0                                 # terminated tails: exact zeros
+    tref = torch.zeros(lv.n_rows, 2, requires_grad=True)
+    O.grid_encode((x + 1) / 2, tref, lv).backward(grad)
+    dfeat = grad.reshape(M, 16, 2).permute(1, 0, 2).contiguous().to(dev)
+    dtable = torch.zeros(lv.n_rows, 2, device=dev)
+    E.grid_encode_backward(x.to(dev), 1.0, dfeat, levels, M, None, M, dtable, variant=variant)
+    _close(dtable, tref.grad, 1e-3, 2e-4 if variant == 3 else 5e-5, "run-merged dtable")
+    if variant == 2:  # (the 8-byte records quantise to 2^-30 of the level's bound: a 1e-7-weight corner may vanish)
+        nz_ref = (tref.grad.abs().sum(-1) > 0)
+        assert torch.equal((dtable.abs().sum(-1) > 0).cpu() | ~nz_ref, torch.ones_like(nz_ref))  # no row lost
+
+
+@pytest.mark.parametrize("variant", [2, 3])
 def test_bucketed_scatter_overflow_falls_back_to_atomics(dev, variant):
     """All samples inside one fine cell: every record of a hashed level lands in <= 8 buckets, far
     beyond their reserved regions -> the excess must take the global-atomic fallback and the sums

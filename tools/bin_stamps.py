@@ -14,9 +14,9 @@ for _p in (ROOT, os.path.join(ROOT, "latent-nerf-test_amd")):
     sys.path.insert(0, _p)
 import torch  # noqa: E402
 
-PHASES = ["0 loop top (+ parked records of the previous hashed item)", "1 hashed: rank + stage (LDS)", "2 hashed: barrier 1",
-          "3 reservations issued + NEXT item's records prepared (+ its inputs / direct reservations waited for by the stamp)",
-          "4 hashed: copy-out, stores completed", "5 hashed: barrier 2", "6 direct: stores completed", "7 -", "8 -"]
+PHASES = ["0 loop top", "1 A: cell, rows, runs, emit mask", "2 B: ranking (LDS counters)", "3 barrier 1",
+          "4 C+D: reservations + prefetch issued and waited for, values, tile max", "5 E+F: count scan, staging",
+          "6 destinations (reservations waited for)", "7 barrier 3", "8 G: copy-out, stores completed (direct levels: stores)"]
 
 
 def main():
