@@ -15,7 +15,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from ...utils import make_path, seed_everything, tensor2numpy
+from ...utils import make_path, seed_everything, tensor2numpy, write_video
 from ..configs.train_config import TrainConfig
 from ..models.network_grid import NeRFNetwork
 from . import distributed as D
@@ -191,14 +191,19 @@ class Trainer:
 
     @torch.no_grad()
     def evaluate(self, dataset, save_path: Path, save_as_video=False):
+        """One render per evaluation pose: PNG files during training, one video for the final pass (file names of
+        src/latent_paint/training/trainer.py:146-172)."""
+        from PIL import Image
         self.nerf.eval()
         frames = []
         for i, data in enumerate(dataset):
             pred, depth = self.eval_render(data)
             rgb = self.preview_rgb(pred)
             frames.append(rgb)
-            if self.rank == 0:
-                np.save(save_path / ("step_%05d_%04d_rgb.npy" % (self.train_step, i)), rgb)
+            if self.rank == 0 and not save_as_video:
+                Image.fromarray(rgb).save(save_path / ("step_%05d_%04d_rgb.png" % (self.train_step, i)))
+        if self.rank == 0 and save_as_video and frames:
+            write_video(save_path / ("step_%05d_rgb" % self.train_step), frames)
         return frames
 
     def full_eval(self):

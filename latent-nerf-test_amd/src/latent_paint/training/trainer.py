@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from ... import config_cli
 from ...latent_nerf.training.guidance import StableDiffusionGuidance, SyntheticGuidance
 from ...latent_nerf.training.optimizer import FusedAdam
-from ...utils import make_path, seed_everything, tensor2numpy
+from ...utils import make_path, seed_everything, tensor2numpy, write_video
 from ..configs.train_config import TrainConfig
 from ..models.textured_mesh import TexturedMeshModel
 from .views_dataset import ViewsDataset
@@ -159,13 +159,7 @@ class Trainer:
         if texture is not None:   # the texture map is the same for every view
             Image.fromarray(tensor2numpy(texture[0])).save(save_path / ("step_%05d_texture.png" % self.train_step))
         if save_as_video and frames:
-            video = np.stack(frames, axis=0)
-            try:
-                import imageio
-                imageio.mimsave(save_path / ("step_%05d_rgb.mp4" % self.train_step), video, fps=25, quality=8,
-                                macro_block_size=1)
-            except ImportError:   # no video writer here: keep the frames
-                np.save(save_path / ("step_%05d_rgb.npy" % self.train_step), video)
+            write_video(save_path / ("step_%05d_rgb" % self.train_step), frames)
         return frames
 
     def full_eval(self):

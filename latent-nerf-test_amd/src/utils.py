@@ -55,3 +55,19 @@ def seed_everything(seed: int) -> None:
     torch.manual_seed(seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed(seed)
+
+
+def write_video(stem: Path, frames, fps: int = 25) -> Path:
+    """uint8 frames [T,H,W,3] -> `<stem>.mp4` through imageio when it is importable (what the reference's trainers call,
+    src/latent_paint/training/trainer.py:170-172), else an animated `<stem>.gif` through Pillow.  Returns the file."""
+    frames = [np.asarray(f, dtype=np.uint8) for f in frames]
+    try:
+        import imageio
+        out = Path(str(stem) + ".mp4")
+        imageio.mimsave(out, np.stack(frames, axis=0), fps=fps, quality=8, macro_block_size=1)
+    except ImportError:
+        from PIL import Image
+        out = Path(str(stem) + ".gif")
+        ims = [Image.fromarray(f) for f in frames]
+        ims[0].save(out, save_all=True, append_images=ims[1:], duration=int(round(1000 / fps)), loop=0)
+    return out

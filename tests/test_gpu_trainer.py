@@ -62,8 +62,12 @@ def test_training_reduces_guidance_error_and_checkpoints_roundtrip(dev, tmp_path
     tr.train_step = 90
     tr.save_checkpoint(full=True)
     assert [c.name for c in sorted(tr.ckpt_path.glob("*.pth"))] == ["step_000060.pth", "step_000090.pth"]
-    frames = tr.full_eval() if False else tr.evaluate(tr.dataloaders["val"], tr.eval_renders_path)
+    frames = tr.evaluate(tr.dataloaders["val"], tr.eval_renders_path)
     assert len(frames) == 2 and frames[0].shape == (32, 32, 3) and frames[0].dtype.name == "uint8"
+    assert sorted(p.name for p in tr.eval_renders_path.glob("step_00090_*_rgb.png")) == \
+        ["step_00090_0000_rgb.png", "step_00090_0001_rgb.png"]
+    video = tr.evaluate(tr.dataloaders["val"], tr.final_renders_path, save_as_video=True)   # what full_eval() does
+    assert len(video) == 2 and len(list(tr.final_renders_path.glob("step_00090_rgb.*"))) == 1
 
 
 def test_bf16_training_step_runs(dev, tmp_path):

@@ -78,3 +78,15 @@ def test_precision_follows_fp16_only_where_left_on_auto():
     assert r.mlp_precision == "auto" and r.precision("mlp_precision") == "f32" and r.precision("table_dtype") == "f32"
     with pytest.raises(ValueError):
         load_config(["--render.mlp_precision", "fp8"])
+
+
+def test_write_video_writes_every_frame(tmp_path):
+    """mp4 through imageio where it exists, else an animated GIF through Pillow: either way one file, all frames."""
+    import numpy as np
+    from src.utils import write_video
+    frames = [np.full((8, 8, 3), 40 * i, dtype=np.uint8) for i in range(5)]
+    out = write_video(tmp_path / "step_00001_rgb", frames)
+    assert out.exists() and out.stat().st_size > 0 and out.suffix in (".mp4", ".gif")
+    if out.suffix == ".gif":
+        from PIL import Image
+        assert Image.open(out).n_frames == 5
