@@ -94,12 +94,15 @@ int lnerf_packbits(const float *grid, int64_t n_cells, float thresh, const float
                    lnerf_stream_t stream);
 
 /* ---- H4: `raymarching.march_rays_train`.
- * Three launches: per-ray count (one wavefront per ray, ballot + popcount over 64 lattice
- * points at a time), single-workgroup exclusive scan, per-ray write (ballot prefix-sum
- * compaction).  Output order is deterministic: samples of ray n follow those of ray n-1.
+ * Two launches up to 8192 rays: per-ray count (one wavefront per ray, ballot + popcount over 64 lattice points at a
+ * time), per-ray write (ballot prefix-sum compaction) whose wavefront first sums the counts of the rays before its own;
+ * three launches above (count, single-workgroup exclusive scan, write).  Output order is deterministic: samples of ray
+ * n follow those of ray n-1.
  *   rays    int32 [N,3]  (ray id, offset, count)
- *   counter int32 [4]    [0]=M total samples written, [1]=number of rays with count>0,
- *                        [2]=rays dropped because offset+count exceeded `capacity`, [3]=reserved
+ *   counter int32 [lnerf_march_counter_len(N)]
+ *                        [0]=M total samples written, [1]=number of rays with count>0,
+ *                        [2]=rays dropped because offset+count exceeded `capacity`, [3]=reserved,
+ *                        [4 ...) scratch of the call (two-launch form: per-ray counts, per-workgroup sums)
  *   jitter of the march start t0 = near + dt(near) * u_n, one of
  *     noises [N] in [0,1)          the upstream form (`noises = torch.rand(N)`);
  *     noise_counter (device int32) counter-based generator: u_n = hash(n, noise_seed, *noise_counter) in [0,1)
@@ -108,6 +111,7 @@ int lnerf_packbits(const float *grid, int64_t n_cells, float thresh, const float
  *                                  captured hipGraph, no host RNG state;
  *     both NULL                    no jitter.
  *   xyzs [capacity,3], dirs [capacity,3], deltas [capacity,2] = (dt, t). */
+int64_t lnerf_march_counter_len(int64_t N);
 int lnerf_march_rays_train(const float *rays_o, const float *rays_d, const float *nears, const float *fars, int64_t N,
                            const uint8_t *bitfield, float bound, int cascade, int grid_size, int max_steps,
                            float dt_gamma, const float *noises, uint32_t noise_seed, int32_t *noise_counter,

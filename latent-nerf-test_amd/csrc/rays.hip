@@ -172,6 +172,50 @@ __device__ __forceinline__ float march_noise(const MarchNoise &nz, int64_t n) {
     return march_hash_uniform((uint32_t)n, nz.seed, (uint32_t)(*nz.counter - nz.bias));
 }
 
+// Totals of a training march from the per-ray counts, by ONE wavefront (every lane must call it): what k_march_scan
+// writes to `counter`, by the same rule -- a ray is dropped when the samples of all rays before it (dropped or not) plus
+// its own exceed the capacity.  64 rays per round: inclusive wave scan + running carry.  Advances the jitter counter.
+#ifndef LNERF_MARCH_FUSED_MAX_RAYS
+#define LNERF_MARCH_FUSED_MAX_RAYS 8192   // above: the per-wavefront prefix (N^2 / 2 loads) loses to the scan kernel
+#endif
+constexpr int64_t MARCH_FUSED_MAX_RAYS = LNERF_MARCH_FUSED_MAX_RAYS;
+__device__ __forceinline__ void march_totals(const int32_t *__restrict__ cnt, int64_t N, int64_t capacity,
+                                             int32_t *__restrict__ counter, int32_t *__restrict__ noise_counter) {
+    const int lane = lane_id();
+    long long carry = 0, best = 0;
+    int live = 0, drop = 0;
+    for (int64_t base = 0; base < N; base += 64) {
+        const int64_t i = base + lane;
+        const int c = i < N ? cnt[i] : 0;   // (one round trip per 64 rays: this is the rare overflow path)
+        long long inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const long long u = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += u;
+        }
+        const long long off = carry + inc - c;
+        const bool dropped = (c > 0) && (off + c > capacity);
+        if (c > 0 && !dropped) { ++live; best = off + c > best ? off + c : best; }
+        drop += dropped ? 1 : 0;
+        carry += __shfl(inc, 63, 64);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        live += __shfl_xor(live, o, 64);
+        drop += __shfl_xor(drop, o, 64);
+        const long long u = __shfl_xor(best, o, 64);
+        best = u > best ? u : best;
+    }
+    if (lane == 0) {
+        // M: all samples when nothing was dropped, else the end of the last kept span
+        counter[0] = drop > 0 ? (int32_t)best : (int32_t)(carry > capacity ? capacity : carry);
+        counter[1] = live;
+        counter[2] = drop;
+        counter[3] = 0;
+        if (noise_counter) *noise_counter += 1;   // (this pass took its jitter from rays[][1], not from the counter)
+    }
+}
+
 // One wavefront per ray.  Each iteration tests 64 consecutive lattice points of the ray;
 // ballot + popcount gives the count (pass 1) or, with mbcnt, each sample's slot (pass 2).
 template <bool WRITE, bool UNIFORM_DT>
@@ -179,9 +223,17 @@ __global__ void __launch_bounds__(256)
 k_march_train(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ nears,
               const float *__restrict__ fars, RayBox box, int clip, RayGen gen, int64_t N, const uint8_t *__restrict__ bitfield, MarchParams P,
               MarchNoise noises, float *__restrict__ xyzs, float *__restrict__ dirs,
-              float *__restrict__ deltas, int32_t *__restrict__ rays) {
+              float *__restrict__ deltas, int32_t *__restrict__ rays, int32_t *__restrict__ cnt, int64_t capacity,
+              int32_t *__restrict__ counter, int32_t *__restrict__ noise_counter) {
     const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform
-    if (n >= N) return;
+    __shared__ int s_count[4];
+    if (n >= N) {
+        if (!WRITE && cnt) {   // (the workgroup's other wavefronts wait for this one at the barrier below)
+            if ((threadIdx.x & 63) == 0) s_count[threadIdx.x >> 6] = 0;
+            __syncthreads();
+        }
+        return;
+    }
     const int lane = lane_id();
     // the ray: generated here by the count pass of the `_pose` form (k_get_rays' arithmetic; written out for the write
     // pass and the caller), else read
@@ -205,7 +257,62 @@ k_march_train(const float *__restrict__ rays_o, const float *__restrict__ rays_d
     int count = 0;
     int64_t offset = 0;
     int budget = P.max_steps;
-    if (WRITE) {
+    float noise_in = 0.f;
+    if (WRITE && cnt) {
+        // Scan-free form (N <= MARCH_FUSED_MAX_RAYS): the count pass left every ray's count in `cnt`, every workgroup's
+        // (4 rays') sum and number of non-empty rays in cnt[N + workgroup], and the ray's jitter in rays[n][1]; this
+        // wavefront sums what lies before its ray -- what the single-workgroup scan kernel between the two passes did,
+        // without that dispatch (7 us of launch latency for 2 us of work).  One batch of loads for 4096 rays.  `cnt` is
+        // never modified here, so every wavefront sees the original counts whatever the others have already written.
+        const int32_t *wg = cnt + N;
+        const int64_t w = n >> 2;
+        long long part = 0;
+        int nonempty = 0;
+        for (int64_t j0 = 0; j0 < w; j0 += 1024) {   // sixteen loads in flight per lane
+            int v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int64_t j = j0 + k * 64 + lane;
+                v[k] = j < w ? wg[j] : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { part += v[k] & 0xFFFFFF; nonempty += v[k] >> 28; }
+        }
+        {   // the rays of this ray's own workgroup that come before it
+            const int64_t i = 4 * w + lane;
+            const int c = (lane < 4 && i < n) ? cnt[i] : 0;
+            part += c;
+            nonempty += c > 0 ? 1 : 0;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            part += __shfl_xor(part, o, 64);
+            nonempty += __shfl_xor(nonempty, o, 64);
+        }
+        const int c = cnt[n];
+        const bool dropped = (c > 0) && (part + c > capacity);   // (k_march_scan's rule)
+        offset = dropped ? 0 : part;
+        budget = dropped ? 0 : c;
+        noise_in = __int_as_float(rays[n * 3 + 1]);
+        if (lane == 0) {
+            rays[n * 3 + 1] = (int32_t)offset;
+            if (dropped) rays[n * 3 + 2] = 0;
+        }
+        if (n == N - 1) {   // the last ray's wavefront has the totals at hand
+            const long long total = part + c;
+            if (total <= capacity) {
+                if (lane == 0) {
+                    counter[0] = (int32_t)total;
+                    counter[1] = nonempty + (c > 0 ? 1 : 0);
+                    counter[2] = 0;
+                    counter[3] = 0;
+                    if (noise_counter) *noise_counter += 1;   // (this pass took its jitter from rays[][1])
+                }
+            } else {
+                march_totals(cnt, N, capacity, counter, noise_counter);   // rays were dropped: the scan's bookkeeping
+            }
+        }
+    } else if (WRITE) {
         offset = rays[n * 3 + 1];
         budget = rays[n * 3 + 2];  // 0 if the ray was dropped for capacity
     }
@@ -213,7 +320,8 @@ k_march_train(const float *__restrict__ rays_o, const float *__restrict__ rays_d
         const float ox = ro[0], oy = ro[1], oz = ro[2];
         const float dx = rd[0], dy = rd[1], dz = rd[2];
         const float dt0 = clampf(near * P.dt_gamma, P.dt_min, P.dt_max);
-        const float noise = march_noise(noises, n);
+        const float noise = (WRITE && cnt) ? noise_in : march_noise(noises, n);
+        if (!WRITE && cnt && lane == 0) rays[n * 3 + 1] = __float_as_int(noise);   // hand the jitter to the write pass
         const float t0 = near + dt0 * noise;
         float t = t0;
         if (!UNIFORM_DT) {  // lane l starts at lattice point l
@@ -296,8 +404,19 @@ k_march_train(const float *__restrict__ rays_o, const float *__restrict__ rays_d
     }
     if (!WRITE && lane == 0) {
         rays[n * 3] = (int32_t)n;
-        rays[n * 3 + 1] = 0;
+        if (!(cnt && near < far)) rays[n * 3 + 1] = 0;   // (scan-free form: the jitter of a marched ray sits here)
         rays[n * 3 + 2] = count;
+        if (cnt) cnt[n] = count;
+    }
+    if (!WRITE && cnt) {   // per workgroup: samples in bits [0,24) (4 rays x <= 65536 steps), non-empty rays in [28,31)
+        if (lane == 0) s_count[threadIdx.x >> 6] = count;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int sum = 0, ne = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sum += s_count[k]; ne += s_count[k] > 0 ? 1 : 0; }
+            cnt[N + blockIdx.x] = sum | (ne << 28);
+        }
     }
 }
 
@@ -755,25 +874,32 @@ static int march_train_impl(const float *rays_o, const float *rays_d, const floa
     if (raygen) gen = *raygen;
     MarchNoise nz;
     nz.values = noises; nz.counter = noise_counter; nz.seed = noise_seed; nz.bias = 0;
+    // up to MARCH_FUSED_MAX_RAYS rays: two dispatches (the write pass sums the counts before its ray itself; the counts
+    // live behind the four totals in `counter`, see lnerf_march_counter_len); more: count, scan, write
+    int32_t *cnt = N <= MARCH_FUSED_MAX_RAYS ? counter + 4 : nullptr;
     if (dt_gamma == 0.f)
         hipLaunchKernelGGL((k_march_train<false, true>), grid, block, 0, s, rays_o, rays_d, nears, fars, box, clip, gen, N,
-                           bitfield, P, nz, xyzs, dirs, deltas, rays);
+                           bitfield, P, nz, xyzs, dirs, deltas, rays, cnt, capacity, counter, noise_counter);
     else
         hipLaunchKernelGGL((k_march_train<false, false>), grid, block, 0, s, rays_o, rays_d, nears, fars, box, clip, gen, N,
-                           bitfield, P, nz, xyzs, dirs, deltas, rays);
+                           bitfield, P, nz, xyzs, dirs, deltas, rays, cnt, capacity, counter, noise_counter);
     LNERF_CHECK_LAUNCH("march_rays_train(count)");
-    hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, s, rays, N, capacity, counter, noise_counter);
-    LNERF_CHECK_LAUNCH("march_rays_train(scan)");
-    nz.bias = 1;
+    if (!cnt) {
+        hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, s, rays, N, capacity, counter, noise_counter);
+        LNERF_CHECK_LAUNCH("march_rays_train(scan)");
+        nz.bias = 1;
+    }
     if (dt_gamma == 0.f)
         hipLaunchKernelGGL((k_march_train<true, true>), grid, block, 0, s, rays_o, rays_d, nears, fars, box, clip, gen, N,
-                           bitfield, P, nz, xyzs, dirs, deltas, rays);
+                           bitfield, P, nz, xyzs, dirs, deltas, rays, cnt, capacity, counter, noise_counter);
     else
         hipLaunchKernelGGL((k_march_train<true, false>), grid, block, 0, s, rays_o, rays_d, nears, fars, box, clip, gen, N,
-                           bitfield, P, nz, xyzs, dirs, deltas, rays);
+                           bitfield, P, nz, xyzs, dirs, deltas, rays, cnt, capacity, counter, noise_counter);
     LNERF_CHECK_LAUNCH("march_rays_train(write)");
     return LNERF_OK;
 }
+
+int64_t lnerf_march_counter_len(int64_t N) { return 4 + (N >= 0 && N <= MARCH_FUSED_MAX_RAYS ? N + (N + 3) / 4 : 0); }
 
 int lnerf_march_rays_train(const float *rays_o, const float *rays_d, const float *nears, const float *fars, int64_t N,
                            const uint8_t *bitfield, float bound, int cascade, int grid_size, int max_steps,

@@ -67,6 +67,7 @@ _SIGNATURES = {
     "lnerf_mlp_backward_workspace_bytes": [_I],
     "lnerf_grid_scatter_clear_bytes": [_I, _P, _L],
     "lnerf_occ_sample_scratch_bytes": [_L],
+    "lnerf_march_counter_len": [_L],
     "lnerf_occ_sample": [_P, _L, _I, _I, _F, _L, _U, _U, _P, _P, _P, _P],
     "lnerf_mlp_backward": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _L, _P, _P, _P, _P, _P, _P, _P, _P,
                            _P, _P, _P, _I, _P, _Z, _I, _P, _Z, _P],
@@ -96,6 +97,7 @@ _RESTYPES = {
     "lnerf_mlp_backward_workspace_bytes": _Z,
     "lnerf_grid_scatter_clear_bytes": _Z,
     "lnerf_occ_sample_scratch_bytes": _Z,
+    "lnerf_march_counter_len": _L,
     "lnerf_grid_encode_backward_workspace_bytes": _Z,
 }
 

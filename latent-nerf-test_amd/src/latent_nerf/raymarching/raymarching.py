@@ -168,7 +168,8 @@ def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars,
         dirs = torch.empty(capacity, 3, device=dev, dtype=torch.float32)
         deltas = torch.empty(capacity, 2, device=dev, dtype=torch.float32)
         rays = torch.empty(N, 3, device=dev, dtype=torch.int32)
-        counter = torch.empty(4, device=dev, dtype=torch.int32)
+        # (four totals + the scratch the two-launch form of the march keeps its per-ray counts in)
+        counter = torch.empty(int(_b.get_lib().lnerf_march_counter_len(N)), device=dev, dtype=torch.int32)
     if camera is not None:
         if aabb is None or nears is not None:
             raise ValueError("march_rays_train(camera=...) needs aabb= and no nears/fars")

@@ -178,6 +178,27 @@ def test_march_cascades_cap_and_capacity(dev):
     assert M0 == 0 and int(res0.counter[0]) == 0 and int(res0.rays[:, 2].sum()) == 0
 
 
+def test_march_above_8192_rays_takes_the_scan_kernel(dev):
+    """Up to 8192 rays the write pass sums the counts before its ray itself (two launches); above, count / scan / write.
+    Both forms against the oracle, jitter table and capacity overflow included."""
+    G = 32
+    _, bits, _, _, ro, rd = _scene(G=G, HW=96)            # 9216 rays
+    assert ro.shape[0] > 8192
+    noises = torch.rand(ro.shape[0])
+    (xyzs, dirs, deltas, rays, M), res = _march_both(dev, ro, rd, bits, 1.0, 1, G, 128, 0.0, noises)
+    assert res.counter.numel() == 4                        # (no per-ray scratch in this form)
+    assert int(res.counter[0]) == M and M > 10000 and torch.equal(res.rays.cpu(), rays)
+    assert torch.equal(res.xyzs[:M].cpu(), xyzs) and torch.equal(res.deltas[:M].cpu(), deltas)
+    cap = M // 3
+    _, res_c = _march_both(dev, ro, rd, bits, 1.0, 1, G, 128, 0.0, noises, capacity=cap)
+    # the same rays in two halves of 4608 (two-launch form): the first half's spans and drops must agree
+    h = ro.shape[0] // 2
+    _, res_h = _march_both(dev, ro[:h], rd[:h], bits, 1.0, 1, G, 128, 0.0, noises[:h], capacity=cap)
+    assert res_h.counter.numel() == 4 + h + (h + 3) // 4
+    assert torch.equal(res_h.rays.cpu(), res_c.rays[:h].cpu())
+    assert int(res_c.counter[2]) >= int(res_h.counter[2]) > 0 and int(res_c.counter[0]) == int(res_h.counter[0]) <= cap
+
+
 # ------------------------------------------------------------------------------ H5 / H6
 def _rand_points(M, bound=1.0, seed=0):
     g = torch.Generator().manual_seed(seed)
