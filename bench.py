@@ -91,6 +91,8 @@ def parse():
                          "Measured on MI355X / ROCm 7.2: 0.4725 vs 0.4721 ms per step -- the branch does overlap the gather, "
                          "but the cross-queue hand-offs at the fork and the join cost what it hides (DESIGN.md section 5) -- "
                          "hence off by default (profiles/r02_exp_ray_prefetch.jsonl)")
+    ap.add_argument("--fragment-shadow", type=int, default=1,
+                    help="1: the optimiser mirrors the MLP weights into their bf16 fragments (no per-step fragment build)")
     ap.add_argument("--tune", default="", help="lnerf_set_tuning overrides for an experiment: key=value,key=value "
                     "(recorded in the output line; the default run sets none)")
     ap.add_argument("--exchange-groups", type=int, default=4,
@@ -386,7 +388,7 @@ def main():
     if fuse and world > 1:
         raise SystemExit("--fuse-table-update 1 needs --gpus 1 (the gradient all-reduce sits between backward and Adam)")
     opt = FusedAdam(net.get_params(LR if args.lr is None else args.lr), betas=(0.9, 0.99), eps=1e-15, encoder=net.encoder, capturable=True,
-                    fuse_table_update=fuse)
+                    fuse_table_update=fuse, mlp=net if args.fragment_shadow else None)
     opt.grad_scale = 1.0 / world
     tr = args.precision if args.grad_transport == "auto" else args.grad_transport
     groups = args.exchange_groups if (world > 1 and tr == "bf16") else 0
@@ -532,6 +534,7 @@ def main():
             "launch": launch, "eager_probe_steps": n_probe,
             "ray_prefetch": ("rays + occupancy march of step k+1 on a side stream during step k "
                              "(NeRFRenderer.prepare_rays, two buffer sets, two steps per captured graph)") if prefetch else None,
+            "mlp_fragment_shadow": bool(opt.mlp is not None),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

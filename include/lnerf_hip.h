@@ -225,6 +225,11 @@ int lnerf_grid_encode_backward_adam(const float *xyzs, float bound, const void *
                                     void *shadow_bf16, float lr, float beta1, float beta2, float eps, int step,
                                     const int32_t *step_dev, float grad_scale, lnerf_stream_t stream);
 
+/* ---- H7 helper: inverse of the bf16 weight-fragment layout at the head of the MLP workspace: map_wK[2 i], map_wK[2 i + 1] = the two
+ * bf16 elements of that image which hold weight i of wK (forward / transposed fragments).  map_w1 int32[64*32*2],
+ * map_w2 int32[64*64*2], map_w3 int32[out_dim*64*2].  For lnerf_adam_step_multi_shadow. */
+int lnerf_mlp_fragment_maps(int out_dim, int32_t *map_w1, int32_t *map_w2, int32_t *map_w3, lnerf_stream_t stream);
+
 /* ---- H7: fused sigma/latent MLP  32 -> 64 -> 64 -> out_dim (= 1 + C), ReLU hidden.
  * Weights are PyTorch nn.Linear layout: w1 [64,32], b1 [64], w2 [64,64], b2 [64], w3 [out_dim,64],
  * b3 [out_dim], all f32.  sigma = exp(h0 + blob_scale*exp(-|x|^2/(2 blob_std^2))), rgbs = h[1:].
@@ -232,7 +237,9 @@ int lnerf_grid_encode_backward_adam(const float *xyzs, float bound, const void *
  * level_stride <= 2^24 samples (32-bit byte offsets inside the kernels); with out_dim == 5 the bf16 path moves the
  * latent rows (rgbs, drgbs: [*, 4] f32) 16 bytes at a time: those buffers must be 16-byte aligned.
  * workspace (optional, 16-byte aligned, >= 36 KiB; the buffer of lnerf_mlp_backward_workspace_bytes() serves): with
- * it the bf16 path builds its weight fragments (the backward's too) once per launch instead of once per workgroup. */
+ * it the bf16 path builds its weight fragments (the backward's too) once per launch instead of once per workgroup;
+ * precision | LNERF_MLP_FRAGMENTS_READY: they are current already (fragment shadow of the optimiser, or an earlier
+ * forward with the same weights) -- no build at all. */
 int lnerf_mlp_forward(const void *feat, int feat_dtype, int64_t level_stride, const float *xyzs, const float *w1,
                       const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, int out_dim,
                       float blob_scale, float blob_std, int64_t m_host, const int32_t *m_dev, float *sigmas,
@@ -350,6 +357,16 @@ int lnerf_adam_step_multi(int count, float *const *p_host, float *const *g_host,
                           float *const *v_host, const int64_t *n_host, const float *lr_host, float beta1, float beta2,
                           float eps, int step, const int32_t *step_dev, float grad_scale, int zero_grad,
                           lnerf_stream_t stream);
+/* The same launch, which also mirrors tensors into a bf16 image: map_host[k] (NULL: tensor k is not mirrored) holds two
+ * int32 positions per element of tensor k (-1: none); the updated value is stored as bf16 at shadow_bf16[position].
+ * With the maps of lnerf_mlp_fragment_maps and the head of the MLP workspace as the image, the optimiser keeps the MLP's
+ * weight fragments current and lnerf_mlp_forward(... | LNERF_MLP_FRAGMENTS_READY) skips its per-step build (one
+ * dispatch of the step). */
+int lnerf_adam_step_multi_shadow(int count, float *const *p_host, float *const *g_host, float *const *m_host,
+                                 float *const *v_host, const int64_t *n_host, const float *lr_host, float beta1,
+                                 float beta2, float eps, int step, const int32_t *step_dev, float grad_scale,
+                                 int zero_grad, const int32_t *const *map_host, void *shadow_bf16,
+                                 lnerf_stream_t stream);
 int lnerf_cast_f32_to_bf16(const float *src, void *dst, int64_t n, lnerf_stream_t stream);
 
 #ifdef __cplusplus

@@ -409,10 +409,20 @@ using namespace lnerf;
 
 extern "C" {
 
+int lnerf_mlp_fragment_maps(int out_dim, int32_t *map_w1, int32_t *map_w2, int32_t *map_w3, lnerf_stream_t stream) {
+    LNERF_REQUIRE(out_dim >= 2 && out_dim <= 8, "mlp_fragment_maps: out_dim must be in [2,8] (got %d)", out_dim);
+    LNERF_REQUIRE(map_w1 && map_w2 && map_w3, "mlp_fragment_maps: null pointer");
+    return launch_mlp_fragment_maps(out_dim, map_w1, map_w2, map_w3, as_stream(stream));
+}
+
 int lnerf_mlp_forward(const void *feat, int feat_dtype, int64_t level_stride, const float *xyzs, const float *w1,
                       const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, int out_dim,
                       float blob_scale, float blob_std, int64_t m_host, const int32_t *m_dev, float *sigmas,
                       float *rgbs, int precision, void *workspace, size_t workspace_bytes, lnerf_stream_t stream) {
+    // (the caller keeps the fragments at the head of `workspace` current: the optimiser's fragment shadow, or an
+    // earlier forward with the same weights)
+    const bool fragments_ready = (precision & LNERF_MLP_FRAGMENTS_READY) != 0;
+    precision &= ~LNERF_MLP_FRAGMENTS_READY;
     int rc = mlp_common_checks("mlp_forward", feat, feat_dtype, level_stride, xyzs, w1, b1, w2, b2, w3, b3, out_dim,
                                blob_std, m_host, precision);
     if (rc) return rc;
@@ -430,9 +440,11 @@ int lnerf_mlp_forward(const void *feat, int feat_dtype, int64_t level_stride, co
         if (workspace && workspace_bytes >= MLP_FRAG_BYTES) {
             LNERF_REQUIRE(((uintptr_t)workspace & 15) == 0, "mlp_forward: workspace must be 16-byte aligned");
             // all of them, the backward's too: lnerf_mlp_backward(... | LNERF_MLP_FRAGMENTS_READY) skips its own build
-            const int rcf = launch_mlp_fragments_bf16(a, workspace, true, as_stream(stream));
+            const int rcf = fragments_ready ? LNERF_OK : launch_mlp_fragments_bf16(a, workspace, true, as_stream(stream));
             if (rcf) return rcf;
             a.frag_global = workspace;
+        } else {
+            LNERF_REQUIRE(!fragments_ready, "mlp_forward: LNERF_MLP_FRAGMENTS_READY without a workspace");
         }
         return launch_mlp_forward_bf16(a, sigmas, rgbs, (int)blocks, g_mlp_fwd_wps, as_stream(stream));
     }

@@ -42,31 +42,58 @@ constexpr int RS = 68;      // bf16 elements per row of a [128 samples][feature]
 
 __device__ __forceinline__ int phi_of(int s, int q, int jj) { return 32 * s + 16 * (jj >> 2) + 4 * q + (jj & 3); }
 
+// Where element e of the weight-fragment image comes from: tensor 1 / 2 / 3 (= w1 / w2 / w3) and the index into it, or
+// 0 for a constant zero (padding of the 16-row output tile).  ONE statement of the layout: the builder below reads
+// through it, k_mlp_fragment_maps inverts it for the optimiser's fragment shadow.
+__device__ __forceinline__ int frag_source(int e, int out_dim, int &idx) {
+    const int f = e >> 9, l = (e >> 3) & 63, jj = e & 7;
+    const int q = l >> 4, c = l & 15;
+    if (f < F_W2A) {
+        idx = (16 * (f - F_W1A) + c) * MLP_IN + 8 * q + jj;
+        return 1;
+    } else if (f < F_W3A) {
+        const int mt = (f - F_W2A) >> 1, s = (f - F_W2A) & 1;
+        idx = (16 * mt + c) * MLP_HID + phi_of(s, q, jj);
+        return 2;
+    } else if (f < F_W3T) {
+        const int s = f - F_W3A;
+        idx = c * MLP_HID + phi_of(s, q, jj);
+        return c < out_dim ? 3 : 0;
+    } else if (f < F_W2T) {
+        const int mt = f - F_W3T, n = 4 * q + jj;
+        idx = n * MLP_HID + 16 * mt + c;
+        return (jj < 4 && n < out_dim) ? 3 : 0;
+    } else if (f < F_W1T) {
+        const int mt = (f - F_W2T) >> 1, s = (f - F_W2T) & 1;
+        idx = phi_of(s, q, jj) * MLP_HID + 16 * mt + c;
+        return 2;
+    }
+    const int mt = (f - F_W1T) >> 1, s = (f - F_W1T) & 1;
+    idx = phi_of(s, q, jj) * MLP_IN + 16 * mt + c;
+    return 1;
+}
+
 // build weight fragments cooperatively (all threads of the workgroup)
 __device__ __forceinline__ void build_fragments(const MlpArgs &a, __bf16 *frag, int n_frag, int tid, int nthreads) {
     for (int e = tid; e < n_frag * 512; e += nthreads) {
-        const int f = e >> 9, l = (e >> 3) & 63, jj = e & 7;
-        const int q = l >> 4, c = l & 15;
-        float v = 0.f;
-        if (f < F_W2A) {
-            v = a.w1[(16 * (f - F_W1A) + c) * MLP_IN + 8 * q + jj];
-        } else if (f < F_W3A) {
-            const int mt = (f - F_W2A) >> 1, s = (f - F_W2A) & 1;
-            v = a.w2[(16 * mt + c) * MLP_HID + phi_of(s, q, jj)];
-        } else if (f < F_W3T) {
-            const int s = f - F_W3A;
-            v = c < a.out_dim ? a.w3[c * MLP_HID + phi_of(s, q, jj)] : 0.f;
-        } else if (f < F_W2T) {
-            const int mt = f - F_W3T, n = 4 * q + jj;
-            v = (jj < 4 && n < a.out_dim) ? a.w3[n * MLP_HID + 16 * mt + c] : 0.f;
-        } else if (f < F_W1T) {
-            const int mt = (f - F_W2T) >> 1, s = (f - F_W2T) & 1;
-            v = a.w2[phi_of(s, q, jj) * MLP_HID + 16 * mt + c];
-        } else {
-            const int mt = (f - F_W1T) >> 1, s = (f - F_W1T) & 1;
-            v = a.w1[phi_of(s, q, jj) * MLP_IN + 16 * mt + c];
-        }
+        int idx;
+        const int t = frag_source(e, a.out_dim, idx);
+        const float v = t == 1 ? a.w1[idx] : t == 2 ? a.w2[idx] : t == 3 ? a.w3[idx] : 0.f;
         frag[e] = (__bf16)v;
+    }
+}
+
+// Inverse of the layout: map_t[2 i] / map_t[2 i + 1] = the element of the fragment image that holds weight i of tensor
+// t in the forward / the transposed (backward) fragments -- every weight sits in exactly one of each.  With these the
+// optimiser's multi-tensor Adam launch writes the bf16 fragments itself (lnerf_adam_step_multi_shadow), and the
+// per-step fragment build (one dispatch) goes away.
+__global__ void __launch_bounds__(256) k_mlp_fragment_maps(int out_dim, int32_t *m1, int32_t *m2, int32_t *m3) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < F_ALL * 512; e += gridDim.x * 256) {
+        int idx;
+        const int t = frag_source(e, out_dim, idx);
+        const int slot = (e >> 9) < F_W3T ? 0 : 1;
+        int32_t *m = t == 1 ? m1 : t == 2 ? m2 : t == 3 ? m3 : nullptr;
+        if (m) m[2 * idx + slot] = e;
     }
 }
 
@@ -926,6 +953,18 @@ int mlp_stamps_read(unsigned long long *out32) {
     return LNERF_OK;
 }
 #endif
+
+int launch_mlp_fragment_maps(int out_dim, int32_t *m1, int32_t *m2, int32_t *m3, hipStream_t stream) {
+    if (hipMemsetAsync(m1, 0xFF, (size_t)MLP_HID * MLP_IN * 2 * sizeof(int32_t), stream) != hipSuccess ||
+        hipMemsetAsync(m2, 0xFF, (size_t)MLP_HID * MLP_HID * 2 * sizeof(int32_t), stream) != hipSuccess ||
+        hipMemsetAsync(m3, 0xFF, (size_t)out_dim * MLP_HID * 2 * sizeof(int32_t), stream) != hipSuccess) {
+        set_error("mlp_fragment_maps: hipMemsetAsync failed");
+        return LNERF_ERR_HIP;
+    }
+    hipLaunchKernelGGL(k_mlp_fragment_maps, dim3(16), dim3(256), 0, stream, out_dim, m1, m2, m3);
+    LNERF_CHECK_LAUNCH("mlp(fragment maps)");
+    return LNERF_OK;
+}
 
 int launch_mlp_fragments_bf16(const MlpArgs &a, void *frag_out, bool backward_too, hipStream_t stream) {
     const int n = backward_too ? F_SW : F_FWD;

@@ -36,6 +36,7 @@ __device__ __forceinline__ float blob_of(const MlpArgs &a, int64_t m) {
 
 // bf16 path launchers (mlp_bf16.hip)
 int launch_mlp_fragments_bf16(const MlpArgs &a, void *frag_out, bool backward_too, hipStream_t stream);
+int launch_mlp_fragment_maps(int out_dim, int32_t *m1, int32_t *m2, int32_t *m3, hipStream_t stream);
 int launch_mlp_forward_bf16(const MlpArgs &a, float *sigmas, float *rgbs, int blocks, int wps, hipStream_t stream);
 int launch_mlp_backward_bf16(const MlpArgs &a, const float *sigmas, const float *dsigmas, const float *drgbs,
                              float *dfeat, float *slabs, int blocks, int variant, hipStream_t stream);

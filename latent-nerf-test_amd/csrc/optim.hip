@@ -68,6 +68,8 @@ struct AdamMulti {
     float *p[ADAM_MULTI_MAX], *g[ADAM_MULTI_MAX], *m[ADAM_MULTI_MAX], *v[ADAM_MULTI_MAX];
     int64_t n[ADAM_MULTI_MAX];
     float lr[ADAM_MULTI_MAX];
+    const int32_t *map[ADAM_MULTI_MAX];  // optional per tensor: two positions per element in `shadow` (-1: none)
+    uint16_t *shadow;                    // bf16 image the mapped tensors are mirrored into (the MLP's weight fragments)
 };
 // tick: the last workgroup to finish advances the device step counter (every workgroup has read it by then) -- the
 // separate one-thread launch of lnerf_adam_tick costs a whole dispatch (~4 us in a replayed graph).  step_dev[1] is
@@ -88,12 +90,19 @@ __global__ void __launch_bounds__(256) k_adam_multi(AdamMulti t, AdamArgs a, int
     const int k = blockIdx.y;
     a.lr = t.lr[k];
     float *p = t.p[k], *g = t.g[k], *m = t.m[k], *v = t.v[k];
+    const int32_t *map = t.shadow ? t.map[k] : nullptr;
     const int64_t n = t.n[k];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float P = p[i], G = g[i], Mv = m[i], V = v[i];
         adam_one(P, G, Mv, V, a);
         p[i] = P; m[i] = Mv; v[i] = V;
         if (a.zero_grad) g[i] = G;
+        if (map) {   // uniform per workgroup
+            const int2 at = reinterpret_cast<const int2 *>(map)[i];
+            const uint16_t h = f32_to_bf16(P);
+            if (at.x >= 0) t.shadow[at.x] = h;
+            if (at.y >= 0) t.shadow[at.y] = h;
+        }
     }
 }
 
@@ -161,7 +170,17 @@ int lnerf_adam_step_multi(int count, float *const *p_host, float *const *g_host,
                           float *const *v_host, const int64_t *n_host, const float *lr_host, float beta1, float beta2,
                           float eps, int step, const int32_t *step_dev, float grad_scale, int zero_grad,
                           lnerf_stream_t stream) {
+    return lnerf_adam_step_multi_shadow(count, p_host, g_host, m_host, v_host, n_host, lr_host, beta1, beta2, eps, step,
+                                        step_dev, grad_scale, zero_grad, nullptr, nullptr, stream);
+}
+
+int lnerf_adam_step_multi_shadow(int count, float *const *p_host, float *const *g_host, float *const *m_host,
+                                 float *const *v_host, const int64_t *n_host, const float *lr_host, float beta1,
+                                 float beta2, float eps, int step, const int32_t *step_dev, float grad_scale,
+                                 int zero_grad, const int32_t *const *map_host, void *shadow_bf16,
+                                 lnerf_stream_t stream) {
     LNERF_REQUIRE(count >= 0 && count <= ADAM_MULTI_MAX, "adam_step_multi: count must be in [0,%d]", ADAM_MULTI_MAX);
+    LNERF_REQUIRE((map_host == nullptr) == (shadow_bf16 == nullptr), "adam_step_multi: maps and shadow go together");
     LNERF_REQUIRE(step_dev || step >= 1, "adam_step_multi: step must be >= 1 (got %d)", step);
     if (count == 0) return LNERF_OK;
     LNERF_REQUIRE(p_host && g_host && m_host && v_host && n_host && lr_host, "adam_step_multi: null array");
@@ -172,8 +191,11 @@ int lnerf_adam_step_multi(int count, float *const *p_host, float *const *g_host,
                       "adam_step_multi: bad tensor %d", k);
         t.p[k] = p_host[k]; t.g[k] = g_host[k]; t.m[k] = m_host[k]; t.v[k] = v_host[k];
         t.n[k] = n_host[k]; t.lr[k] = lr_host[k];
+        t.map[k] = map_host ? map_host[k] : nullptr;
+        LNERF_REQUIRE(!t.map[k] || ((uintptr_t)t.map[k] & 7) == 0, "adam_step_multi: map %d must be 8-byte aligned", k);
         nmax = n_host[k] > nmax ? n_host[k] : nmax;
     }
+    t.shadow = (uint16_t *)shadow_bf16;
     AdamArgs a;
     a.lr = 0.f; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
     a.bc1 = (float)(1.0 - pow((double)beta1, (double)(step < 1 ? 1 : step)));

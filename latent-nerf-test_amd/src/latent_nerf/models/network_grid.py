@@ -68,7 +68,7 @@ class _HashMLPField(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyzs, table, shadow, w1, b1, w2, b2, w3, b3, encoder, bound, m_host, m_dev, level_stride,
-                blob_scale, blob_std, precision, workspace):
+                blob_scale, blob_std, precision, workspace, frag_ready):
         from . import encoding as E
         levels = encoder.levels
         src = table if shadow is None else shadow
@@ -83,7 +83,8 @@ class _HashMLPField(torch.autograd.Function):
         _b.call("lnerf_mlp_forward", _p(feat), fdt, int(level_stride), _chk(xyzs, "xyzs"), _chk(w1, "w1"),
                 _chk(b1, "b1"), _chk(w2, "w2"), _chk(b2, "b2"), _chk(w3, "w3"), _chk(b3, "b3"), out_dim,
                 float(blob_scale), float(blob_std), int(m_host), _chk(m_dev, "m_dev", torch.int32, allow_none=True),
-                _p(sigmas), _p(rgbs), precision, _p(workspace), 0 if workspace is None else workspace.numel(), _stream())
+                _p(sigmas), _p(rgbs), precision | (_b.MLP_FRAGMENTS_READY if (frag_ready and precision == _b.BF16) else 0),
+                _p(workspace), 0 if workspace is None else workspace.numel(), _stream())
         ctx.save_for_backward(xyzs, feat, w1, b1, w2, b2, w3, b3, sigmas,
                               m_dev if m_dev is not None else torch.empty(0))
         ctx.meta = (encoder, bound, m_host, m_dev is not None, level_stride, blob_scale, blob_std, precision, workspace,
@@ -132,7 +133,7 @@ class _HashMLPField(torch.autograd.Function):
         else:
             dtable = torch.zeros(tshape, device=dev, dtype=torch.float32)
             E.grid_encode_backward(xyzs, bound, dfeat, encoder.levels, m_host, m_dev, level_stride, dtable, sv)
-        return (None, dtable, None, *grads, None, None, None, None, None, None, None, None, None)
+        return (None, dtable, None, *grads, None, None, None, None, None, None, None, None, None, None)
 
 
 class NeRFNetwork(NeRFRenderer):
@@ -172,19 +173,45 @@ class NeRFNetwork(NeRFRenderer):
                 nn.init.uniform_(w, -bound, bound)
                 nn.init.uniform_(b, -bound, bound)
         self._mlp_ws = None
+        # bf16 weight fragments at the head of the MLP workspace: which weights they were built from, in which buffer the
+        # full image (constants included) was last built, and the optimiser that keeps them current (FusedAdam(mlp=...))
+        self._frag_versions = None
+        self._frag_built_in = None
+        self._frag_owner = None
+
+    def mlp_workspace(self, device):
+        if self._mlp_ws is None or self._mlp_ws.device != device:
+            need = _b.get_lib().lnerf_mlp_backward_workspace_bytes(self.w3.shape[0])
+            self._mlp_ws = torch.empty(need, device=device, dtype=torch.uint8)
+            self._frag_built_in = None
+        return self._mlp_ws
+
+    def weight_versions(self):
+        return (self.w1._version, self.w2._version, self.w3._version,
+                self.w1.data_ptr(), self.w2.data_ptr(), self.w3.data_ptr())
+
+    def fragments_current(self):
+        """True when the weight fragments in the workspace equal the weights: only claimed under an optimiser that
+        mirrors its updates into them (a replayed hipGraph changes the weights without touching torch's version
+        counters; with the mirroring optimiser inside the graph the fragments move with them) and while nothing else
+        has modified the weights since (version counters: FusedAdam bumps them, torch's in-place ops do)."""
+        return (self.precision == "bf16" and self._frag_owner is not None and self._mlp_ws is not None
+                and self._frag_built_in == self._mlp_ws.data_ptr() and self._frag_versions == self.weight_versions())
 
     # ---- per-sample field -------------------------------------------------------------
     def field(self, xyzs, m_host, m_dev=None, level_stride=None):
         """xyzs [cap,3] -> sigmas [cap], latents [cap,C] for the first min(m_host, *m_dev) rows."""
         if level_stride is None:
             level_stride = xyzs.shape[0]
-        if self._mlp_ws is None or self._mlp_ws.device != xyzs.device:
-            need = _b.get_lib().lnerf_mlp_backward_workspace_bytes(self.w3.shape[0])
-            self._mlp_ws = torch.empty(need, device=xyzs.device, dtype=torch.uint8)
+        ws = self.mlp_workspace(xyzs.device)
         enc = self.encoder
+        ready = self.fragments_current()
         sigmas, rgbs = _HashMLPField.apply(xyzs, enc.embeddings, enc.shadow(), self.w1, self.b1, self.w2, self.b2,
                                            self.w3, self.b3, enc, self.bound, m_host, m_dev, level_stride,
-                                           self.blob_scale, self.blob_std, _PREC[self.precision], self._mlp_ws)
+                                           self.blob_scale, self.blob_std, _PREC[self.precision], ws, ready)
+        if not ready and self.precision == "bf16" and int(m_host) > 0:   # that forward built the whole image
+            self._frag_built_in = ws.data_ptr()
+            self._frag_versions = self.weight_versions()
         if not self.latent_mode:
             rgbs = torch.sigmoid(rgbs)
         return sigmas, rgbs

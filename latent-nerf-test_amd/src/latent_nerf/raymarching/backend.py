@@ -89,6 +89,8 @@ _SIGNATURES = {
     "lnerf_adam_step": [_P, _P, _I, _P, _P, _P, _L, _F, _F, _F, _F, _I, _P, _F, _I, _P],
     "lnerf_adam_tick": [_P, _P],
     "lnerf_adam_step_multi": [_I, _P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _F, _I, _P],
+    "lnerf_adam_step_multi_shadow": [_I, _P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _F, _I, _P, _P, _P],
+    "lnerf_mlp_fragment_maps": [_I, _P, _P, _P, _P],
     "lnerf_cast_f32_to_bf16": [_P, _P, _L, _P],
 }
 _RESTYPES = {

@@ -13,13 +13,16 @@ from ..raymarching.raymarching import _p, _stream
 
 class FusedAdam:
     def __init__(self, param_groups, betas=(0.9, 0.99), eps=1e-15, encoder=None, capturable=False,
-                 fuse_table_update=False):
+                 fuse_table_update=False, mlp=None):
         """param_groups: [{'params': [...], 'lr': float}, ...] (as NeRFNetwork.get_params(lr)).
         encoder: the GridEncoder whose `embeddings` are in the groups (for the bf16 shadow refresh).
         fuse_table_update: the hash table's Adam step can be applied by the scatter of the backward pass
         (lnerf_grid_encode_backward_adam) instead of by step(): call arm() right before the step's backward
         (single process, ONE backward per step; set the `grad_scale` attribute first if it is not 1).  A step
-        whose backward was not armed takes the ordinary path."""
+        whose backward was not armed takes the ordinary path.
+        mlp: the NeRFNetwork whose w1 / w2 / w3 are in the groups (bf16 MLP): the multi-tensor launch then also writes
+        the updated weights into the network's bf16 weight fragments (lnerf_adam_step_multi_shadow), and the network's
+        forward stops rebuilding them every step (one dispatch less)."""
         self.betas, self.eps = betas, eps
         self.encoder = encoder
         self.step_no = 0
@@ -44,6 +47,26 @@ class FusedAdam:
         self._vp = (ctypes.c_void_p * n)(*[e[2].data_ptr() for e in self.small])
         self._n = (ctypes.c_int64 * n)(*[e[0].numel() for e in self.small])
         self._lr = (ctypes.c_float * n)(*[e[3] for e in self.small])
+        self.mlp, self._maps, self._map_tensors = None, None, None
+        if mlp is not None and getattr(mlp, "precision", None) == "bf16" and self.small:
+            dev0 = self.small[0][0].device
+            tensors = {}
+            for name in ("w1", "w2", "w3"):
+                w = getattr(mlp, name)
+                tensors[name] = torch.empty(w.numel() * 2, device=dev0, dtype=torch.int32)
+            _b.call("lnerf_mlp_fragment_maps", int(mlp.w3.shape[0]), _p(tensors["w1"]), _p(tensors["w2"]),
+                    _p(tensors["w3"]), _stream())
+            maps = (ctypes.c_void_p * n)()
+            found = 0
+            for k, (p, *_r) in enumerate(self.small):
+                for name in ("w1", "w2", "w3"):
+                    if p is getattr(mlp, name):
+                        maps[k] = tensors[name].data_ptr()
+                        found += 1
+            if found != 3:
+                raise ValueError("FusedAdam(mlp=...): w1, w2, w3 of the network must be among the small parameters")
+            self.mlp, self._maps, self._map_tensors = mlp, maps, tensors
+            mlp._frag_owner = self
         if capturable:
             dev = (self.big + self.small)[0][0].device
             self.step_dev = torch.tensor([1, 0], device=dev, dtype=torch.int32)  # [0]: value used by the NEXT step; [1]: arrival counter of the ticking launch
@@ -116,11 +139,21 @@ class FusedAdam:
                 self._pp[k] = p.data.data_ptr()
                 self._gp[k] = g.data_ptr()
             # (with the device counter this launch, the step's last Adam launch, also advances it: LNERF_ADAM_TICK = 2)
-            _b.call("lnerf_adam_step_multi", len(self.small), self._pp, self._gp, self._mp, self._vp, self._n, self._lr,
-                    b1, b2, self.eps, self.step_no, _p(self.step_dev), float(grad_scale),
-                    2 if self.step_dev is not None else 0, _stream())
+            frag = None if self.mlp is None else self.mlp.mlp_workspace(self.small[0][0].device)
+            _b.call("lnerf_adam_step_multi_shadow", len(self.small), self._pp, self._gp, self._mp, self._vp, self._n,
+                    self._lr, b1, b2, self.eps, self.step_no, _p(self.step_dev), float(grad_scale),
+                    2 if self.step_dev is not None else 0, None if frag is None else self._maps,
+                    None if frag is None else _p(frag), _stream())
         elif self.step_dev is not None:
             _b.call("lnerf_adam_tick", _p(self.step_dev), _stream())
+        # the multi-tensor launch wrote through raw pointers: tell torch, so that anything that cached a function of a
+        # small parameter (the network's weight fragments) sees the change; the mirrored fragments are current for
+        # exactly these versions.  (The table keeps its own bf16 shadow in step with the same Adam pass: its version
+        # counter is what GridEncoder.shadow() compares, and stays.)
+        for p, *_ in self.small:
+            torch.autograd.graph.increment_version(p)
+        if self.mlp is not None:
+            self.mlp._frag_versions = self.mlp.weight_versions()
         if set_to_none:
             for p, *_ in self.big + self.small:
                 p.grad = None

@@ -63,7 +63,7 @@ class Trainer:
         n_views = len(D.views_for_rank(max(cfg.optim.views_per_step, self.world), self.rank, self.world))
         fuse = bool(cfg.optim.fuse_table_update) and self.world == 1 and n_views == 1
         self.optimizer = FusedAdam(self.nerf.get_params(cfg.optim.lr), betas=(0.9, 0.99), eps=1e-15,
-                                   encoder=self.nerf.encoder, fuse_table_update=fuse)
+                                   encoder=self.nerf.encoder, fuse_table_update=fuse, mlp=self.nerf)
         small = [p for p in self.nerf.parameters() if p is not self.nerf.encoder.embeddings]
         # exchange: bf16 on the wire with the bf16 configuration (f32 otherwise); with one view per rank and step the
         # backward pass writes the wire buffer itself and the table travels in level groups (pipelined with the sums)

@@ -577,3 +577,40 @@ def test_sample_budget_follows_the_observed_march(dev):
     assert int(c[0]) <= cfg.max_samples and int(c[2]) > 0 and out["xyzs"].shape[0] == cfg.max_samples
     out["image"].sum().backward()
     assert bool(torch.isfinite(net.encoder.embeddings.grad).all())
+
+
+@pytest.mark.gpu
+def test_optimizer_keeps_the_mlp_weight_fragments_current(dev):
+    """FusedAdam(mlp=net) mirrors the updated w1 / w2 / w3 into the network's bf16 weight fragments, and the forward
+    then skips its per-step fragment build: the field must be bit-identical to a forward that rebuilds them, before
+    and after optimiser steps, and any other modification of a weight must bring the build back."""
+    from src.latent_nerf.training.optimizer import FusedAdam
+    net, *_ = _make(dev, 32, 16, 14, 16, seed=5, mlp_precision="bf16", table_dtype="bf16")
+    opt = FusedAdam(net.get_params(1e-2), encoder=net.encoder, mlp=net)
+    assert net._frag_owner is opt and not net.fragments_current()
+    x = (torch.rand(5000, 3, device=dev) * 2 - 1) * 0.9
+
+    def both():
+        kept = net.fragments_current()
+        with torch.no_grad():
+            a = [t.clone() for t in net.field(x, x.shape[0])]
+            net._frag_versions = None                    # force the build
+            b = [t.clone() for t in net.field(x, x.shape[0])]
+        return kept, a, b
+
+    kept, a, b = both()                                  # first forward ever: builds either way
+    assert not kept and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for it in range(3):
+        sig, lat = net.field(x, x.shape[0])
+        (sig.mean() + lat.square().mean()).backward()
+        w_before = net.w2.detach().clone()
+        opt.step()
+        assert not torch.equal(net.w2.detach(), w_before)
+        kept, a, b = both()
+        assert kept, "the optimiser's mirror must leave the fragments current"
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    with torch.no_grad():
+        net.w1.mul_(1.5)                                 # somebody else's in-place change
+    assert not net.fragments_current()
+    kept, a, b = both()
+    assert not kept and torch.equal(a[0], b[0])
