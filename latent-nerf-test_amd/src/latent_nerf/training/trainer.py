@@ -179,6 +179,11 @@ class Trainer:
                 self.evaluate(self.dataloaders["val"], self.eval_renders_path)
                 self.nerf.train()
         self.log("finished training at step %d" % self.train_step)
+        # the reference's trainers close with the full evaluation pass of the last model
+        # (src/latent_paint/training/trainer.py:141-144)
+        self.log("evaluating the last model...")
+        self.full_eval()
+        self.nerf.train()
 
     # ------------------------------------------------------------------ evaluation
     @torch.no_grad()

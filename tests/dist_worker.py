@@ -25,7 +25,8 @@ def main():
     cfg = apply_overrides(TrainConfig(), {
         "log.exp_name": "dp", "log.exp_root": os.path.join(out_dir, "exp"), "render.train_h": 32, "render.train_w": 32,
         "render.eval_h": 32, "render.eval_w": 32, "render.grid_size": 64, "optim.iters": steps, "optim.lr": 5e-3,
-        "log.save_interval": 10000, "log.eval_size": 1, "optim.fp16": precision == "bf16", "guide.text": "a lego man",
+        "log.save_interval": 10000, "log.eval_size": 1, "log.full_eval_size": 2, "optim.fp16": precision == "bf16",
+        "guide.text": "a lego man",
         "optim.views_per_step": world, "optim.exchange_groups": groups})
     tr = Trainer(cfg, device=dev)
     table0 = tr.nerf.encoder.embeddings.detach().clone()

@@ -20,7 +20,8 @@ def _cfg(tmp_path, **over):
     from src.latent_nerf.configs.train_config import TrainConfig, apply_overrides
     flat = {"log.exp_name": "t", "log.exp_root": str(tmp_path), "render.train_h": 32, "render.train_w": 32,
             "render.eval_h": 32, "render.eval_w": 32, "render.grid_size": 64, "optim.iters": 60, "optim.lr": 5e-3,
-            "log.save_interval": 30, "log.eval_size": 2, "optim.fp16": False, "guide.text": "a lego man"}
+            "log.save_interval": 30, "log.eval_size": 2, "log.full_eval_size": 3, "optim.fp16": False,
+            "guide.text": "a lego man"}
     flat.update(over)
     return apply_overrides(TrainConfig(), flat)
 
