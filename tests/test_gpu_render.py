@@ -614,3 +614,43 @@ def test_optimizer_keeps_the_mlp_weight_fragments_current(dev):
     assert not net.fragments_current()
     kept, a, b = both()
     assert not kept and torch.equal(a[0], b[0])
+
+
+@pytest.mark.gpu
+def test_fragment_mirror_inside_a_replayed_graph(dev):
+    """The mirroring optimiser captured in a hipGraph: replays move the weights AND their fragments (torch's version
+    counters see nothing of it), so a later eager forward that skips the build must still equal one that rebuilds."""
+    from src.latent_nerf.training.graph_step import GraphedTrainStep
+    from src.latent_nerf.training.optimizer import FusedAdam
+    G, HW = 64, 32
+    net, *_ = _make(dev, G, HW, 14, 16, seed=6, mlp_precision="bf16", table_dtype="bf16")
+    net.train()
+    ro, rd = _rays(HW, 65.0, 10.0, 1.3)
+    ro, rd = ro.to(dev), rd.to(dev)
+    bg = torch.rand(HW * HW, 4, device=dev)
+    g = torch.randn(1, HW * HW, 4, device=dev) * 0.3
+    plist = list(net.parameters())
+    x = (torch.rand(4000, 3, device=dev) * 2 - 1) * 0.9
+
+    def fwd_bwd():
+        out = net.render(ro, rd, bg_color=bg, perturb=False)
+        out["image"].backward(gradient=g)
+        return out
+
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        opt = FusedAdam(net.get_params(1e-2), encoder=net.encoder, capturable=True, mlp=net)
+        gs = GraphedTrainStep(fwd_bwd, lambda: opt.step(), plist, world=1, warmup=2, stream=stream)
+        w0 = net.w2.detach().clone()
+        for _ in range(4):
+            gs()
+        stream.synchronize()
+        assert float((net.w2.detach() - w0).abs().max()) > 0 and net.fragments_current()
+        with torch.no_grad():
+            a = [t.clone() for t in net.field(x, x.shape[0])]      # skips the build
+            net._frag_versions = None
+            b = [t.clone() for t in net.field(x, x.shape[0])]      # rebuilds
+        stream.synchronize()
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    torch.cuda.synchronize()
