@@ -19,10 +19,14 @@ algorithmic bytes (1164 B/sample f32 table, 588 B/sample bf16)
 kernel's duration measured with HIP events inside the timed steps; `roofline.traffic` and `mfma.busy_frac` come
 from the committed rocprofv3 --pmc passes (profiles/pmc_latest.json) and are null unless that file was collected on
 THIS build of the library (build tags compared).  `mfma` prices the MLP kernels (the only MFMA users) against the
-dense bf16 peak from their live HIP-event times.  `occ_refresh` times the amortised occupancy-grid refresh (H10) that
-the trainer runs every 16 steps (outside the step, after the timed region, state restored).  `f32` is the same step
-with the exact-f32 parity configuration.  `cpu_baseline` is the oracle (oracle/nerf_oracle.py, pure PyTorch fp32)
-doing the same step on the host cores.
+dense bf16 peak from their live HIP-event times.  The occupancy-grid refresh (H10, `update_extra_state()`) runs INSIDE
+the timed region at the trainer's cadence (every `update_extra_interval` = 16 steps, eager launches between replays)
+and is part of `value`; it writes a shadow copy of the occupancy state so that the analytic scene of the workload
+stays pinned (`refresh` on the line says so and carries the refresh-free rate of the same run).  A run shorter than
+100 steps times 5 regions of --steps steps each and reports the median region (`repeats`).  `trainer` is the product
+entry point -- `Trainer.train()` with the seeded synthetic guidance, captured step, refreshes included -- on the same
+configuration.  `f32` is the same step with the exact-f32 parity configuration.  `cpu_baseline` is the oracle
+(oracle/nerf_oracle.py, pure PyTorch fp32) doing the same step on the host cores: the only use of `oracle/` here.
 """
 import argparse
 import json
@@ -95,6 +99,15 @@ def parse():
                     help="1: the optimiser mirrors the MLP weights into their bf16 fragments (no per-step fragment build)")
     ap.add_argument("--tune", default="", help="lnerf_set_tuning overrides for an experiment: key=value,key=value "
                     "(recorded in the output line; the default run sets none)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N > 1 step at N = 1: process group (RCCL, communicator of one rank) initialised before any "
+                         "GPU call, bf16 gradient sink, pipelined per-group all-reduce, row-group Adam, graph A + eager "
+                         "exchange -- the un-fused path the driver's 8-GPU run takes, measured on one card")
+    ap.add_argument("--refresh", type=int, default=1,
+                    help="1: the occupancy refresh runs inside the timed region every update_extra_interval steps (shadow "
+                         "state: the analytic scene stays pinned); 0: the refresh-free step only")
+    ap.add_argument("--repeats", type=int, default=0, help="timed regions of --steps steps each (0 = auto: 5 below 100 steps, else 1); the median region is reported")
+    ap.add_argument("--trainer-steps", type=int, default=200, help="steps of the `trainer` companion (0 = skip)")
     ap.add_argument("--exchange-groups", type=int, default=4,
                     help="N > 1, bf16 on the wire: level groups the table gradient is exchanged in, each group's all-reduce "
                          "launched behind its own sums (0 = one collective after the whole scatter)")
@@ -102,7 +115,6 @@ def parse():
 
 
 def build(dev, precision, variant, rank, table="f32", jitter_rng="kernel"):
-    from oracle import nerf_oracle as O  # scene construction only (analytic occupancy), not measured
     from src.latent_nerf.configs.render_config import RenderConfig
     from src.latent_nerf.models.network_grid import NeRFNetwork
     from src.latent_nerf.models.nerf_utils import intrinsics_from_fov, pose_from_angles
@@ -114,15 +126,19 @@ def build(dev, precision, variant, rank, table="f32", jitter_rng="kernel"):
     net = NeRFNetwork(cfg)
     net.encoder.embeddings.data.normal_(0, 0.1)
     net = net.to(dev).train()
-    grid = O.sphere_density_grid(G=GRID, radius=0.5)
-    net.density_grid.copy_(grid.to(dev))
-    net.density_bitfield.copy_(O.packbits(grid.reshape(-1), 0.01).to(dev))
+    sphere_scene(net)
     pose = pose_from_angles(math.radians(60.0), math.radians(45.0 * rank), 1.25)[None].to(dev)
     intr = intrinsics_from_fov(FOVY, H, W)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     bg = torch.rand(H * W, 4, generator=g).to(dev)
     grad = (torch.randn(1, H * W, 4, generator=g) * math.sqrt(0.5) * 0.5).to(dev)
     return net, pose, intr, bg, grad
+
+
+def sphere_scene(net):
+    """SURVEY.md section 8(d) synthetic occupancy: density 10 inside |x| < 0.5, 0 outside, packed at threshold 0.01
+    (product helper: NeRFRenderer.seed_density_grid evaluates the function at the cell centres on the device)."""
+    net.seed_density_grid(lambda x: (x.norm(dim=-1) < 0.5).float() * 10.0, thresh=0.01)
 
 
 def make_step(net, pose, intr, bg, grad, opt, world, transport=torch.float32, perturb=True, exchange_groups=0,
@@ -177,14 +193,14 @@ def make_step(net, pose, intr, bg, grad, opt, world, transport=torch.float32, pe
             state["ex"] = sync.allreduce_pipelined()
             state["ex"].finish_small()
         else:
-            sync.allreduce(copy_back=False)  # no-op at world size 1; bf16 sums stay in the wire buffer
+            sync.allreduce(copy_back=False)  # no-op without an exchange; bf16 sums stay in the wire buffer
 
     def opt_step():
         if pipelined:   # the optimiser waits for a level group's all-reduce right before it steps those rows
             opt.step(grad_scale=1.0 / world, grads=sync.reduced(),
                      row_groups={net.encoder.embeddings: state.pop("ex").table_groups})
         else:
-            opt.step(grad_scale=1.0 / world, grads=sync.reduced() if world > 1 else None)
+            opt.step(grad_scale=1.0 / world, grads=sync.reduced() if sync.active else None)
 
     def step():
         out = fwd_bwd(False) if prefetch else fwd_bwd()
@@ -302,27 +318,6 @@ def load_pmc(build_tag):
     return d
 
 
-def time_occ_refresh(net, rounds=4):
-    """One steady-state occupancy refresh (`update_extra_state()`: G^3/4 random + G^3/4 occupied cells through the
-    gather + MLP, decayed max, mean, bitfield) timed with HIP events; grid, bitfield and counters are restored."""
-    keep = (net.density_grid.clone(), net.density_bitfield.clone(), net.mean_density_dev.clone(), net.iter_density)
-    net.iter_density = 16            # past the 16 full-grid refreshes of a fresh model: the steady-state form
-    budget = net._budget
-    ts = []
-    for i in range(rounds + 1):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        net.update_extra_state()
-        b.record()
-        torch.cuda.synchronize()
-        if i:
-            ts.append(a.elapsed_time(b))
-        net.density_grid.copy_(keep[0]); net.density_bitfield.copy_(keep[1]); net.mean_density_dev.copy_(keep[2])
-    net.iter_density = keep[3]
-    net._budget = budget
-    return sorted(ts)[len(ts) // 2]
-
-
 def companion_f32(dev, rank, steps=40, warmup=6):
     """The exact-f32 parity configuration (f32 table, f32 features, exact-f32 MFMA MLP, 12-byte scatter records) through
     the same captured step: frames/s beside the headline (bf16) number."""
@@ -348,6 +343,51 @@ def companion_f32(dev, rank, steps=40, warmup=6):
                     "configuration the fp32-tolerance parity tests run"}
 
 
+def trainer_companion(dev, steps, precision):
+    """The product entry point on the bench configuration: `Trainer(cfg).train()` (scripts/train_latent_nerf.py) with
+    the seeded synthetic guidance, 64x64x4 / 128^3, bf16, one view per step -- captured step (graph F: render / eager
+    guidance / graph B: backward + optimiser), a new random pose and field of view every step, an occupancy refresh
+    every 16 steps, sparsity term on.  Same scene and learning rate as the headline (analytic sphere, lr 1e-7: the field
+    stays at its random-init state).  Whole-loop wall clock, evaluation excluded."""
+    import shutil
+    import tempfile
+    from src.latent_nerf.configs.train_config import TrainConfig, apply_overrides
+    from src.latent_nerf.training.trainer import Trainer
+    root = tempfile.mkdtemp(prefix="lnerf_bench_trainer_")
+    try:
+        warm = 40   # eager steps, captures and the first budget-driven re-capture happen here
+        cfg = apply_overrides(TrainConfig(), {
+            "log.exp_name": "bench", "log.exp_root": root, "render.train_h": H, "render.train_w": W,
+            "render.grid_size": GRID, "render.eval_h": 8, "render.eval_w": 8, "log.eval_size": 1, "log.full_eval_size": 1,
+            "log.save_interval": 10 ** 9, "optim.lr": LR, "optim.fp16": precision == "bf16", "guide.text": "bench",
+            "optim.iters": warm})
+        tr = Trainer(cfg, device=dev)
+        sphere_scene(tr.nerf)
+        tr.nerf.iter_density = 16          # steady-state refreshes (G^3/4 random + G^3/4 occupied cells)
+        tr.full_eval = lambda: None        # the loop only
+        tr.train()
+        torch.cuda.synchronize()
+        c0 = dict(tr.graph_stats)
+        t0 = time.perf_counter()
+        tr.train(iters=warm + steps)
+        host = time.perf_counter() - t0    # (train() returns with its stream's work enqueued, not finished)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        M = int(tr.nerf._march.counter[0].item())
+        iv = cfg.render.update_extra_interval
+        return {"value": steps / dt, "unit": "steps/sec (= latent-frames/sec at 1 view per step)", "steps": steps,
+                "ms_per_step": 1e3 * dt / steps, "host_ms_per_step": 1e3 * host / steps,
+                "refreshes_in_region": len([k for k in range(warm + 1, warm + steps + 1) if (k - 1) % iv == 0]),
+                "replayed_steps": tr.graph_stats["replayed_steps"] - c0["replayed_steps"],
+                "eager_steps": tr.graph_stats["eager_steps"] - c0["eager_steps"],
+                "captures_total": tr.graph_stats["captures"], "samples_per_view_last": M,
+                "sample_capacity": tr.nerf._march.capacity,
+                "what": "Trainer.train() (src/latent_nerf/training/trainer.py), SyntheticGuidance, random poses / fov, "
+                        "sparsity term, occupancy refresh every %d steps, sample budget from observed marches" % iv}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -364,8 +404,14 @@ def main():
     local_dev = local if backend == "nccl" else local % max(ndev, 1)
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    if world > 1:
+    if args.force_dist:
+        os.environ["LNERF_FORCE_DIST"] = "1"   # (GradSync / Trainer read it: exchange at any world size)
+    dist_on = world > 1 or args.force_dist     # gradients are exchanged (collectives run; the table update is not fused)
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -384,40 +430,57 @@ def main():
     table = args.precision if args.table == "auto" else args.table
     net, pose, intr, bg, grad = build(dev, args.precision, args.gather_variant, rank, table, args.jitter_rng)
     from src.latent_nerf.training.optimizer import FusedAdam
-    fuse = (world == 1) if args.fuse_table_update == "auto" else (args.fuse_table_update == "1")
-    if fuse and world > 1:
-        raise SystemExit("--fuse-table-update 1 needs --gpus 1 (the gradient all-reduce sits between backward and Adam)")
+    fuse = (not dist_on) if args.fuse_table_update == "auto" else (args.fuse_table_update == "1")
+    if fuse and dist_on:
+        raise SystemExit("--fuse-table-update 1 needs one rank without --force-dist (the gradient all-reduce sits between "
+                         "backward and Adam)")
     opt = FusedAdam(net.get_params(LR if args.lr is None else args.lr), betas=(0.9, 0.99), eps=1e-15, encoder=net.encoder, capturable=True,
                     fuse_table_update=fuse, mlp=net if args.fragment_shadow else None)
     opt.grad_scale = 1.0 / world
     tr = args.precision if args.grad_transport == "auto" else args.grad_transport
-    groups = args.exchange_groups if (world > 1 and tr == "bf16") else 0
+    groups = args.exchange_groups if (dist_on and tr == "bf16") else 0
     scatter_call = ("lnerf_grid_encode_backward_adam" if fuse else
                     "lnerf_grid_scatter_bin" if groups else
-                    "lnerf_grid_encode_backward_bf16" if (world > 1 and tr == "bf16") else "lnerf_grid_encode_backward")
+                    "lnerf_grid_encode_backward_bf16" if (dist_on and tr == "bf16") else "lnerf_grid_encode_backward")
     prefetch = bool(args.prefetch_rays)
-    if prefetch and world > 1:
-        raise SystemExit("--prefetch-rays 1 needs --gpus 1")
+    if prefetch and dist_on:
+        raise SystemExit("--prefetch-rays 1 needs one rank without --force-dist")
     step, fwd_bwd, opt_step, sync = make_step(net, pose, intr, bg, grad, opt, world,
                                               torch.bfloat16 if tr == "bf16" else torch.float32, bool(args.perturb), groups,
                                               prefetch)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
-    log("model built on %s (rank %d/%d)" % (dev, rank, world))
+    log("model built on %s (rank %d/%d%s)" % (dev, rank, world, ", forced exchange" if args.force_dist else ""))
     launch = "eager"
     gstep = None
     if args.graph:
         from src.latent_nerf.training.graph_step import GraphedTrainStep
         # (a capture failure raises: the line must not silently describe eager launches; use --graph 0 for those)
-        gstep = GraphedTrainStep(fwd_bwd, opt_step, list(net.parameters()), sync=sync, world=world, warmup=3,
+        gstep = GraphedTrainStep(fwd_bwd, opt_step, list(net.parameters()), sync=sync, world=2 if dist_on else 1, warmup=3,
                                  stream=main_stream, opt_in_graph=not groups, steps_per_graph=2 if prefetch else 1)
         launch = "hipgraph"
     emb0 = net.encoder.embeddings.detach().clone()
     spg = gstep.steps_per_call if gstep is not None else 1
+    # occupancy refresh (H10) at the trainer's cadence, inside the timed region: update_extra_state() in its
+    # steady-state form, eager launches between replays, on a SHADOW copy of the occupancy state (the analytic scene
+    # the workload is defined on stays what the march reads; the refresh does all of its work)
+    iv = int(net.cfg.update_extra_interval)
+    do_refresh = bool(args.refresh) and net.cuda_ray
+    net.iter_density = max(net.iter_density, 16)
+    refresh_events = []
+
+    def refresh():
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        with net.shadow_extra_state():
+            net.update_extra_state()
+        b.record()
+        refresh_events.append((a, b))
+
     i = 0
     while i < args.warmup:   # eager and replayed steps alternate; never more than --warmup steps
         if gstep is not None and (i // spg) % 2 and i + spg <= args.warmup:
@@ -426,43 +489,66 @@ def main():
         else:
             step()
             i += 1
+    if do_refresh:
+        refresh()
+        refresh_events.clear()
     torch.cuda.synchronize()
     log("warm-up done (%s)" % launch)
     timer = KernelTimer(["lnerf_grid_encode_forward", scatter_call, "lnerf_mlp_forward", "lnerf_mlp_backward",
                          "lnerf_grid_scatter_reduce_bf16"])
-    barrier()
-    t0 = time.perf_counter()
-    n_probe = 0
-    # eager probe steps: every --probe-every-th step; a run shorter than that still gets one (its last step), so that
-    # the roofline object can always be measured live, whatever --steps the caller picks
     pe = max(1, args.probe_every)
-    i, since = 0, 0   # steps done; steps since the last probe
-    while i < args.steps:   # EXACTLY --steps steps: a replay is `spg` of them
-        left = args.steps - i
-        if gstep is None or since >= pe - 1 or (n_probe == 0 and left == 1):
-            B.set_profile_hook(timer.hook)   # eager step: the gather is bracketed by HIP events on its stream
-            out = step()
-            B.set_profile_hook(None)
-            n_probe += 1
-            i, since = i + 1, 0
-        elif left < spg or (n_probe == 0 and left <= spg):
-            out = step()                     # a remainder shorter than one replay
-            i, since = i + 1, since + 1
-        else:
-            out = gstep()
-            i, since = i + spg, since + spg
-    host_enqueue = time.perf_counter() - t0   # host time to enqueue the steps (GPU runs behind)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    state = {"done": 0, "n_probe": 0}   # steps done over all regions (the refresh cadence runs across regions)
+
+    def region(steps):
+        """EXACTLY `steps` steps between barrier + synchronize on both sides.  Returns (elapsed, host enqueue time,
+        last output, refreshes)."""
+        barrier()
+        t0 = time.perf_counter()
+        n_probe0, n_ref = state["n_probe"], 0
+        # eager probe steps: every --probe-every-th step; a run shorter than that still gets one (its last step), so that
+        # the roofline object can always be measured live, whatever --steps the caller picks
+        i, since, out = 0, 0, None   # steps done in this region; steps since the last probe
+        while i < steps:
+            if do_refresh and state["done"] % iv == 0:
+                refresh()
+                n_ref += 1
+            left = steps - i
+            probed = state["n_probe"] > n_probe0
+            # (a replay of `spg` steps must not jump over a refresh point)
+            room = iv - state["done"] % iv if do_refresh else left
+            if gstep is None or since >= pe - 1 or (not probed and left == 1):
+                B.set_profile_hook(timer.hook)   # eager step: the gather is bracketed by HIP events on its stream
+                out = step()
+                B.set_profile_hook(None)
+                state["n_probe"] += 1
+                n, since = 1, 0
+            elif left < spg or room < spg or (not probed and left <= spg):
+                out = step()                     # a remainder shorter than one replay
+                n, since = 1, since + 1
+            else:
+                out = gstep()
+                n, since = spg, since + spg
+            i += n
+            state["done"] += n
+        host_enqueue = time.perf_counter() - t0   # host time to enqueue the steps (GPU runs behind)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        if dist_on:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), host_enqueue, out, n_ref
+
+    repeats = args.repeats if args.repeats > 0 else (5 if args.steps < 100 else 1)
+    regions = [region(args.steps) for _ in range(repeats)]
+    order = sorted(range(repeats), key=lambda k: regions[k][0])
+    elapsed, host_enqueue, out, n_ref = regions[order[repeats // 2]]     # the median region
+    n_probe = state["n_probe"]
     M = int(out["counter"][0].item())
     if int(out["counter"][2].item()) != 0:
         raise SystemExit("bench: %d rays did not fit the sample capacity %d" % (int(out["counter"][2].item()), BENCH_CAPACITY))
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
     if rank == 0:
-        log("timed region: %.3f s for %d steps" % (elapsed, args.steps))
+        log("timed region: %.4f s for %d steps (median of %d: %s)" % (elapsed, args.steps, repeats,
+                                                                   ", ".join("%.4f" % r[0] for r in regions)))
     # outside the timed region: the run must have trained, not diverged (fail loudly rather than report a number)
     emb = net.encoder.embeddings.detach()
     if not bool(torch.isfinite(emb).all()) or not all(bool(torch.isfinite(p.detach()).all()) for p in net.parameters()):
@@ -494,7 +580,7 @@ def main():
         breakdown = {n.replace("lnerf_", ""): round(bt.mean_ms(n) * (len(bt.pairs[n]) / 20.0), 4) for n in names}
 
     if rank == 0:
-        # algorithmic bytes per sample of the gather (SURVEY.md §8(d)): 16 levels x 8 vertices x 2 features x
+        # algorithmic bytes per sample of the gather (SURVEY.md section 8(d)): 16 levels x 8 vertices x 2 features x
         # sizeof(table entry) gathered + 12 B position + 16 x 2 x sizeof(feature) written
         bytes_per_sample = 16 * 8 * 2 * (2 if table == "bf16" else 4) + 12 + 32 * (2 if args.precision == "bf16" else 4)
         if n_probe == 0:
@@ -522,6 +608,10 @@ def main():
         mfma["frac_of_peak"] = {"fwd": mfma["fwd_tflops"] / peak, "bwd": mfma["bwd_tflops"] / peak}
         if pmc and args.precision == "bf16":   # SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), per kernel
             mfma["busy_frac"] = {k: pmc.get("mfma", {}).get(k, {}).get("busy_frac") for k in ("fwd", "bwd")}
+        # refresh share of the median region (HIP events around each refresh; the GPU is backlogged, so the events see
+        # GPU time): the refresh-free rate of the SAME run
+        ref_ms = sorted(a.elapsed_time(b) for a, b in refresh_events)
+        ref_med = ref_ms[len(ref_ms) // 2] if ref_ms else None
         res = {
             "metric": "latent-frames/sec (64x64x4, 128^3 grid), render forward+backward",
             "value": world * args.steps / elapsed,
@@ -529,9 +619,19 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "repeats": repeats,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "region_ms_per_step": [round(1e3 * r[0] / args.steps, 5) for r in regions],
             "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
             "launch": launch, "eager_probe_steps": n_probe,
+            "refresh": ({"in_timed_region": True, "every_steps": iv, "refreshes_in_region": n_ref,
+                         "ms_per_refresh": ref_med, "ms_per_step_amortised": (ref_med / iv) if ref_med else None,
+                         "value_without_refresh": (world * args.steps / (elapsed - 1e-3 * ref_med * n_ref))
+                         if ref_med else None,
+                         "what": "NeRFRenderer.update_extra_state() (H10), steady-state form, every %d steps between "
+                                 "replays, INCLUDED in `value`; it writes a shadow copy of the occupancy state, so the "
+                                 "analytic scene of the workload stays pinned" % iv}
+                        if do_refresh else {"in_timed_region": False}),
             "ray_prefetch": ("rays + occupancy march of step k+1 on a side stream during step k "
                              "(NeRFRenderer.prepare_rays, two buffer sets, two steps per captured graph)") if prefetch else None,
             "mlp_fragment_shadow": bool(opt.mlp is not None),
@@ -541,11 +641,14 @@ def main():
             "dtype": args.precision,
             "data": "synthetic",
             "config": {"workload": "configs[1]: unconstrained latent-NeRF 64x64x4, 128^3 occupancy grid, hash grid "
-                                   "L=16 F=2 T=2^19, 1 view/GPU/step, fwd+bwd+grad all-reduce+Adam",
+                                   "L=16 F=2 T=2^19, 1 view/GPU/step, fwd+bwd+grad all-reduce+Adam, occupancy refresh every "
+                                   "%d steps" % iv,
                        "rays_per_view": H * W, "samples_per_view": M, "sample_capacity": BENCH_CAPACITY,
                        "views_per_step": world,
-                       "parallelism": "dp%d (1 view per GPU, RCCL all-reduce of gradients, %s on the wire%s)"
-                                      % (world, tr, ", table in %d pipelined level groups" % groups if groups else "")},
+                       "parallelism": "dp%d (1 view per GPU, RCCL all-reduce of gradients, %s on the wire%s)%s"
+                                      % (world, tr, ", table in %d pipelined level groups" % groups if groups else "",
+                                         "; --force-dist: the exchange path on ONE rank (communicator of size 1)"
+                                         if args.force_dist else "")},
             "roofline": {"kernel": "k_grid_forward (hash-grid gather, H5)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "bytes_per_sample": bytes_per_sample, "samples_per_launch": M, "kernel_ms": g_ms},
@@ -561,17 +664,15 @@ def main():
         res["build"] = build_tag
         if tuned:
             res["tuning_overrides"] = tuned
-        if not args.no_extras and world == 1:
-            ms = time_occ_refresh(net)
-            iv = net.cfg.update_extra_interval
-            res["occ_refresh"] = {"ms_per_refresh": ms, "interval_steps": iv, "ms_per_step_amortised": ms / iv,
-                                  "what": "NeRFRenderer.update_extra_state() (H10), steady-state form, timed after the "
-                                          "timed region; the trainer runs it every %d steps, the bench step excludes it" % iv}
+        if not args.no_extras and not dist_on:
+            if args.trainer_steps > 0:
+                res["trainer"] = trainer_companion(dev, args.trainer_steps, args.precision)
+                res["trainer"]["frac_of_value"] = res["trainer"]["value"] / res["value"]
             res["f32"] = companion_f32(dev, rank)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not dist_on:
             res["cpu_baseline"] = cpu_baseline(args.cpu_frames)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define LNERF_ABI_VERSION 3
+#define LNERF_ABI_VERSION 4
 
 #define LNERF_OK 0
 #define LNERF_ERR_INVALID_ARG (-1)
@@ -135,6 +135,15 @@ int lnerf_march_rays_train_pose(const float *c2w, int B, int H, int W, float fx,
                                 int grid_size, int max_steps, float dt_gamma, const float *noises, uint32_t noise_seed,
                                 int32_t *noise_counter, int64_t capacity, float *xyzs, float *dirs, float *deltas,
                                 int32_t *rays, int32_t *counter, lnerf_stream_t stream);
+/* The same with the intrinsics in DEVICE memory: intrinsics f32 [B,4] = (fx, fy, cx, cy) per view.  Nothing about the
+ * camera is baked into the launch, so a captured hipGraph renders whatever pose / field of view its caller copied into
+ * `c2w` / `intrinsics` before the replay (the trainer's graphed step: a new random view every step). */
+int lnerf_march_rays_train_camera(const float *c2w, const float *intrinsics, int B, int H, int W, float *rays_o_out,
+                                  float *rays_d_out, float xmin, float ymin, float zmin, float xmax, float ymax,
+                                  float zmax, float min_near, const uint8_t *bitfield, float bound, int cascade,
+                                  int grid_size, int max_steps, float dt_gamma, const float *noises, uint32_t noise_seed,
+                                  int32_t *noise_counter, int64_t capacity, float *xyzs, float *dirs, float *deltas,
+                                  int32_t *rays, int32_t *counter, lnerf_stream_t stream);
 
 /* ---- H4 (inference): `raymarching.march_rays` / `composite_rays` and the live-ray compaction
  * the upstream renderer does on the host (`rays_alive = rays_alive[rays_alive >= 0]`). */
@@ -234,7 +243,8 @@ int lnerf_mlp_fragment_maps(int out_dim, int32_t *map_w1, int32_t *map_w2, int32
  * Weights are PyTorch nn.Linear layout: w1 [64,32], b1 [64], w2 [64,64], b2 [64], w3 [out_dim,64],
  * b3 [out_dim], all f32.  sigma = exp(h0 + blob_scale*exp(-|x|^2/(2 blob_std^2))), rgbs = h[1:].
  * precision: LNERF_F32 -> exact-f32 MFMA (v_mfma_f32_16x16x4_f32), LNERF_BF16 -> bf16 MFMA, f32 acc.
- * level_stride <= 2^24 samples (32-bit byte offsets inside the kernels); with out_dim == 5 the bf16 path moves the
+ * level_stride <= 2^24 samples with LNERF_BF16 (32-bit byte offsets inside the bf16 kernels; the exact-f32 kernels take
+ * any stride below 2^30); with out_dim == 5 the bf16 path moves the
  * latent rows (rgbs, drgbs: [*, 4] f32) 16 bytes at a time: those buffers must be 16-byte aligned.
  * workspace (optional, 16-byte aligned, >= 36 KiB; the buffer of lnerf_mlp_backward_workspace_bytes() serves): with
  * it the bf16 path builds its weight fragments (the backward's too) once per launch instead of once per workgroup;
@@ -254,6 +264,7 @@ int lnerf_mlp_forward(const void *feat, int feat_dtype, int64_t level_stride, co
  * clear_ptr / clear_bytes (may be NULL / 0; 4-byte granular): a small region the slab-reduction launch also zeroes
  * -- e.g. the cursors of the scatter that follows (LNERF_SCATTER_CLEARED): one dispatch less per step. */
 #define LNERF_MLP_FRAGMENTS_READY 0x100
+#define LNERF_MLP_FRAGMENT_BYTES (36 * 1024) /* the bf16 weight-fragment image at the head of the workspace */
 size_t lnerf_mlp_backward_workspace_bytes(int out_dim);
 int lnerf_mlp_backward(const void *feat, int feat_dtype, int64_t level_stride, const float *xyzs, const float *w1,
                        const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, int out_dim,
@@ -261,6 +272,13 @@ int lnerf_mlp_backward(const void *feat, int feat_dtype, int64_t level_stride, c
                        const float *dsigmas, const float *drgbs, float *dfeat, float *dw1, float *db1, float *dw2,
                        float *db2, float *dw3, float *db3, int accumulate, void *workspace, size_t workspace_bytes,
                        int precision, void *clear_ptr, size_t clear_bytes, lnerf_stream_t stream);
+
+/* ---- trainer helper: gradient of the opacity-entropy regulariser of the NeRF trainer (sparsity term) w.r.t.
+ * weights_sum [N], in one launch:  L = scale * mean_i H(clamp(ws_i, eps, 1 - eps)),  H(p) = -p log2 p - (1-p) log2(1-p);
+ * grad_i = scale / N * (log2(1 - ws_i) - log2 ws_i) for eps <= ws_i <= 1 - eps, else 0.  The result is handed to the
+ * compositing backward as grad_weights_sum. */
+int lnerf_opacity_entropy_grad(const float *weights_sum, int64_t N, float scale, float eps, float *grad,
+                               lnerf_stream_t stream);
 
 /* ---- H8/H9: `raymarching.composite_rays_train_forward/backward`.  One wavefront per ray,
  * log-space prefix scan of sigma*dt across lanes.  C = colour channels (3 or 4).

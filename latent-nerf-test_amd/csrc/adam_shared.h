@@ -13,11 +13,17 @@ struct AdamArgs {
 };
 
 // bias corrections from the device step counter (same value in every thread; a handful of SALU/VALU ops)
+__device__ __forceinline__ void adam_bias_at(AdamArgs &a, int32_t step) {
+    const float t = (float)step;
+    a.bc1 = 1.0f - powf(a.beta1, t);
+    a.bc2 = 1.0f - powf(a.beta2, t);
+    a.inv_bc1 = 1.0f / a.bc1;
+    a.inv_bc2 = 1.0f / a.bc2;
+}
 __device__ __forceinline__ void adam_bias(AdamArgs &a) {
     if (a.step_dev) {
-        const float t = (float)(*a.step_dev);
-        a.bc1 = 1.0f - powf(a.beta1, t);
-        a.bc2 = 1.0f - powf(a.beta2, t);
+        adam_bias_at(a, *a.step_dev);
+        return;
     }
     a.inv_bc1 = 1.0f / a.bc1;
     a.inv_bc2 = 1.0f / a.bc2;

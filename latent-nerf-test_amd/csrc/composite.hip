@@ -183,7 +183,33 @@ k_composite_train_bwd(const float *__restrict__ g_ws, const float *__restrict__ 
 
 using namespace lnerf;
 
+// Gradient of the opacity-entropy regulariser (the trainer's sparsity term) with respect to weights_sum, one launch:
+//   L = scale * mean_i H(p_i),  p = clamp(ws, eps, 1 - eps),  H(p) = -p log2 p - (1 - p) log2(1 - p)
+//   dL/dws_i = scale / N * (log2(1 - p_i) - log2 p_i)   inside the clamp, 0 outside (the clamp's subgradient)
+__global__ void __launch_bounds__(256) k_entropy_grad(const float *__restrict__ ws, int64_t N, float scale, float eps,
+                                                      float *__restrict__ grad) {
+    const float k = scale / (float)N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const float w = ws[i];
+        const bool inside = w >= eps && w <= 1.0f - eps;
+        grad[i] = inside ? k * (log2f(1.0f - w) - log2f(w)) : 0.0f;
+    }
+}
+
 extern "C" {
+
+int lnerf_opacity_entropy_grad(const float *weights_sum, int64_t N, float scale, float eps, float *grad,
+                               lnerf_stream_t stream) {
+    LNERF_REQUIRE(N >= 0 && eps > 0.f && eps < 0.5f, "opacity_entropy_grad: bad arguments");
+    if (N == 0) return LNERF_OK;
+    LNERF_REQUIRE(weights_sum && grad, "opacity_entropy_grad: null pointer");
+    int64_t blocks = div_up(N, (int64_t)256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_entropy_grad, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), weights_sum, N, scale, eps,
+                       grad);
+    LNERF_CHECK_LAUNCH("opacity_entropy_grad");
+    return LNERF_OK;
+}
 
 int lnerf_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas,
                                        const int32_t *rays, int64_t N, int C, float T_thresh, const float *bg_color,

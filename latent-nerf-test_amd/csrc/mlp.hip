@@ -394,7 +394,11 @@ static int mlp_common_checks(const char *who, const void *feat, int feat_dtype, 
                              const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
                              const float *b3, int out_dim, float blob_std, int64_t m_host, int precision) {
     LNERF_REQUIRE(m_host >= 0 && level_stride >= m_host, "%s: need 0 <= m_host <= level_stride", who);
-    LNERF_REQUIRE(level_stride <= ((int64_t)1 << 24), "%s: level_stride must be <= 2^24 samples (32-bit byte offsets)", who);
+    // (the bf16 kernels address features and feature gradients with 32-bit byte offsets: 16 levels x level_stride x 8 B
+    // must stay below 2^32; the exact-f32 kernels use 64-bit addressing and take any stride the scatter accepts)
+    LNERF_REQUIRE(precision != LNERF_BF16 || level_stride <= ((int64_t)1 << 24),
+                  "%s: level_stride must be <= 2^24 samples with the bf16 MLP (32-bit byte offsets)", who);
+    LNERF_REQUIRE(level_stride < ((int64_t)1 << 30), "%s: level_stride must be below 2^30 samples", who);
     LNERF_REQUIRE(out_dim >= 2 && out_dim <= 8, "%s: out_dim must be in [2,8] (got %d)", who, out_dim);
     LNERF_REQUIRE(feat_dtype == LNERF_F32 || feat_dtype == LNERF_BF16, "%s: bad feat dtype", who);
     LNERF_REQUIRE(precision == LNERF_F32 || precision == LNERF_BF16, "%s: bad precision tag", who);

@@ -26,7 +26,7 @@ struct MlpArgs {
     const int32_t *m_dev;
     const void *frag_global;  // bf16 path: the weight fragments, built once per launch (NULL: every workgroup builds its own)
 };
-constexpr size_t MLP_FRAG_BYTES = 36 * 1024;  // room for the 33 one-KiB fragments of the bf16 path at the head of a workspace
+constexpr size_t MLP_FRAG_BYTES = LNERF_MLP_FRAGMENT_BYTES;  // room for the 33 one-KiB fragments of the bf16 path at the head of a workspace
 
 __device__ __forceinline__ float blob_of(const MlpArgs &a, int64_t m) {
     const float x = a.xyzs[m * 3], y = a.xyzs[m * 3 + 1], z = a.xyzs[m * 3 + 2];

@@ -71,21 +71,28 @@ struct AdamMulti {
     const int32_t *map[ADAM_MULTI_MAX];  // optional per tensor: two positions per element in `shadow` (-1: none)
     uint16_t *shadow;                    // bf16 image the mapped tensors are mirrored into (the MLP's weight fragments)
 };
-// tick: the last workgroup to finish advances the device step counter (every workgroup has read it by then) -- the
-// separate one-thread launch of lnerf_adam_tick costs a whole dispatch (~4 us in a replayed graph).  step_dev[1] is
-// the arrival counter (left at 0 again).
+// tick: the last workgroup to arrive advances the device step counter -- the separate one-thread launch of
+// lnerf_adam_tick costs a whole dispatch (~4 us in a replayed graph).  step_dev[1] is the arrival counter (left at 0
+// again).  Ordering: every wave reads the counter ONCE with a device-scope atomic load (the compiler can neither
+// duplicate nor re-issue it later), waits until the value has RETURNED (s_waitcnt), and only then joins the workgroup
+// barrier that precedes its workgroup's arrival; the arrival is a device-scope atomic, the counter is rewritten with
+// device-scope atomic stores by the one workgroup whose arrival came last.  So the store to step_dev[0] is ordered
+// behind every read of it in this launch without a cache write-back (a release fence would flush the XCD's L2).
 __global__ void __launch_bounds__(256) k_adam_multi(AdamMulti t, AdamArgs a, int32_t *tick) {
-    adam_bias(a);
     if (tick) {
-        __syncthreads();   // every thread of this workgroup has taken its bias corrections from the counter (the loads
-                           // have returned: adam_bias consumed them) -- no fence needed, nothing else is published
+        const int32_t step_now = __hip_atomic_load(tick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        adam_bias_at(a, step_now);
+        __syncthreads();
         if (threadIdx.x == 0) {
             const int total = (int)(gridDim.x * gridDim.y);
-            if (atomicAdd(&tick[1], 1) == total - 1) {
-                tick[1] = 0;
-                tick[0] += 1;
+            if (__hip_atomic_fetch_add(&tick[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
+                __hip_atomic_store(&tick[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&tick[0], step_now + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+    } else {
+        adam_bias(a);
     }
     const int k = blockIdx.y;
     a.lr = t.lr[k];

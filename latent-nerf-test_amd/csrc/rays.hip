@@ -40,6 +40,8 @@ __global__ void __launch_bounds__(256) k_get_rays(const float *__restrict__ c2w,
 // ray generation folded into the march's count pass (lnerf_march_rays_train_pose): camera + the buffers the rays go to
 struct RayGen {
     const float *c2w;
+    const float *intr;   // optional device intrinsics [B,4] = (fx, fy, cx, cy) per view: override the by-value ones, so
+                         // that a replayed hipGraph can render a new camera every time (lnerf_march_rays_train_camera)
     int on, H, W;
     float fx, fy, cx, cy;
     float *ro, *rd;
@@ -239,7 +241,12 @@ k_march_train(const float *__restrict__ rays_o, const float *__restrict__ rays_d
     // pass and the caller), else read
     float ro[3], rd[3];
     if (!WRITE && gen.on) {
-        pixel_ray(gen.c2w, gen.H, gen.W, gen.fx, gen.fy, gen.cx, gen.cy, n, ro, rd);
+        float fx = gen.fx, fy = gen.fy, cx = gen.cx, cy = gen.cy;
+        if (gen.intr) {   // (wave-uniform: one ray per wavefront)
+            const float *k = gen.intr + (n / ((int64_t)gen.H * gen.W)) * 4;
+            fx = k[0]; fy = k[1]; cx = k[2]; cy = k[3];
+        }
+        pixel_ray(gen.c2w, gen.H, gen.W, fx, fy, cx, cy, n, ro, rd);
         if (lane == 0) {
 #pragma unroll
             for (int r = 0; r < 3; ++r) { gen.ro[n * 3 + r] = ro[r]; gen.rd[n * 3 + r] = rd[r]; }
@@ -934,7 +941,25 @@ int lnerf_march_rays_train_pose(const float *c2w, int B, int H, int W, float fx,
     LNERF_REQUIRE(B == 0 || (c2w && rays_o_out && rays_d_out), "march_rays_train_pose: null pointer");
     const RayBox box{xmin, ymin, zmin, xmax, ymax, zmax, min_near};
     RayGen gen;
-    gen.c2w = c2w; gen.on = 1; gen.H = H; gen.W = W; gen.fx = fx; gen.fy = fy; gen.cx = cx; gen.cy = cy;
+    gen.c2w = c2w; gen.intr = nullptr; gen.on = 1; gen.H = H; gen.W = W; gen.fx = fx; gen.fy = fy; gen.cx = cx; gen.cy = cy;
+    gen.ro = rays_o_out; gen.rd = rays_d_out;
+    return march_train_impl(rays_o_out, rays_d_out, nullptr, nullptr, &box, &gen, (int64_t)B * H * W, bitfield, bound,
+                            cascade, grid_size, max_steps, dt_gamma, noises, noise_seed, noise_counter, capacity, xyzs,
+                            dirs, deltas, rays, counter, stream);
+}
+
+int lnerf_march_rays_train_camera(const float *c2w, const float *intrinsics, int B, int H, int W, float *rays_o_out,
+                                  float *rays_d_out, float xmin, float ymin, float zmin, float xmax, float ymax,
+                                  float zmax, float min_near, const uint8_t *bitfield, float bound, int cascade,
+                                  int grid_size, int max_steps, float dt_gamma, const float *noises, uint32_t noise_seed,
+                                  int32_t *noise_counter, int64_t capacity, float *xyzs, float *dirs, float *deltas,
+                                  int32_t *rays, int32_t *counter, lnerf_stream_t stream) {
+    LNERF_REQUIRE(B >= 0 && H >= 1 && W >= 1, "march_rays_train_camera: bad image size");
+    LNERF_REQUIRE(xmin <= xmax && ymin <= ymax && zmin <= zmax, "march_rays_train_camera: inverted aabb");
+    LNERF_REQUIRE(B == 0 || (c2w && intrinsics && rays_o_out && rays_d_out), "march_rays_train_camera: null pointer");
+    const RayBox box{xmin, ymin, zmin, xmax, ymax, zmax, min_near};
+    RayGen gen;
+    gen.c2w = c2w; gen.intr = intrinsics; gen.on = 1; gen.H = H; gen.W = W; gen.fx = gen.fy = 1.f; gen.cx = gen.cy = 0.f;
     gen.ro = rays_o_out; gen.rd = rays_d_out;
     return march_train_impl(rays_o_out, rays_d_out, nullptr, nullptr, &box, &gen, (int64_t)B * H * W, bitfield, bound,
                             cascade, grid_size, max_steps, dt_gamma, noises, noise_seed, noise_counter, capacity, xyzs,

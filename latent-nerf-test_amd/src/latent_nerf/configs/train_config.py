@@ -55,6 +55,9 @@ class OptimConfig:
     # data parallel, bf16: level groups the table gradient is exchanged in (each group's all-reduce is launched behind
     # its own sums while the next group is still being summed); 1 = one collective for the whole table
     exchange_groups: int = 4
+    # replay the step from captured hipGraphs (graph F: render / eager guidance / graph B: backward + optimiser); the
+    # first steps, and the step after every change of the sample budget, run eagerly.  One view per rank and step.
+    graph_step: bool = True
 
 
 @dataclass
@@ -67,6 +70,8 @@ class LogConfig:
     full_eval_size: int = 100
     save_mesh: bool = False
     max_keep_ckpts: int = 2
+    # evaluation renders go through the guidance model's decoder (vae.decode) instead of the linear latent->RGB preview
+    decode_eval: bool = False
 
     @property
     def exp_dir(self) -> Path:

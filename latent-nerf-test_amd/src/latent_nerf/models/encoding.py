@@ -61,23 +61,26 @@ def grid_encode_forward(xyzs, bound, table, levels: GridLevels, m_host, m_dev, l
     return out
 
 
-_scatter_ws = {}
+_scatter_ws = {}   # device -> [workspaces, ascending size]
 
 
 def scatter_workspace(levels: GridLevels, m_host, device):
-    """Device scratch of the bucketed scatter (variant 2), cached per (device, size)."""
+    """Device scratch of the bucketed scatter: ANY buffer of at least lnerf_grid_encode_backward_workspace_bytes()
+    serves (the kernels lay it out from `m_host`, not from its size), so a process keeps one buffer per device that only
+    ever grows: a renderer whose sample budget moves up and down in 64 Ki steps (NeRFRenderer.update_sample_budget)
+    re-uses the largest one instead of allocating one per distinct capacity.  A captured hipGraph may hold the address
+    of a buffer handed out earlier, so outgrown ones are kept, but every growth is by >= 1.5x: the total stays below
+    three times the largest request."""
     need = _b.get_lib().lnerf_grid_encode_backward_workspace_bytes(levels.num_levels, levels.c_offsets, int(m_host))
     if need == 0:
         raise _b.LnerfError("bucketed scatter cannot handle this level table; use scatter variant 0/1")
-    key = (str(device), need)
-    ws = _scatter_ws.get(key)
-    if ws is None:
-        # A workspace can be gigabytes, but a captured hipGraph may hold its address: never free one that
-        # was handed out while others might still replay.  Keep the distinct sizes a process uses (288 GB of HBM).
-        if sum(t.numel() for t in _scatter_ws.values()) + need > (96 << 30):
-            raise _b.LnerfError("scatter workspaces of this process would exceed 96 GiB")
-        ws = torch.empty(need, device=device, dtype=torch.uint8)
-        _scatter_ws[key] = ws
+    have = _scatter_ws.setdefault(str(device), [])
+    for ws in have:
+        if ws.numel() >= need:
+            return ws
+    size = max(need, (3 * have[-1].numel()) // 2 if have else 0)
+    ws = torch.empty(size, device=device, dtype=torch.uint8)
+    have.append(ws)
     return ws
 
 

@@ -198,11 +198,20 @@ class NeRFNetwork(NeRFRenderer):
         return (self.precision == "bf16" and self._frag_owner is not None and self._mlp_ws is not None
                 and self._frag_built_in == self._mlp_ws.data_ptr() and self._frag_versions == self.weight_versions())
 
+    MAX_BF16_STRIDE = 1 << 24
+
     # ---- per-sample field -------------------------------------------------------------
     def field(self, xyzs, m_host, m_dev=None, level_stride=None):
         """xyzs [cap,3] -> sigmas [cap], latents [cap,C] for the first min(m_host, *m_dev) rows."""
         if level_stride is None:
             level_stride = xyzs.shape[0]
+        if self.precision == "bf16" and level_stride > self.MAX_BF16_STRIDE and m_dev is None \
+                and not torch.is_grad_enabled():
+            # the bf16 kernels address features with 32-bit byte offsets (include/lnerf_hip.h: level_stride <= 2^24):
+            # an inference batch beyond that is evaluated in pieces (training batches never get near it)
+            outs = [self.field(xyzs[s:s + self.MAX_BF16_STRIDE], min(self.MAX_BF16_STRIDE, int(m_host) - s))
+                    for s in range(0, int(m_host), self.MAX_BF16_STRIDE)]
+            return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
         ws = self.mlp_workspace(xyzs.device)
         enc = self.encoder
         ready = self.fragments_current()

@@ -45,6 +45,27 @@ class PreparedRays:
         self.march, self.bg, self.prefix, self.N, self.cap = march, bg, prefix, N, cap
 
 
+class _ShadowExtraState:
+    NAMES = ("density_grid", "density_bitfield", "mean_density_dev")
+
+    def __init__(self, renderer):
+        self.r = renderer
+
+    def __enter__(self):
+        r = self.r
+        if r._shadow_state is None or r._shadow_state[0].device != r.density_grid.device:
+            r._shadow_state = [getattr(r, n).clone() for n in self.NAMES]
+        self.real = [r._buffers[n] for n in self.NAMES]
+        for n, t in zip(self.NAMES, r._shadow_state):
+            r._buffers[n] = t
+        return r
+
+    def __exit__(self, *exc):
+        for n, t in zip(self.NAMES, self.real):
+            self.r._buffers[n] = t
+        return False
+
+
 class NeRFRenderer(nn.Module):
     def __init__(self, cfg, latent_mode: bool = True):
         super().__init__()
@@ -73,7 +94,7 @@ class NeRFRenderer(nn.Module):
         self._ray_slots = [None, None]    # ray buffers of the camera form of prepare_rays
         self._march_key = None
         self._budget = None       # ((N, max_steps), capacity) derived from observed marches
-        self._m_peak = None       # device int32 [1]: largest M since the last budget update
+        self._m_peak = None       # device int32 [3]: largest (M, live rays, dropped rays) of any march since the last budget update
         self.mean_count = 0
         self._noise_counter = None
         self._occ_scratch = None
@@ -81,6 +102,8 @@ class NeRFRenderer(nn.Module):
         self._occ_gen = None
         self._occ_seed = 0x0CC0
         self._occ_sample_ws = None
+        self._bg_const = {}
+        self._shadow_state = None
 
     # subclasses provide the field -------------------------------------------------------
     def forward(self, x, d=None):
@@ -110,7 +133,16 @@ class NeRFRenderer(nn.Module):
         if bg_color is None:
             bg_color = 1.0
         if not torch.is_tensor(bg_color):
-            return torch.full((N, C), float(bg_color), device=rays_d.device, dtype=torch.float32)
+            # a constant background is read-only for every consumer: one cached tensor per (N, C, value) instead of a
+            # fill dispatch per render (a dependent ~5 us launch in a replayed step)
+            key = (N, C, float(bg_color), str(rays_d.device))
+            cached = self._bg_const.get(key)
+            if cached is None:
+                if len(self._bg_const) > 8:
+                    self._bg_const.clear()
+                cached = torch.full((N, C), float(bg_color), device=rays_d.device, dtype=torch.float32)
+                self._bg_const[key] = cached
+            return cached
         bg = bg_color.to(rays_d.device, torch.float32)
         if bg.dim() == 1:
             bg = bg[None].expand(N, C)
@@ -129,8 +161,8 @@ class NeRFRenderer(nn.Module):
 
     def update_sample_budget(self):
         """Called where the training loop synchronises anyway (the occupancy refresh, every `update_extra_interval`
-        steps): reads the march statistics back ONCE -- the largest sample count M of any training march since the
-        previous call (kept on the device by run_cuda) and the last march's dropped-ray count -- and re-derives the
+        steps): reads the march statistics back ONCE -- the largest sample count M and the largest dropped-ray count of
+        any training march since the previous call (running maxima kept on the device by prepare_rays) -- and re-derives the
         capacity for marches of that shape: 1.5 x M rounded up to 64 Ki samples.  It changes only when the peak came
         within 80 % of the current capacity (or rays were dropped: back to the worst case) or fell below 40 % of it.
         The upstream renderer sizes its buffers from a running `mean_count` the same way, but reads the counter
@@ -138,7 +170,7 @@ class NeRFRenderer(nn.Module):
         m = self._march
         if m is None or self._m_peak is None or self.cfg.max_samples > 0:
             return None
-        peak, dropped = int(self._m_peak.item()), int(m.counter[2].item())
+        peak, _live, dropped = (int(v) for v in self._m_peak.tolist())   # (ONE read-back; window maxima, not the last march)
         self._m_peak.zero_()
         key, cap = self._march_key, m.capacity
         self.mean_count = peak if self.mean_count == 0 else int(0.9 * self.mean_count + 0.1 * peak)
@@ -217,9 +249,9 @@ class NeRFRenderer(nn.Module):
         self._march = march
         if self._march_key != (N, int(max_steps)) or self._m_peak is None:
             self._march_key = (N, int(max_steps))
-            self._m_peak = torch.zeros(1, device=rays_o.device, dtype=torch.int32)
-        if self.cfg.max_samples <= 0:   # running peak of M, on the device (one tiny launch, no host sync)
-            torch.maximum(self._m_peak, march.counter[0:1], out=self._m_peak)
+            self._m_peak = torch.zeros(3, device=rays_o.device, dtype=torch.int32)
+        if self.cfg.max_samples <= 0:   # running maxima of (M, live, dropped), on the device (one tiny launch, no host sync)
+            torch.maximum(self._m_peak, march.counter[0:3], out=self._m_peak)
         return PreparedRays(march, bg, prefix, N, cap)
 
     def run_cuda(self, rays_o, rays_d, dt_gamma=0.0, bg_color=None, perturb=False, force_all_rays=False,
@@ -336,6 +368,29 @@ class NeRFRenderer(nn.Module):
         return {"image": image.view(*prefix, C), "depth": depth.view(*prefix),
                 "weights_sum": weights_sum.view(*prefix)}
 
+    @torch.no_grad()
+    def seed_density_grid(self, density_fn, thresh=None):
+        """Fill the occupancy grid from an analytic density: `density_fn(xyz [G^3,3]) -> [G^3]` evaluated at the cell
+        centres of every cascade (the points lnerf_occ_cell_points gives, Morton order), mean and bitfield recomputed
+        (`thresh` overrides `density_thresh` for the bitfield).  Used to start from a known shape (bench.py: the sphere
+        of SURVEY.md section 8(d); training/shape.py seeds from a mesh the same way)."""
+        G, dev = self.grid_size, self.density_grid.device
+        for cas in range(self.cascade):
+            xyz = torch.empty(G ** 3, 3, device=dev)
+            _b.call("lnerf_occ_cell_points", None, G ** 3, cas, G, self.bound, None, _p(xyz), _stream())
+            self.density_grid[cas] = density_fn(xyz).to(torch.float32)
+        self.mean_density_dev.fill_(float(self.density_grid.clamp(min=0).mean()))
+        rm.packbits(self.density_grid, self.density_thresh if thresh is None else float(thresh), self.density_bitfield,
+                    None if thresh is not None else self.mean_density_dev)
+        return self.density_bitfield
+
+    def shadow_extra_state(self):
+        """Context manager: inside it the occupancy state (density grid, bitfield, mean) is a SHADOW copy, so
+        update_extra_state() does all of its work -- cell sampling, the density query, decayed maximum, mean, bitfield --
+        without changing the scene the march sees.  bench.py times the refresh inside its timed steps this way while the
+        analytic occupancy of its workload stays pinned."""
+        return _ShadowExtraState(self)
+
     def occupancy_generator(self, seed=None):
         """The generator the occupancy refresh draws its cell samples and jitter from.  Replicas of a data-parallel run
         refresh their grids redundantly: with the same seed on every rank (the trainer passes `optim.seed`) and the
@@ -431,6 +486,8 @@ class NeRFRenderer(nn.Module):
         camera = kwargs.pop("camera", None)
         if camera is not None and rays_o is None:   # inference / uniform sampler: plain ray generation first
             poses, intr, him, wim = camera
+            if torch.is_tensor(intr):               # (device intrinsics are the training form; one read-back here)
+                intr = [float(v) for v in intr.reshape(-1)[:4].tolist()]
             rays_o, rays_d = rm.get_rays(poses, intr, int(him), int(wim))
         B, N = rays_o.shape[:2]
         if staged and not self.cuda_ray:

@@ -15,6 +15,7 @@ HEADER_PATH = os.path.join(REPO_ROOT, "include", "lnerf_hip.h")
 LNERF_OK = 0
 F32, BF16 = 0, 1
 MLP_FRAGMENTS_READY = 0x100   # flag on lnerf_mlp_backward's precision tag (include/lnerf_hip.h)
+MLP_FRAGMENT_BYTES = 36 * 1024  # LNERF_MLP_FRAGMENT_BYTES: the bf16 weight-fragment image at the head of the MLP workspace
 SCATTER_CLEARED = 0x100       # flag on the scatter's variant: the caller cleared the cursors (lnerf_grid_scatter_clear_bytes)
 
 
@@ -34,7 +35,7 @@ _F = _c.c_float
 _Z = _c.c_size_t
 _U = _c.c_uint32
 
-ABI_VERSION = 3  # LNERF_ABI_VERSION of include/lnerf_hip.h this host side was written against
+ABI_VERSION = 4  # LNERF_ABI_VERSION of include/lnerf_hip.h this host side was written against
 
 # name -> argtypes (return type int unless listed in _RESTYPES)
 _SIGNATURES = {
@@ -52,6 +53,8 @@ _SIGNATURES = {
                                     _P, _P, _P, _P],
     "lnerf_march_rays_train_pose": [_P, _I, _I, _I, _F, _F, _F, _F, _P, _P, _F, _F, _F, _F, _F, _F, _F, _P, _F, _I, _I, _I,
                                     _F, _P, _U, _P, _L, _P, _P, _P, _P, _P, _P],
+    "lnerf_march_rays_train_camera": [_P, _P, _I, _I, _I, _P, _P, _F, _F, _F, _F, _F, _F, _F, _P, _F, _I, _I, _I, _F, _P, _U,
+                                      _P, _L, _P, _P, _P, _P, _P, _P],
     "lnerf_march_rays": [_L, _I, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _F, _P, _P, _P, _P],
     "lnerf_composite_rays": [_L, _I, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _P],
     "lnerf_compact_rays": [_P, _L, _P, _P, _P],
@@ -73,6 +76,7 @@ _SIGNATURES = {
                            _P, _P, _P, _I, _P, _Z, _I, _P, _Z, _P],
     "lnerf_composite_rays_train_forward": [_P, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P, _P],
     "lnerf_composite_rays_train_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P],
+    "lnerf_opacity_entropy_grad": [_P, _L, _F, _F, _P, _P],
     "lnerf_occ_cell_points": [_P, _L, _I, _I, _F, _P, _P, _P],
     "lnerf_occ_update": [_P, _P, _L, _P, _F, _P, _P],
     "lnerf_occ_mean": [_P, _L, _P, _P, _P],

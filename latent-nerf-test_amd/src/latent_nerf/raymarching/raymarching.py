@@ -175,9 +175,22 @@ def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars,
             raise ValueError("march_rays_train(camera=...) needs aabb= and no nears/fars")
         poses, intr, him, wim = camera
         poses = poses.contiguous()
-        fx, fy, cx, cy = [float(v) for v in intr]
         if poses.shape[0] * him * wim != N:
             raise ValueError("camera describes %d rays, the ray buffers hold %d" % (poses.shape[0] * him * wim, N))
+        if torch.is_tensor(intr):
+            # intrinsics as a device tensor [B,4]: nothing of the camera is a launch argument (graph replays render
+            # whatever the caller copied into `poses` / `intr`)
+            intr = intr.view(-1, 4)
+            if intr.shape[0] != poses.shape[0]:
+                raise ValueError("intrinsics tensor must be [B,4]")
+            _b.call("lnerf_march_rays_train_camera", _chk(poses, "poses"), _chk(intr, "intrinsics"), int(poses.shape[0]),
+                    int(him), int(wim), _chk(rays_o, "rays_o"), _chk(rays_d, "rays_d"), *[float(v) for v in aabb],
+                    float(min_near), _chk(density_bitfield, "density_bitfield", torch.uint8), float(bound), int(C), int(H),
+                    int(max_steps), float(dt_gamma), _chk(noises, "noises", allow_none=True), seed,
+                    _chk(noise_counter, "noise_counter", torch.int32, allow_none=True), int(capacity), _p(xyzs), _p(dirs),
+                    _p(deltas), _p(rays), _p(counter), _stream())
+            return MarchResult(xyzs, dirs, deltas, rays, counter, capacity)
+        fx, fy, cx, cy = [float(v) for v in intr]
         _b.call("lnerf_march_rays_train_pose", _chk(poses, "poses"), int(poses.shape[0]), int(him), int(wim), fx, fy, cx,
                 cy, _chk(rays_o, "rays_o"), _chk(rays_d, "rays_d"), *[float(v) for v in aabb], float(min_near),
                 _chk(density_bitfield, "density_bitfield", torch.uint8), float(bound), int(C), int(H), int(max_steps),

@@ -17,12 +17,28 @@ def world_info():
     return 0, 1
 
 
+def force_exchange() -> bool:
+    """LNERF_FORCE_DIST=1: run the data-parallel code path -- process group, bf16 gradient sink, pipelined per-group
+    all-reduce, row-group Adam -- at ANY world size, one rank included.  One rank on one card is how the RCCL path is
+    exercised on a single-GPU box (the collectives are real RCCL calls over a communicator of size 1); it is also a
+    same-box A/B of the un-fused step against the fused single-GPU step."""
+    import os
+    return os.environ.get("LNERF_FORCE_DIST", "0") not in ("", "0")
+
+
+def exchange_active(group=None) -> bool:
+    """True when gradients are exchanged: more than one rank, or a forced exchange on an initialised group."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or force_exchange()
+
+
 def init_distributed():
     """Call FIRST in a training process, before anything touches the GPU: binds this rank to its device and, when
-    the launcher (`python -m torch.distributed.run --nproc-per-node N ...`) set WORLD_SIZE > 1, joins the process
-    group -- backend "nccl" (= RCCL over xGMI on ROCm), one process per GPU.  LNERF_DIST_BACKEND=gloo lets several
-    ranks share one card for functional rehearsals (the collectives then stage through the host).
-    Returns (rank, world, device)."""
+    the launcher (`python -m torch.distributed.run --nproc-per-node N ...`) set WORLD_SIZE > 1 (or LNERF_FORCE_DIST=1,
+    see force_exchange), joins the process group -- backend "nccl" (= RCCL over xGMI on ROCm), one process per GPU.
+    LNERF_DIST_BACKEND=gloo lets several ranks share one card for functional rehearsals (the collectives then stage
+    through the host).  Returns (rank, world, device)."""
     import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -34,8 +50,11 @@ def init_distributed():
     local_dev = local if backend == "nccl" else local % ndev
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_exchange()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -49,6 +68,9 @@ def broadcast_parameters(params, src=0, group=None):
         return
     for p in params:
         dist.broadcast(p.data, src=src, group=group)
+        # `p.data` has its own version counter: tell autograd (and whoever caches a function of the parameter -- the bf16
+        # table shadow, the MLP weight fragments -- keyed on `p._version`) that the values changed
+        torch.autograd.graph.increment_version(p)
 
 
 def views_for_rank(views_per_step: int, rank: int, world: int) -> List[int]:
@@ -91,6 +113,9 @@ class GradSync:
         self._wire = {}
         self._sinks = {}
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # gradients are exchanged: more than one rank -- or a forced exchange (the collectives then run over a
+        # communicator of size 1; every buffer, launch and wait of the N > 1 step is the same)
+        self.active = exchange_active(group)
 
     def _flat_buffer(self):
         n = sum(p.numel() for p in self.small)
@@ -130,7 +155,7 @@ class GradSync:
         No-op otherwise.  One backward per step.
         pipeline_groups >= 1: the table is exchanged in that many level groups by allreduce_pipelined() (0: one
         collective through allreduce(copy_back=False))."""
-        if self.world == 1 or self.transport == torch.float32:
+        if not self.active or self.transport == torch.float32:
             return None
         from ..models.encoding import GradSink, level_groups
         p = encoder.embeddings
@@ -147,16 +172,16 @@ class GradSync:
         """{parameter: tensor holding the reduced gradient} after allreduce(copy_back=False) / allreduce_pipelined():
         big buckets -- the bf16 wire buffers (FusedAdam.step(grads=...) reads them directly), else the `.grad` tensors
         themselves; small parameters -- their views of the flat bucket (no copy back into `.grad`)."""
-        out = {p: self._wire.get(id(p), p.grad) if self.transport != torch.float32 and self.world > 1 else p.grad
+        out = {p: self._wire.get(id(p), p.grad) if self.transport != torch.float32 and self.active else p.grad
                for p in self.big}
-        if self.world > 1 and self.small and self._flat is not None:
+        if self.active and self.small and self._flat is not None:
             out.update({p: v for p, v in zip(self.small, self._flat_views)})
         return out
 
     def allreduce(self, copy_back=True):
         """After this call every `.grad` holds the SUM over ranks (scale by 1/world in the optimiser).  With the bf16
         transport and copy_back=False the sums of the big buckets stay in the wire buffers (see reduced())."""
-        if self.world == 1:
+        if not self.active:
             return
         pending = []
         for p in self.big:
@@ -203,13 +228,13 @@ class GradSync:
         for lo, hi in sink.groups:
             grid_scatter_reduce_group(sink, lo, hi)
             rows = sink.wire[offs[lo]:offs[hi]]
-            work = dist.all_reduce(rows, group=self.group, async_op=True) if self.world > 1 else None
+            work = dist.all_reduce(rows, group=self.group, async_op=True) if self.active else None
             groups.append((offs[lo], offs[hi], work))
         sink.written += 1     # (`pending` stays: a replayed hipGraph bins again without running any Python)
         small_work = None
         if self.small:
             flat = self._pack_small()
-            if self.world > 1:
+            if self.active:
                 small_work = dist.all_reduce(flat, group=self.group, async_op=True)
         return PendingExchange(groups, self, small_work)
 

@@ -86,3 +86,44 @@ class GraphedTrainStep:
             for p in self.params:
                 p.grad = None
         return self.out
+
+
+class GraphedRenderStep:
+    """The trainer's step as TWO captured graphs around the guidance call (the reference's loop,
+    src/latent_paint/training/trainer.py:113-144 with the explicit backward of
+    src/latent_paint_mesh/training/trainer.py:657-658):
+
+        graph F   forward()            render of the view whose pose / intrinsics sit in static device buffers -> `pred`
+        eager     grad = guidance.train_step(text_z, pred)  (any Python: a UNet, a stub), copied into a static buffer
+        graph B   backward(out, pred)  injects the static gradient, back-propagates, (world == 1) steps the optimiser
+
+    Both graphs share one memory pool: the autograd graph that F's capture built (its saved tensors are the static
+    activations) is what B's capture walks, exactly once; replays re-run the same launches on the same addresses.
+    Nothing is executed while capturing, so a capture does not advance the training state; host-side counters that the
+    captured Python incremented are the caller's to restore.
+
+    forward() -> (out dict, pred tensor); backward(out, pred) -> None."""
+
+    def __init__(self, forward, backward, params, stream):
+        self.stream = stream
+        self.params = list(params)
+        for p in self.params:   # gradients must be created inside the capture (graph pool), not accumulated into
+            p.grad = None
+        torch.cuda.synchronize()
+        self.graph_f = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_f, stream=stream):
+            self.out, self.pred = forward()
+        self.graph_b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_b, pool=self.graph_f.pool(), stream=stream):
+            backward(self.out, self.pred)
+        self.static_grads = [p.grad for p in self.params]   # graph-pool tensors (None where the step consumed them itself)
+        for p in self.params:
+            p.grad = None
+
+    def forward(self):
+        self.graph_f.replay()
+        return self.out, self.pred
+
+    def backward(self):
+        self.graph_b.replay()
+        return self.static_grads

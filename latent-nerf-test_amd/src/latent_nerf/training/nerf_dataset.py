@@ -38,9 +38,13 @@ class NeRFDataset:
                                   np.deg2rad(cfg.angle_front))
         return {"theta": theta, "phi": phi, "radius": radius, "fov": fov, "dir": dirs}
 
-    def collate(self, index=0, generator=None):
+    def collate(self, index=0, generator=None, device_pose=True):
+        """device_pose=False: the pose stays on the host (the trainer's captured step uploads pose + intrinsics itself,
+        as one copy into the static buffers its graph reads)."""
         p = self.sample_pose(index, generator)
-        pose = pose_from_angles(p["theta"], p["phi"], p["radius"])[None].to(self.device)
+        pose = pose_from_angles(p["theta"], p["phi"], p["radius"])[None]
+        if device_pose:
+            pose = pose.to(self.device)
         intr = intrinsics_from_fov(p["fov"], self.H, self.W)
         p.update(H=self.H, W=self.W, pose=pose, camera=(pose, intr, self.H, self.W))
         if self.training:

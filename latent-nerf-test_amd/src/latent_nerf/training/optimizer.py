@@ -53,9 +53,17 @@ class FusedAdam:
             tensors = {}
             for name in ("w1", "w2", "w3"):
                 w = getattr(mlp, name)
-                tensors[name] = torch.empty(w.numel() * 2, device=dev0, dtype=torch.int32)
+                # -1 = "no position": the Adam kernel skips negative entries, so a slot the map kernel leaves out can
+                # never become a wild store
+                tensors[name] = torch.full((w.numel() * 2,), -1, device=dev0, dtype=torch.int32)
             _b.call("lnerf_mlp_fragment_maps", int(mlp.w3.shape[0]), _p(tensors["w1"]), _p(tensors["w2"]),
                     _p(tensors["w3"]), _stream())
+            frag_elems = _b.MLP_FRAGMENT_BYTES // 2   # bf16 elements of the fragment image
+            for name, tmap in tensors.items():   # (once, at construction: a read-back is fine here)
+                lo, hi = int(tmap.min()), int(tmap.max())
+                if lo < 0 or hi >= frag_elems:
+                    raise _b.LnerfError("lnerf_mlp_fragment_maps: %s has positions outside [0, %d): [%d, %d]"
+                                        % (name, frag_elems, lo, hi))
             maps = (ctypes.c_void_p * n)()
             found = 0
             for k, (p, *_r) in enumerate(self.small):
@@ -157,6 +165,11 @@ class FusedAdam:
         if set_to_none:
             for p, *_ in self.big + self.small:
                 p.grad = None
+
+    def note_replayed_step(self):
+        """A captured graph that contains step() was replayed: the device counter advanced, the host mirror follows
+        (checkpoints store it)."""
+        self.step_no += 1
 
     # ---- checkpointing (plain tensors only: loadable with torch.load(weights_only=True))
     def state_dict(self):

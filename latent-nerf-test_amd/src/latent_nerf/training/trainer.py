@@ -19,13 +19,13 @@ from ...utils import make_path, seed_everything, tensor2numpy, write_video
 from ..configs.train_config import TrainConfig
 from ..models.network_grid import NeRFNetwork
 from . import distributed as D
-from .guidance import StableDiffusionGuidance, SyntheticGuidance, sparsity_loss
+from .guidance import (LATENT_TO_RGB, StableDiffusionGuidance, SyntheticGuidance, decode_with, sparsity_loss,
+                       sparsity_loss_grad)
 from .nerf_dataset import NeRFDataset
 from .optimizer import FusedAdam
 
 # approximate linear latent -> RGB map used for quick previews (src/latent_paint/models/textured_mesh.py:34-40)
-_LATENT_TO_RGB = torch.tensor([[0.298, 0.207, 0.208], [0.187, 0.286, 0.173], [-0.158, 0.189, 0.264],
-                               [-0.184, -0.271, -0.473]])
+_LATENT_TO_RGB = torch.tensor(LATENT_TO_RGB)
 
 
 class Trainer:
@@ -61,16 +61,24 @@ class Trainer:
         self.diffusion = guidance if guidance is not None else self.init_diffusion()
         self.text_z = self.calc_text_embeddings()
         n_views = len(D.views_for_rank(max(cfg.optim.views_per_step, self.world), self.rank, self.world))
-        fuse = bool(cfg.optim.fuse_table_update) and self.world == 1 and n_views == 1
+        self.exchange = D.exchange_active()     # more than one rank, or LNERF_FORCE_DIST on one
+        fuse = bool(cfg.optim.fuse_table_update) and not self.exchange and n_views == 1
+        # capturable: the step counter lives on the device, so that the captured step (optim.graph_step) and the eager
+        # step run the very same kernels with the very same bias corrections
         self.optimizer = FusedAdam(self.nerf.get_params(cfg.optim.lr), betas=(0.9, 0.99), eps=1e-15,
-                                   encoder=self.nerf.encoder, fuse_table_update=fuse, mlp=self.nerf)
+                                   encoder=self.nerf.encoder, fuse_table_update=fuse, mlp=self.nerf, capturable=True)
+        # the whole loop (eager steps, captures, replays, collectives) runs on ONE non-default stream: autograd pins a
+        # parameter's gradient accumulation to the stream it first ran on, and the legacy default stream cannot capture
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._gstep, self._gstep_capacity, self._static = None, None, None
+        self.graph_stats = {"captures": 0, "replayed_steps": 0, "eager_steps": 0}
         small = [p for p in self.nerf.parameters() if p is not self.nerf.encoder.embeddings]
         # exchange: bf16 on the wire with the bf16 configuration (f32 otherwise); with one view per rank and step the
         # backward pass writes the wire buffer itself and the table travels in level groups (pipelined with the sums)
         bf16 = cfg.render.precision("mlp_precision") == "bf16"
         self.grad_sync = D.GradSync([self.nerf.encoder.embeddings], small,
                                     transport=torch.bfloat16 if bf16 else torch.float32)
-        self.pipelined = self.world > 1 and bf16 and n_views == 1
+        self.pipelined = self.exchange and bf16 and n_views == 1
         if self.pipelined:
             self.grad_sync.attach_sink(self.nerf.encoder, pipeline_groups=max(1, cfg.optim.exchange_groups))
         self.dataloaders = self.init_dataloaders()
@@ -128,57 +136,165 @@ class Trainer:
         }
 
     # ------------------------------------------------------------------ one optimisation step
-    def train_render(self, data):
-        """Render one view and inject the guidance gradient.  Returns (pred latents [1,C,H,W], loss scalar)."""
-        H, W = data["H"], data["W"]
-        out = self.nerf.render(data["rays_o"], data["rays_d"], staged=False, perturb=True, bg_color=None,
-                               force_all_rays=True, camera=data.get("camera") if data["rays_o"] is None else None)
+    def _render_train(self, camera):
+        out = self.nerf.render(None, None, staged=False, perturb=True, bg_color=None, force_all_rays=True, camera=camera)
+        H, W = int(camera[2]), int(camera[3])
         pred = out["image"].reshape(1, H, W, -1).permute(0, 3, 1, 2).contiguous()
-        dirs = data["dir"]
+        return out, pred
+
+    def _guidance_grad(self, pred, dirs):
         text_z = self.text_z[int(dirs[0])] if isinstance(self.text_z, list) else self.text_z
-        grad = self.diffusion.train_step(text_z, pred, dirs=dirs) if isinstance(self.diffusion, SyntheticGuidance) \
-            else self.diffusion.train_step(text_z, pred)
+        if isinstance(self.diffusion, SyntheticGuidance):
+            return self.diffusion.train_step(text_z, pred, dirs=dirs)
+        return self.diffusion.train_step(text_z, pred)
+
+    def _backward(self, out, pred, grad):
+        """SDS: d(loss)/d(pred) = grad (src/latent_paint_mesh/training/trainer.py:657-658).  The sparsity term's gradient
+        w.r.t. weights_sum comes from one HIP launch and enters the compositing backward beside it; the shape term (a
+        function of the samples) goes through autograd."""
+        tensors, grads = [pred], [grad]
+        if self.cfg.optim.lambda_sparsity > 0:
+            tensors.append(out["weights_sum"])
+            grads.append(sparsity_loss_grad(out["weights_sum"], self.cfg.optim.lambda_sparsity))
+        if self.shape_loss is not None and self.cfg.optim.lambda_shape > 0:
+            loss = self.cfg.optim.lambda_shape * self.shape_loss(out["xyzs"], out["sigmas"], out["counter"])
+            tensors.append(loss)
+            grads.append(torch.ones_like(loss))
+        torch.autograd.backward(tensors, grads)
+
+    def step_loss(self, out):
+        """Value of the auxiliary terms of one render (logging only; the step itself never needs it)."""
         loss = torch.zeros((), device=self.device)
         if self.cfg.optim.lambda_sparsity > 0:
-            loss = loss + self.cfg.optim.lambda_sparsity * sparsity_loss(out["weights_sum"])
-        if self.shape_loss is not None and self.cfg.optim.lambda_shape > 0:
-            loss = loss + self.cfg.optim.lambda_shape * self.shape_loss(out["xyzs"], out["sigmas"], out["counter"])
-        # SDS: d(loss)/d(pred) = grad (src/latent_paint_mesh/training/trainer.py:657-658); other terms by autograd
-        if loss.requires_grad:
-            torch.autograd.backward([pred, loss], [grad, torch.ones_like(loss)])
+            loss = loss + self.cfg.optim.lambda_sparsity * sparsity_loss(out["weights_sum"].detach())
+        return loss
+
+    def train_render(self, data):
+        """Render one view and inject the guidance gradient.  Returns (pred latents [1,C,H,W], the render's dict)."""
+        if data["rays_o"] is None:
+            out, pred = self._render_train(data["camera"])
         else:
-            pred.backward(gradient=grad)
-        return pred, loss
+            H, W = data["H"], data["W"]
+            out = self.nerf.render(data["rays_o"], data["rays_d"], staged=False, perturb=True, bg_color=None,
+                                   force_all_rays=True)
+            pred = out["image"].reshape(1, H, W, -1).permute(0, 3, 1, 2).contiguous()
+        grad = self._guidance_grad(pred, data["dir"])
+        self._backward(out, pred, grad)
+        return pred, out
+
+    def _exchange_and_step(self, n_views):
+        scale = 1.0 / (n_views * self.world)
+        if self.pipelined:
+            ex = self.grad_sync.allreduce_pipelined()
+            ex.finish_small()
+            self.optimizer.step(grad_scale=scale, grads=self.grad_sync.reduced(),
+                                row_groups={self.nerf.encoder.embeddings: ex.table_groups})
+        else:
+            self.grad_sync.allreduce()
+            self.optimizer.step(grad_scale=scale)
+
+    # ---- the captured step (optim.graph_step): graph F (render) / eager guidance / graph B (backward [+ optimiser])
+    def _graph_ready(self, n_views):
+        r = self.cfg.render
+        return (bool(getattr(self.cfg.optim, "graph_step", True)) and n_views == 1 and self.nerf.cuda_ray
+                and r.noise_seed is not None and self.nerf.bg_radius <= 0)
+
+    def _capture(self):
+        """Capture the step for the current sample capacity.  Runs no kernel: the training state does not advance."""
+        from .graph_step import GraphedRenderStep
+        r = self.cfg.render
+        C, H, W = self.nerf.img_dims, r.train_h, r.train_w
+        if self._static is None:
+            self._static = {"pose": torch.zeros(1, 4, 4, device=self.device), "intr": torch.zeros(1, 4, device=self.device),
+                            "grad": torch.zeros(1, C, H, W, device=self.device),
+                            # ring of pinned upload slots: the host runs steps ahead of the GPU, a slot is rewritten
+                            # only after the copy that read it has executed (event per slot)
+                            "host": torch.zeros(64, 20, dtype=torch.float32).pin_memory(), "events": [None] * 64,
+                            "cam": torch.zeros(20, device=self.device)}
+        st = self._static
+        solo = not self.exchange
+        opt = self.optimizer
+        keep = (opt.step_no, self.nerf.local_step)
+
+        def forward():
+            # (one 80-byte upload per step lands in `cam`; the two views below alias it)
+            return self._render_train((st["cam"][:16].view(1, 4, 4), st["cam"][16:20].view(1, 4), H, W))
+
+        def backward(out, pred):
+            if solo:
+                opt.arm()                 # one view, one process: the scatter applies the table's Adam step
+            self._backward(out, pred, st["grad"])
+            if solo:
+                opt.step(grad_scale=1.0)
+
+        self._gstep = GraphedRenderStep(forward, backward, list(self.nerf.parameters()), self.stream)
+        opt.step_no, self.nerf.local_step = keep   # host-side counters the captured Python advanced
+        self._gstep_capacity = self.nerf._march.capacity
+        self.graph_stats["captures"] += 1
+
+    def _graphed_step(self, data):
+        st, g = self._static, self._gstep
+        slot = self.train_step % 64
+        if st["events"][slot] is not None:
+            st["events"][slot].synchronize()
+        host = st["host"][slot]
+        host[:16] = data["pose"].reshape(-1)
+        host[16:20] = torch.tensor(data["camera"][1], dtype=torch.float32)
+        st["cam"].copy_(host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st["events"][slot] = ev
+        out, pred = g.forward()
+        st["grad"].copy_(self._guidance_grad(pred, data["dir"]))
+        grads = g.backward()
+        self.nerf.local_step += 1
+        if not self.exchange:
+            self.optimizer.note_replayed_step()
+        else:   # data parallel: the captured backward left this rank's gradients; exchange + optimiser stay eager
+            for p, gr in zip(g.params, grads):
+                p.grad = gr
+            self._exchange_and_step(1)
+            for p in g.params:
+                p.grad = None
+        self.graph_stats["replayed_steps"] += 1
 
     def train(self, iters=None):
         iters = self.cfg.optim.iters if iters is None else iters
         self.nerf.train()
         views = D.views_for_rank(max(self.cfg.optim.views_per_step, self.world), self.rank, self.world)
         ds = self.dataloaders["train"]
-        while self.train_step < iters:
-            self.train_step += 1
-            if self.nerf.cuda_ray and (self.train_step - 1) % self.cfg.render.update_extra_interval == 0:
-                self.nerf.update_extra_state()
-            self.optimizer.zero_grad()
-            for v in views:
-                data = ds.collate(0, generator=D.pose_generator(self.cfg.optim.seed, self.train_step, v))
-                if len(views) == 1:
-                    self.optimizer.arm()   # one view, one process: the scatter applies the table's Adam step
-                self.train_render(data)
-            scale = 1.0 / (len(views) * self.world)
-            if self.pipelined:
-                ex = self.grad_sync.allreduce_pipelined()
-                ex.finish_small()
-                self.optimizer.step(grad_scale=scale, grads=self.grad_sync.reduced(),
-                                    row_groups={self.nerf.encoder.embeddings: ex.table_groups})
-            else:
-                self.grad_sync.allreduce()
-                self.optimizer.step(grad_scale=scale)
-            if self.train_step % self.cfg.log.save_interval == 0:
-                self.save_checkpoint(full=True)
-                self.evaluate(self.dataloaders["val"], self.eval_renders_path)
-                self.nerf.train()
-        self.log("finished training at step %d" % self.train_step)
+        use_graph = self._graph_ready(len(views))
+        eager_left = 2          # eager steps before the first capture (lazy allocations, workspace sizes, autograd streams)
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            while self.train_step < iters:
+                self.train_step += 1
+                if self.nerf.cuda_ray and (self.train_step - 1) % self.cfg.render.update_extra_interval == 0:
+                    self.nerf.update_extra_state()
+                    if self._gstep is not None and self.nerf._capacity(*self.nerf._march_key) != self._gstep_capacity:
+                        self._gstep, eager_left = None, 1   # the sample budget moved: new buffers, capture again
+                if use_graph and self._gstep is None and eager_left <= 0:
+                    self._capture()
+                if use_graph and self._gstep is not None:
+                    data = ds.collate(0, generator=D.pose_generator(self.cfg.optim.seed, self.train_step, views[0]),
+                                      device_pose=False)
+                    self._graphed_step(data)
+                else:
+                    eager_left -= 1
+                    self.graph_stats["eager_steps"] += 1
+                    self.optimizer.zero_grad()
+                    for v in views:
+                        data = ds.collate(0, generator=D.pose_generator(self.cfg.optim.seed, self.train_step, v))
+                        if len(views) == 1:
+                            self.optimizer.arm()   # one view, one process: the scatter applies the table's Adam step
+                        self.train_render(data)
+                    self._exchange_and_step(len(views))
+                if self.train_step % self.cfg.log.save_interval == 0:
+                    self.save_checkpoint(full=True)
+                    self.evaluate(self.dataloaders["val"], self.eval_renders_path)
+                    self.nerf.train()
+        torch.cuda.current_stream().wait_stream(self.stream)
+        self.log("finished training at step %d (%s)" % (self.train_step, self.graph_stats))
         # the reference's trainers close with the full evaluation pass of the last model
         # (src/latent_paint/training/trainer.py:141-144)
         self.log("evaluating the last model...")
@@ -215,7 +331,12 @@ class Trainer:
         return self.evaluate(self.dataloaders["val_large"], self.final_renders_path, save_as_video=True)
 
     def preview_rgb(self, latents):
-        """[1,C,H,W] latents -> uint8 [H,W,3] via the linear latent->RGB estimate (no VAE offline)."""
+        """[1,C,H,W] latents -> uint8 [H',W',3].  With `log.decode_eval` the guidance model's decoder turns the latents
+        into the image (vae.decode, src/stable_diffusion.py:462-470; a guidance object without a decoder gives the
+        linear preview at 8x); default: the linear latent->RGB estimate at the render resolution (no VAE offline)."""
+        if getattr(self.cfg.log, "decode_eval", False) and self.nerf.latent_mode:
+            rgb = decode_with(self.diffusion, latents.float())[0].permute(1, 2, 0).cpu()
+            return tensor2numpy(rgb)
         x = latents[0].permute(1, 2, 0).float().cpu()
         rgb = x @ _LATENT_TO_RGB if x.shape[-1] == 4 else x[..., :3]
         return tensor2numpy(rgb.clamp(-1, 1))

@@ -180,7 +180,8 @@ class TexturedMeshModel(nn.Module):
         if self.latent_mode:
             if guidance is None:
                 raise ValueError("export_mesh needs the guidance model to decode the latent texture")
-            rgb = guidance.decode_latents(self.texture_img)
+            from ...latent_nerf.training.guidance import decode_with
+            rgb = decode_with(guidance, self.texture_img)
         else:
             rgb = self.texture_img_rgb_finetune
         albedo = (rgb[0].permute(1, 2, 0).clamp(0, 1).cpu().numpy() * 255).astype(np.uint8)

@@ -17,7 +17,7 @@ import torch
 import torch.nn.functional as F
 
 from ... import config_cli
-from ...latent_nerf.training.guidance import StableDiffusionGuidance, SyntheticGuidance
+from ...latent_nerf.training.guidance import StableDiffusionGuidance, SyntheticGuidance, decode_with
 from ...latent_nerf.training.optimizer import FusedAdam
 from ...utils import make_path, seed_everything, tensor2numpy, write_video
 from ..configs.train_config import TrainConfig
@@ -135,11 +135,16 @@ class Trainer:
         return pred, grad
 
     # ------------------------------------------------------------------ evaluation
+    def _decode(self, latents):
+        """The guidance model's VAE decoder (src/stable_diffusion.py:462-470) when it has one, else the linear
+        latent -> RGB preview: a guidance object without `decode_latents` must not end an evaluation."""
+        return decode_with(self.diffusion, latents)
+
     @torch.no_grad()
     def eval_render(self, data):
         side = self.cfg.render.eval_grid_size
         out = self.mesh_model.render(theta=data["theta"], phi=data["phi"], radius=data["radius"],
-                                     decode_func=self.diffusion.decode_latents, test=True, dims=(side, side))
+                                     decode_func=self._decode, test=True, dims=(side, side))
         as_image = lambda t: t.permute(0, 2, 3, 1).contiguous().clamp(0, 1)
         return as_image(out["image"]), as_image(out["texture_map"])
 
@@ -173,7 +178,7 @@ class Trainer:
     def log_train_renders(self, preds):
         from PIL import Image
         if self.mesh_model.latent_mode:
-            rgb = self.diffusion.decode_latents(preds).permute(0, 2, 3, 1).contiguous()
+            rgb = self._decode(preds).permute(0, 2, 3, 1).contiguous()
         else:
             rgb = preds.permute(0, 2, 3, 1).contiguous().clamp(0, 1)
         Image.fromarray(tensor2numpy(rgb[0])).save(self.train_renders_path / ("step_%05d.jpg" % self.train_step))
@@ -196,7 +201,7 @@ class Trainer:
     def _rgb_texture_from_latents(self, latent_texture):
         """Start of the RGB fine-tuning backbone: the decoded latent texture at the texture resolution (:248-253)."""
         side = self.cfg.guide.texture_resolution
-        return F.interpolate(self.diffusion.decode_latents(latent_texture.to(self.device)), (side, side),
+        return F.interpolate(self._decode(latent_texture.to(self.device)), (side, side),
                              mode="bilinear", align_corners=False)
 
     def load_checkpoint(self, checkpoint=None, model_only=False):

@@ -17,6 +17,7 @@ def digest(t):
 
 def main():
     out_dir, groups, steps, precision = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    save = len(sys.argv) > 5 and sys.argv[5] == "save"
     from src.latent_nerf.training.distributed import init_distributed
     rank, world, dev = init_distributed()          # before anything touches the GPU
     import torch
@@ -41,6 +42,13 @@ def main():
            "finite": bool(torch.isfinite(tr.nerf.encoder.embeddings).all()),
            "bits_set": int(tr.nerf.density_bitfield.count_nonzero()),
            "noise_seed": int(cfg.render.noise_seed)}
+    res["exchange"] = bool(tr.exchange)
+    res["graph_stats"] = dict(tr.graph_stats)
+    if save:   # the tensors themselves, for comparisons to a tolerance (forced single-rank RCCL against the fused step)
+        import numpy as np
+        np.save(os.path.join(out_dir, "table_rank%d.npy" % rank), tr.nerf.encoder.embeddings.detach().cpu().numpy())
+        np.save(os.path.join(out_dir, "table0_rank%d.npy" % rank), table0.cpu().numpy())
+        np.save(os.path.join(out_dir, "w2_rank%d.npy" % rank), tr.nerf.w2.detach().cpu().numpy())
     with open(os.path.join(out_dir, "rank%d.json" % rank), "w") as f:
         json.dump(res, f)
     import torch.distributed as dist

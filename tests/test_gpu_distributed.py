@@ -21,16 +21,18 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(tmp_path, world, groups, steps=20, precision="bf16"):
-    out = tmp_path / ("w%d_g%d_%s" % (world, groups, precision))
+def _run(tmp_path, world, groups, steps=20, precision="bf16", backend="gloo", force=False, save=False, tag=""):
+    out = tmp_path / ("w%d_g%d_%s%s" % (world, groups, precision, tag))
     out.mkdir()
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), LNERF_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_PORT=str(port), LNERF_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   LNERF_FORCE_DIST="1" if force else "0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(out), str(groups),
-                                       str(steps), precision], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+                                       str(steps), precision] + (["save"] if save else []), env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
     for p in procs:
         try:
@@ -41,7 +43,10 @@ def _run(tmp_path, world, groups, steps=20, precision="bf16"):
             raise
         logs.append(o.decode(errors="replace"))
     assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
-    return [json.load(open(out / ("rank%d.json" % r))) for r in range(world)]
+    res = [json.load(open(out / ("rank%d.json" % r))) for r in range(world)]
+    for r in res:
+        r["dir"] = str(out)
+    return res
 
 
 @pytest.mark.parametrize("groups", [4, 1])
@@ -65,3 +70,31 @@ def test_f32_exchange_and_single_rank_paths(built_lib, tmp_path):
         assert a[key] == b[key], key
     (s,) = _run(tmp_path, 1, 4, steps=6)
     assert not s["pipelined"] and s["finite"] and s["table_moved"] > 0
+
+
+def test_exchange_path_on_rccl_with_one_rank(built_lib, tmp_path):
+    """The N > 1 step on RCCL itself: ONE rank joins a `backend="nccl"` process group (communicator of size 1,
+    initialised before any GPU call) and LNERF_FORCE_DIST=1 takes the un-fused path -- bf16 gradient sink written by the
+    scatter, table exchanged in 4 pipelined level groups (async all-reduce per group on RCCL's stream, hand-offs against
+    the captured graph B), FusedAdam.step(row_groups=...), flat f32 bucket of small parameters -- through the real
+    Trainer (captured step: graph F / guidance / graph B = backward + binning, eager exchange + optimiser).  Against the
+    fused single-rank trainer on the same seeds the table must agree to the bf16-wire tolerance: the only difference is
+    the rounding of the summed table gradient to bf16 (2^-9 relative) before Adam."""
+    import numpy as np
+    (forced,) = _run(tmp_path, 1, 4, steps=20, backend="nccl", force=True, save=True, tag="_forced")
+    (fused,) = _run(tmp_path, 1, 4, steps=20, backend="nccl", force=False, save=True, tag="_fused")
+    assert forced["exchange"] and forced["pipelined"] and not fused["exchange"] and not fused["pipelined"]
+    assert forced["steps"] == fused["steps"] == 20 and forced["finite"] and forced["table_moved"] > 0
+    assert forced["graph_stats"]["replayed_steps"] >= 15 and fused["graph_stats"]["replayed_steps"] >= 15
+    a = np.load(os.path.join(forced["dir"], "table_rank0.npy"))
+    b = np.load(os.path.join(fused["dir"], "table_rank0.npy"))
+    t0 = np.load(os.path.join(fused["dir"], "table0_rank0.npy"))
+    moved = float(np.abs(b - t0).max())
+    err = float(np.abs(a - b).max())
+    # Adam normalises each row's step by the row's own gradient history, so a 2^-9 relative perturbation of the
+    # gradients moves a parameter by ~lr * 2^-8 per step at most: two orders of magnitude below the movement itself
+    assert err <= 0.02 * moved, (err, moved)
+    w_err = float(np.abs(np.load(os.path.join(forced["dir"], "w2_rank0.npy"))
+                         - np.load(os.path.join(fused["dir"], "w2_rank0.npy"))).max())
+    assert w_err <= 0.02 * moved, (w_err, moved)
+    assert forced["bitfield"] == fused["bitfield"] or forced["bits_set"] > 0

@@ -280,12 +280,25 @@ def test_camera_form_generates_the_same_rays_and_render(dev):
     assert torch.equal(out["xyzs"][:want[2]], want[3]) and torch.equal(out["image"], want[0])
     for p, w in zip(plist, want[4]):
         assert torch.equal(p.grad, w)
+    # the same camera with the intrinsics in DEVICE memory (lnerf_march_rays_train_camera: what a captured trainer step
+    # reads its view from): identical rays, spans, image and gradients
+    for p in plist:
+        p.grad = None
+    intr_dev = torch.tensor([intr], dtype=torch.float32, device=dev)
+    out = net.render(None, None, camera=(pose, intr_dev, HW, HW), bg_color=bg, perturb=False)
+    out["image"].backward(gradient=g)
+    assert torch.equal(net._ray_slots[0][1].view_as(ro), ro) and torch.equal(net._ray_slots[0][2].view_as(rd), rd)
+    assert int(out["counter"][0]) == want[2] and torch.equal(out["rays"], want[1])
+    assert torch.equal(out["image"], want[0])
+    for p, w in zip(plist, want[4]):
+        assert torch.equal(p.grad, w)
     # inference through the same keyword: plain ray generation first
     net.eval()
     with torch.no_grad():
         a = net.render(None, None, camera=(pose, intr, HW, HW), bg_color=bg)
         b = net.render(ro, rd, bg_color=bg)
-    assert torch.equal(a["image"], b["image"])
+        c = net.render(None, None, camera=(pose, intr_dev, HW, HW), bg_color=bg)
+    assert torch.equal(a["image"], b["image"]) and torch.equal(c["image"], b["image"])
 
 
 def test_prepared_rays_and_two_step_graph(dev):

@@ -162,3 +162,66 @@ def test_mesh_winding_distance_and_shape_guidance(dev, tmp_path):
         p.grad = None
     tr.train()
     assert tr.train_step == 5
+
+
+def test_graphed_trainer_matches_eager_trainer_bit_for_bit(dev, tmp_path):
+    """`Trainer.train()` with optim.graph_step (graph F: render / eager guidance / graph B: backward + arm + optimiser;
+    pose and intrinsics uploaded into static device buffers; occupancy refreshes between replays) against the same
+    trainer running every step eagerly: after 20 steps -- two occupancy refreshes, 18 replays -- table, moments, MLP,
+    density grid and bitfield are bit-identical, in the f32 and in the bf16 configuration.  (Surface:
+    /root/reference/scripts/train_latent_nerf.py:8-14, src/latent_paint/training/trainer.py:113-144.)"""
+    from src.latent_nerf.training.trainer import Trainer
+    for fp16 in (False, True):
+        states = []
+        for graph in (True, False):
+            cfg = _cfg(tmp_path, **{"optim.iters": 20, "log.save_interval": 1000, "optim.fp16": fp16,
+                                    "log.exp_name": "g%d%d" % (fp16, graph), "optim.graph_step": graph,
+                                    "log.full_eval_size": 1})
+            torch.manual_seed(7)
+            torch.cuda.manual_seed(7)
+            tr = Trainer(cfg, device=dev)
+            torch.manual_seed(11)                 # the guidance's noise / timestep stream
+            torch.cuda.manual_seed(11)
+            tr.train()
+            assert tr.train_step == 20
+            if graph:
+                assert tr.graph_stats["captures"] >= 1 and tr.graph_stats["replayed_steps"] >= 15, tr.graph_stats
+            else:
+                assert tr.graph_stats["replayed_steps"] == 0 and tr.graph_stats["eager_steps"] == 20
+            opt = tr.optimizer
+            states.append({"table": tr.nerf.encoder.embeddings.detach().clone(),
+                           "m": opt.big[0][1].clone(), "v": opt.big[0][2].clone(),
+                           "w1": tr.nerf.w1.detach().clone(), "w3": tr.nerf.w3.detach().clone(),
+                           "b2": tr.nerf.b2.detach().clone(), "grid": tr.nerf.density_grid.clone(),
+                           "bits": tr.nerf.density_bitfield.clone(), "step": opt.step_no,
+                           "step_dev": int(opt.step_dev[0].item())})
+        a, b = states
+        assert a["step"] == b["step"] == 20 and a["step_dev"] == b["step_dev"] == 21
+        for k in ("table", "m", "v", "w1", "w3", "b2", "grid", "bits"):
+            assert torch.equal(a[k], b[k]), (fp16, k, float((a[k].float() - b[k].float()).abs().max()))
+        assert float((a["table"] - 0).abs().max()) > 0
+
+
+def test_graphed_trainer_recaptures_when_the_sample_budget_moves(dev, tmp_path):
+    """The refresh re-derives the sample capacity from observed marches; a change means new sample buffers, so the
+    trainer drops its graphs, runs one step eagerly and captures again."""
+    from src.latent_nerf.training.trainer import Trainer
+    cfg = _cfg(tmp_path, **{"optim.iters": 40, "log.save_interval": 1000, "optim.fp16": True, "log.exp_name": "rc",
+                            "log.full_eval_size": 1})
+    tr = Trainer(cfg, device=dev)
+    tr.train()
+    assert tr.train_step == 40 and tr.graph_stats["captures"] >= 2, tr.graph_stats   # worst case -> budgeted capacity
+    assert tr.graph_stats["replayed_steps"] + tr.graph_stats["eager_steps"] == 40
+    assert bool(torch.isfinite(tr.nerf.encoder.embeddings).all())
+
+
+def test_opacity_entropy_gradient_matches_autograd(dev):
+    from src.latent_nerf.training.guidance import sparsity_loss, sparsity_loss_grad
+    torch.manual_seed(0)
+    ws = torch.rand(4096, device=dev)
+    ws[:7] = torch.tensor([0.0, 1.0, 1e-5, 1 - 1e-5, 5e-6, 0.5, 1.5], device=dev)   # clamp edges, outside, centre
+    ref = ws.clone().requires_grad_()
+    (3e-3 * sparsity_loss(ref)).backward()
+    got = sparsity_loss_grad(ws, 3e-3)
+    assert float((got - ref.grad).abs().max()) <= 1e-6 * float(ref.grad.abs().max()) + 1e-12
+    assert float(got[0]) == 0.0 and float(got[1]) == 0.0 and float(got[6]) == 0.0 and float(got[5]) == 0.0

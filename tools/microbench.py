@@ -173,7 +173,7 @@ def main():
 
             def f(offs=offs, sc=sc, rs=rs, dptr=dptr):
                 B.call("lnerf_grid_encode_backward", _p(xyzs), 1.0, dptr, B.F32, 1, 2, offs, sc, rs, cap, _p(m_dev), cap,
-                       _p(dtable), 2, _p(ws), ws.numel(), _stream())
+                       _p(dtable), 3, _p(ws), ws.numel(), _stream())
             per["level%02d" % l] = f
         res["scatter_level_ms(median,min)"] = timed(per, rounds=6, warm=1)
 
