@@ -75,6 +75,10 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=5, help="timed CPU frames (~2 s each on 16 cores; + 1 warm-up)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed companions (f32 step, occupancy refresh)")
     ap.add_argument("--gather-variant", type=int, default=0)
+    ap.add_argument("--gridtype", default="hash", choices=["hash", "blocked"],
+                    help="layout of the hashed levels: hash = Instant-NGP (the headline); blocked = opt-in 4 x 2 x 2 vertex "
+                         "blocks per 64-byte line (for profiling the variant through the whole step; the default run reports "
+                         "it as the `blocked` companion)")
     ap.add_argument("--fuse-table-update", default="auto", choices=["auto", "0", "1"],
                     help="hash-table Adam step applied inside the scatter's reduce pass (single GPU only; auto = on at N=1)")
     ap.add_argument("--jitter-rng", default="kernel", choices=["kernel", "torch"],
@@ -97,6 +101,9 @@ def parse():
                          "hence off by default (profiles/r02_exp_ray_prefetch.jsonl)")
     ap.add_argument("--fragment-shadow", type=int, default=1,
                     help="1: the optimiser mirrors the MLP weights into their bf16 fragments (no per-step fragment build)")
+    ap.add_argument("--tail", type=int, default=1,
+                    help="1: the step ends with ONE launch (lnerf_step_tail: scatter finishing pass + MLP slab sum + Adam of "
+                         "the MLP's tensors + step-counter tick + clearing of the scatter's level maxima); 0: separate launches")
     ap.add_argument("--tune", default="", help="lnerf_set_tuning overrides for an experiment: key=value,key=value "
                     "(recorded in the output line; the default run sets none)")
     ap.add_argument("--force-dist", action="store_true",
@@ -114,7 +121,7 @@ def parse():
     return ap.parse_args()
 
 
-def build(dev, precision, variant, rank, table="f32", jitter_rng="kernel"):
+def build(dev, precision, variant, rank, table="f32", jitter_rng="kernel", gridtype="hash"):
     from src.latent_nerf.configs.render_config import RenderConfig
     from src.latent_nerf.models.network_grid import NeRFNetwork
     from src.latent_nerf.models.nerf_utils import intrinsics_from_fov, pose_from_angles
@@ -122,7 +129,7 @@ def build(dev, precision, variant, rank, table="f32", jitter_rng="kernel"):
     torch.manual_seed(0)
     cfg = RenderConfig(grid_size=GRID, train_h=H, train_w=W, mlp_precision=precision, table_dtype=table,
                        gather_variant=variant, noise_seed=(0x5EED + rank) if jitter_rng == "kernel" else None,
-                       max_samples=BENCH_CAPACITY)
+                       max_samples=BENCH_CAPACITY, gridtype=gridtype)
     net = NeRFNetwork(cfg)
     net.encoder.embeddings.data.normal_(0, 0.1)
     net = net.to(dev).train()
@@ -318,6 +325,43 @@ def load_pmc(build_tag):
     return d
 
 
+def companion_blocked(dev, rank, precision, steps=60, warmup=10):
+    """The opt-in `blocked` layout of the hashed levels (render.gridtype = "blocked": 4 x 2 x 2 vertex blocks in one
+    64-byte line of the bf16 table, 2.8 instead of 4.25 lines per sample and level) through the same captured step:
+    frames/s and the gather's kernel time beside the headline, which stays on Instant-NGP's hash."""
+    from src.latent_nerf.raymarching import backend as B
+    from src.latent_nerf.training.graph_step import GraphedTrainStep
+    from src.latent_nerf.training.optimizer import FusedAdam
+    net, pose, intr, bg, grad = build(dev, precision, 0, rank, precision, gridtype="blocked")
+    opt = FusedAdam(net.get_params(LR), betas=(0.9, 0.99), eps=1e-15, encoder=net.encoder, capturable=True,
+                    fuse_table_update=True, mlp=net)
+    step, fwd_bwd, opt_step, sync = make_step(net, pose, intr, bg, grad, opt, 1)
+    gstep = GraphedTrainStep(fwd_bwd, opt_step, list(net.parameters()), sync=sync, world=1, warmup=3,
+                             stream=torch.cuda.current_stream())
+    for _ in range(warmup):
+        gstep()
+    timer = KernelTimer(["lnerf_grid_encode_forward"])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if i % 8 == 7:
+            B.set_profile_hook(timer.hook)
+            out = step()
+            B.set_profile_hook(None)
+        else:
+            out = gstep()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    M = int(out["counter"][0].item())
+    g_ms = timer.mean_ms("lnerf_grid_encode_forward")
+    bps = 16 * 8 * 2 * 2 + 12 + 32 * 2 if precision == "bf16" else 1164
+    return {"value": steps / dt, "unit": "latent-frames/sec", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+            "samples_per_view": M, "gather_kernel_ms": g_ms, "gather_GBps": M * bps / (g_ms * 1e-3) / 1e9,
+            "gather_frac_of_hbm_peak": M * bps / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "what": "render.gridtype = blocked (hashed levels: block of 4 x 2 x 2 vertices = one 64-byte line of the bf16 "
+                    "table); a different table layout, NOT the headline's Instant-NGP hash"}
+
+
 def companion_f32(dev, rank, steps=40, warmup=6):
     """The exact-f32 parity configuration (f32 table, f32 features, exact-f32 MFMA MLP, 12-byte scatter records) through
     the same captured step: frames/s beside the headline (bf16) number."""
@@ -359,7 +403,7 @@ def trainer_companion(dev, steps, precision):
         cfg = apply_overrides(TrainConfig(), {
             "log.exp_name": "bench", "log.exp_root": root, "render.train_h": H, "render.train_w": W,
             "render.grid_size": GRID, "render.eval_h": 8, "render.eval_w": 8, "log.eval_size": 1, "log.full_eval_size": 1,
-            "log.save_interval": 10 ** 9, "optim.lr": LR, "optim.fp16": precision == "bf16", "guide.text": "bench",
+            "log.save_interval": 10 ** 9, "log.quiet": True, "optim.lr": LR, "optim.fp16": precision == "bf16", "guide.text": "bench",
             "optim.iters": warm})
         tr = Trainer(cfg, device=dev)
         sphere_scene(tr.nerf)
@@ -428,14 +472,15 @@ def main():
     main_stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(main_stream)
     table = args.precision if args.table == "auto" else args.table
-    net, pose, intr, bg, grad = build(dev, args.precision, args.gather_variant, rank, table, args.jitter_rng)
+    net, pose, intr, bg, grad = build(dev, args.precision, args.gather_variant, rank, table, args.jitter_rng, args.gridtype)
     from src.latent_nerf.training.optimizer import FusedAdam
     fuse = (not dist_on) if args.fuse_table_update == "auto" else (args.fuse_table_update == "1")
     if fuse and dist_on:
         raise SystemExit("--fuse-table-update 1 needs one rank without --force-dist (the gradient all-reduce sits between "
                          "backward and Adam)")
     opt = FusedAdam(net.get_params(LR if args.lr is None else args.lr), betas=(0.9, 0.99), eps=1e-15, encoder=net.encoder, capturable=True,
-                    fuse_table_update=fuse, mlp=net if args.fragment_shadow else None)
+                    fuse_table_update=fuse, mlp=net if args.fragment_shadow else None,
+                    tail=bool(args.tail) and fuse and bool(args.fragment_shadow))
     opt.grad_scale = 1.0 / world
     tr = args.precision if args.grad_transport == "auto" else args.grad_transport
     groups = args.exchange_groups if (dist_on and tr == "bf16") else 0
@@ -634,7 +679,9 @@ def main():
                         if do_refresh else {"in_timed_region": False}),
             "ray_prefetch": ("rays + occupancy march of step k+1 on a side stream during step k "
                              "(NeRFRenderer.prepare_rays, two buffer sets, two steps per captured graph)") if prefetch else None,
+            "gridtype": args.gridtype,
             "mlp_fragment_shadow": bool(opt.mlp is not None),
+            "step_tail": bool(opt._tail is not None),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -664,10 +711,11 @@ def main():
         res["build"] = build_tag
         if tuned:
             res["tuning_overrides"] = tuned
-        if not args.no_extras and not dist_on:
+        if not args.no_extras and not dist_on and args.gridtype == "hash":
             if args.trainer_steps > 0:
                 res["trainer"] = trainer_companion(dev, args.trainer_steps, args.precision)
                 res["trainer"]["frac_of_value"] = res["trainer"]["value"] / res["value"]
+            res["blocked"] = companion_blocked(dev, rank, args.precision)
             res["f32"] = companion_f32(dev, rank)
         if not args.no_cpu_baseline and not dist_on:
             res["cpu_baseline"] = cpu_baseline(args.cpu_frames)

@@ -186,6 +186,15 @@ size_t lnerf_grid_encode_backward_workspace_bytes(int num_levels, const int32_t 
  * launches something right before the scatter anyway can clear them there (lnerf_mlp_backward takes such a region)
  * and pass `variant | LNERF_SCATTER_CLEARED`. */
 #define LNERF_SCATTER_CLEARED 0x100
+/* variant | LNERF_GRID_BLOCKED (forward AND backward entry points, consistently): an opt-in layout of the HASHED levels
+ * (not Instant-NGP's): the vertex lattice is cut into blocks of 4 x 2 x 2, the block coordinate is hashed and the 16 rows
+ * of a block are consecutive: row = (hash(x >> 2, y >> 1, z >> 1) mod (rows / 16)) * 16 + (x & 3) + 4 (y & 1) + 8 (z & 1).
+ * One block = one 64-byte line of the bf16 table: a sample's 8 vertices touch 2.8 lines on average instead of 4.25.
+ * Dense levels are unchanged.  Restated in oracle/nerf_oracle.py (grid_corner_indices(blocked=True)). */
+#define LNERF_GRID_BLOCKED 0x400
+/* variant | LNERF_SCATTER_DEFER_FINISH (lnerf_grid_encode_backward_adam): the finishing pass of the sliced buckets is not
+ * launched -- lnerf_step_tail does it (with everything else that is left of the step) in one launch. */
+#define LNERF_SCATTER_DEFER_FINISH 0x200
 size_t lnerf_grid_scatter_clear_bytes(int num_levels, const int32_t *offsets_host, int64_t m_host);
 int lnerf_grid_encode_backward(const float *xyzs, float bound, const void *dfeat, int dfeat_dtype, int num_levels,
                                int level_dim, const int32_t *offsets_host, const float *scales_host,
@@ -264,6 +273,11 @@ int lnerf_mlp_forward(const void *feat, int feat_dtype, int64_t level_stride, co
  * clear_ptr / clear_bytes (may be NULL / 0; 4-byte granular): a small region the slab-reduction launch also zeroes
  * -- e.g. the cursors of the scatter that follows (LNERF_SCATTER_CLEARED): one dispatch less per step. */
 #define LNERF_MLP_FRAGMENTS_READY 0x100
+/* precision | LNERF_MLP_DEFER_REDUCE: the per-workgroup gradient slabs stay in `workspace` (lnerf_mlp_backward_slabs() of
+ * them); the d* outputs are not written (may be NULL), clear_bytes must be 0.  lnerf_step_tail sums the slabs and applies
+ * the Adam step of the six tensors. */
+#define LNERF_MLP_DEFER_REDUCE 0x200
+int lnerf_mlp_backward_slabs(int64_t m_host, int precision);
 #define LNERF_MLP_FRAGMENT_BYTES (36 * 1024) /* the bf16 weight-fragment image at the head of the workspace */
 size_t lnerf_mlp_backward_workspace_bytes(int out_dim);
 int lnerf_mlp_backward(const void *feat, int feat_dtype, int64_t level_stride, const float *xyzs, const float *w1,
@@ -385,6 +399,30 @@ int lnerf_adam_step_multi_shadow(int count, float *const *p_host, float *const *
                                  float beta2, float eps, int step, const int32_t *step_dev, float grad_scale,
                                  int zero_grad, const int32_t *const *map_host, void *shadow_bf16,
                                  lnerf_stream_t stream);
+/* ---- the TAIL of a single-GPU optimisation step, one launch (a dependent dispatch in a replayed graph costs ~4.5 us
+ * whatever it computes; three of them sat behind the scatter for a few microseconds of work):
+ *   - finishing pass of the sliced buckets of the hash-grid scatter, with the fused Adam step of their rows
+ *     (after lnerf_grid_encode_backward_adam(variant | LNERF_SCATTER_DEFER_FINISH); num_levels = 0: skipped);
+ *   - sum of the MLP's gradient slabs (after lnerf_mlp_backward(precision | LNERF_MLP_DEFER_REDUCE)) in the fixed order
+ *     of the ordinary reduction, and the Adam step of w1, b1, w2, b2, w3, b3 straight from the sums
+ *     (params / exp_avg / exp_avg_sq: host arrays of six device pointers; maps_host: optional, the three fragment maps of
+ *     lnerf_mlp_fragment_maps -- the updated weights are mirrored into the fragment image at the head of mlp_workspace;
+ *     mlp_workspace = NULL: skipped);
+ *   - LNERF_TAIL_TICK: *step_dev += 1 once every workgroup has read it (needs the scatter part: the arrival counters
+ *     live in the header of the scatter workspace, which lnerf_grid_encode_backward_workspace_bytes() includes and a
+ *     fresh workspace must have zeroed once);
+ *   - LNERF_TAIL_CLEAR_SCATTER: the scatter's level maxima (first lnerf_grid_scatter_clear_bytes() bytes of its
+ *     workspace) are zero on exit, i.e. the NEXT scatter call may pass LNERF_SCATTER_CLEARED.
+ * Same arithmetic as the separate launches (csrc/adam_shared.h): parameters and moments are bit-identical. */
+#define LNERF_TAIL_TICK 1
+#define LNERF_TAIL_CLEAR_SCATTER 2
+int lnerf_step_tail(int num_levels, int level_dim, const int32_t *offsets_host, const float *scales_host,
+                    const int32_t *res_host, int64_t m_host, int variant, void *scatter_workspace,
+                    size_t scatter_workspace_bytes, float *dtable_zero, float *table, float *exp_avg, float *exp_avg_sq,
+                    void *shadow_bf16, float table_lr, const void *mlp_workspace, size_t mlp_workspace_bytes,
+                    int mlp_precision, int out_dim, float *const *params_host, float *const *exp_avg_host,
+                    float *const *exp_avg_sq_host, float mlp_lr, const int32_t *const *maps_host, float beta1, float beta2,
+                    float eps, int step, int32_t *step_dev, float grad_scale, int flags, lnerf_stream_t stream);
 int lnerf_cast_f32_to_bf16(const float *src, void *dst, int64_t n, lnerf_stream_t stream);
 
 #ifdef __cplusplus

@@ -131,6 +131,7 @@ struct GridMeta {
     int offsets[LNERF_MAX_LEVELS + 1];
     float scales[LNERF_MAX_LEVELS];
     int res[LNERF_MAX_LEVELS];
+    int blocked;   // LNERF_GRID_BLOCKED: hashed levels keep 4 x 2 x 2 vertex blocks together (grid.hip corner_rows)
 };
 
 }  // namespace lnerf

@@ -12,6 +12,7 @@
 //            tables of its own levels instead of all 16.
 #include "common.h"
 #include "adam_shared.h"
+#include "mlp_shared.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -30,9 +31,14 @@ __device__ __forceinline__ uint32_t grid_index(uint32_t x, uint32_t y, uint32_t 
 }
 
 // rows of the 8 vertices of a cell at once: the two integer multiplies of the spatial hash (quarter-rate
-// VALU) are shared by all corners ((y+1)*P == y*P + P mod 2^32), dense levels add strides to one base
+// VALU) are shared by all corners ((y+1)*P == y*P + P mod 2^32), dense levels add strides to one base.
+// blocked (LNERF_GRID_BLOCKED, an opt-in layout of the HASHED levels, not Instant-NGP's): the lattice is cut into blocks
+// of 4 x 2 x 2 vertices, the BLOCK coordinate is hashed and a block's 16 rows are consecutive --
+//     row = (hash(x >> 2, y >> 1, z >> 1) mod (hsize / 16)) * 16 + (x & 3) + 4 (y & 1) + 8 (z & 1)
+// -- so that a block is one 64-byte line of the bf16 table: a cell's 8 vertices touch 1.25 x 1.5 x 1.5 = 2.8 lines on
+// average instead of 4.25 (x pairs share a line either way; here y and z neighbours do half the time).
 __device__ __forceinline__ void corner_rows(uint32_t gx, uint32_t gy, uint32_t gz, uint32_t res, uint32_t hsize,
-                                            uint32_t row[8]) {
+                                            uint32_t row[8], bool blocked = false) {
     const uint32_t stride = res + 1;
     const uint64_t cube = (uint64_t)stride * stride * stride;
     if (cube <= (uint64_t)hsize) {  // wave-uniform
@@ -41,6 +47,30 @@ __device__ __forceinline__ void corner_rows(uint32_t gx, uint32_t gy, uint32_t g
         const uint32_t base = gx + __umul24(gy, stride) + __umul24(gz, s2);
 #pragma unroll
         for (int c = 0; c < 8; ++c) row[c] = base + (c & 1) + ((c >> 1) & 1) * stride + ((c >> 2) & 1) * s2;
+        return;
+    }
+    if (blocked) {  // wave-uniform
+        const uint32_t nblk = hsize >> 4;
+        const uint32_t x1 = gx + 1u;
+        const uint32_t hx[2] = {gx >> 2, x1 >> 2};
+        const uint32_t y0 = (gy >> 1) * 2654435761u, z0 = (gz >> 1) * 805459861u;
+        // (y + 1) >> 1 is the next block exactly when y is odd
+        const uint32_t hy[2] = {y0, (gy & 1u) ? y0 + 2654435761u : y0};
+        const uint32_t hz[2] = {z0, (gz & 1u) ? z0 + 805459861u : z0};
+        const uint32_t wx[2] = {gx & 3u, x1 & 3u};
+        const uint32_t wy[2] = {(gy & 1u) << 2, ((gy + 1u) & 1u) << 2};
+        const uint32_t wz[2] = {(gz & 1u) << 3, ((gz + 1u) & 1u) << 3};
+        if ((nblk & (nblk - 1u)) == 0u) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                row[c] = (((hx[c & 1] ^ hy[(c >> 1) & 1] ^ hz[(c >> 2) & 1]) & (nblk - 1u)) << 4) |
+                         (wx[c & 1] | wy[(c >> 1) & 1] | wz[(c >> 2) & 1]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                row[c] = (((hx[c & 1] ^ hy[(c >> 1) & 1] ^ hz[(c >> 2) & 1]) % nblk) << 4) |
+                         (wx[c & 1] | wy[(c >> 1) & 1] | wz[(c >> 2) & 1]);
+        }
         return;
     }
     const uint32_t hx[2] = {gx, gx + 1u};
@@ -256,7 +286,7 @@ k_grid_forward(const float *__restrict__ xyzs, float bound, const TT *__restrict
         p.gx = p.gy = p.gz = 0u; p.fx = p.fy = p.fz = 0.f;
         if (valid) p = level_pos(xyzs, m, bound, scale);
         uint32_t rows[8];
-        corner_rows(p.gx, p.gy, p.gz, res, hsize, rows);
+        corner_rows(p.gx, p.gy, p.gz, res, hsize, rows, meta.blocked != 0);
         bool fetch = valid;
         int src = lane;
         if (dedup) {
@@ -328,7 +358,7 @@ k_grid_backward_atomic(const float *__restrict__ xyzs, float bound, const TG *__
         const LevelPos p = level_pos(xyzs, m, bound, scale);
         const float2 gg = Feat2<TG>::load(dfeat + ((int64_t)l * level_stride + m) * 2, 0);
         uint32_t rows[8];
-        corner_rows(p.gx, p.gy, p.gz, res, hsize, rows);
+        corner_rows(p.gx, p.gy, p.gz, res, hsize, rows, meta.blocked != 0);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const uint32_t bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
@@ -344,21 +374,26 @@ k_grid_backward_atomic(const float *__restrict__ xyzs, float bound, const TG *__
 }
 
 // ------------------------------------------------------------------------------------------
-// Backward, variant 2: two-pass bucketed scatter (no global float atomics on the hot path).
+// Backward, variants 2 / 3: two-pass bucketed scatter -- no global atomics anywhere.
 //
 // Scattered 8-byte float atomics run at the memory side at ~20 G requests/s chip-wide
 // (MI355X_MICROARCH.md "Global float atomics"): 55 M vertex updates per frame cost ~10 ms that
 // way.  Instead every level's table is cut into buckets of BK_ROWS consecutive rows (64 KiB of
-// f32x2 accumulators = one LDS tile):
-//   pass 1 (k_scatter_bin)    one thread per (sample, level) computes its 8 (row, w*g) records (runs of
-//                             samples in one cell merged first on coarse levels), groups the workgroup's
-//                             records by bucket in LDS, reserves a span per touched bucket with ONE returning
-//                             global atomic, and appends the records to the bucket's region with plain stores;
-//   pass 2 (k_scatter_reduce) one workgroup per (bucket, slice) streams its records (coalesced
-//                             16 B/lane), accumulates them with LDS float atomics and adds the
-//                             64 KiB tile to the gradient table with coalesced stores.
-// A bucket that overflows its region falls back to global atomics for the excess records, so the
-// result is always complete.
+// 64-bit accumulators = one LDS tile):
+//   pass 1 (k_scatter_bin)    a work ITEM is 512 consecutive samples of one level.  One thread per sample computes its
+//                             8 (row, w*g) records (runs of samples in one cell merged first on coarse levels) and the
+//                             workgroup groups them by bucket in an LDS stage.  The stage IS the item's chunk of the
+//                             record region: it is copied out as it stands (16 bytes per lane, perfectly coalesced),
+//                             next to one table entry per (item, bucket) = (first slot, count) of the bucket's SEGMENT
+//                             inside the chunk.  No reservations, no cursors, no head-room, no overflow path: an item
+//                             owns ITEM_RECS = 4096 record slots, exactly what 512 samples can emit.
+//   pass 2 (k_scatter_reduce) one workgroup per (bucket, slice) walks the items' segments of its bucket (the wave's
+//                             lanes take consecutive records of the concatenated segments), accumulates them with
+//                             64-bit fixed-point LDS atomics and finishes its 4096 rows (gradient add, bf16 output, or
+//                             the fused Adam step).
+// Every record has a fixed place that depends on the input only, every sum is an exact integer sum: the
+// result is bitwise reproducible for ANY input (round 2's layout reserved spans with global atomics and fell back to
+// float atomics when a bucket's region overflowed).
 constexpr int BK_SHIFT = 12, BK_ROWS = 1 << BK_SHIFT;  // 4096 rows * 8 B = 32 KiB of accumulators
 // threads (= samples) per binning tile: template parameter BIN_T of k_scatter_bin (256 or 512)
 constexpr int BK_MAX_PER_LEVEL = 256;                   // LDS counters per workgroup tile
@@ -402,27 +437,39 @@ struct alignas(8) Rec8 {
     __device__ __forceinline__ float b() const { return __uint_as_float((hi >> 6) << 6); }
 };
 static_assert(BK_SHIFT == 12, "Rec8 stores 12 row bits");
+// "This record is needed HERE, by every lane": an empty asm that reads the registers.  A load whose result is only used
+// under a lane predicate is otherwise SUNK into the predicated block by the compiler -- one load, one s_waitcnt
+// vmcnt(0), one use at a time instead of a batch of loads in flight (measured on the reduce pass: 2-3x its time).
+__device__ __forceinline__ void pin_record(Rec8 &r) { asm volatile("" : "+v"(r.lo), "+v"(r.hi)); }
+__device__ __forceinline__ void pin_record(Rec12 &r) { asm volatile("" : "+v"(r.row), "+v"(r.v0), "+v"(r.v1)); }
 
-// Distance between two buckets' cursors (and two levels' maxima) in int32 words: one 128-byte line each.  Device-scope
-// atomics execute at the memory side, and those that hit ONE line are served one after the other whatever word they
-// name: with the cursors packed (32 to a line, a level's 128 on 4 lines) the binning pass's 1.3 M reservations per
-// launch queued on 64 lines -- same-box A/B of the bench step: scatter 0.274 -> 0.254 ms with a line per cursor
-// (64-byte spacing: no change; 256-byte: same as 128).
+// Distance between two levels' maxima in uint32 words: one 128-byte line each (device-scope atomics that hit ONE line
+// are served one after the other at the memory side, whatever words they name).
 #ifndef LNERF_CUR_STRIDE
 #define LNERF_CUR_STRIDE 32
 #endif
 constexpr int CUR_STRIDE = LNERF_CUR_STRIDE;
+constexpr int ITEM_SAMPLES = 512;                 // samples per work item of pass 1 (= threads per workgroup)
+constexpr int ITEM_RECS = ITEM_SAMPLES * 8;       // record slots of an item's chunk
+// workspace header (bytes): [0, HDR_GMAX) level maxima (cleared before pass 1), then the item count of the last pass 1,
+// then one record count per bucket (written by pass 2 for the finishing pass)
+constexpr size_t HDR_GMAX_BYTES = (size_t)LNERF_MAX_LEVELS * CUR_STRIDE * sizeof(uint32_t);
+constexpr size_t HDR_ITEMS_OFF = HDR_GMAX_BYTES;            // int32 [1] (+ padding to 128 bytes)
+constexpr size_t HDR_ARRIVE_OFF = HDR_GMAX_BYTES + 128;     // int32 [9 x CUR_STRIDE]: arrival counters of the step's tail
+                                                            // launch (root + 8 shards, a line each; zero between launches)
+constexpr size_t HDR_BUCKETN_OFF = HDR_ARRIVE_OFF + 9 * CUR_STRIDE * sizeof(int32_t);    // int32 [buckets]
 
 struct BucketMeta {
     int nb[LNERF_MAX_LEVELS];            // buckets per level
     int bstart[LNERF_MAX_LEVELS + 1];    // first global bucket id of the level
-    int cap[LNERF_MAX_LEVELS];           // record capacity of each bucket of the level
-    int slices[LNERF_MAX_LEVELS];        // pass-2 workgroups per bucket
+    int slices[LNERF_MAX_LEVELS];        // pass-2 workgroups per bucket (worst case; the active count is decided on the device)
     int compact[LNERF_MAX_LEVELS];       // 1: merge runs of equal rows inside a wavefront before binning
     int wgstart[LNERF_MAX_LEVELS + 1];   // first pass-2 workgroup of the level
-    long long rstart[LNERF_MAX_LEVELS];  // first record slot of the level's region
     int pstart[LNERF_MAX_LEVELS];        // sliced levels: first partial-sum tile of the level (pass 2 -> finish)
     int fstart[LNERF_MAX_LEVELS];        // sliced levels: first bucket index in the finishing pass's grid
+    int n_items;                         // item capacity: ceil(m_host / ITEM_SAMPLES)
+    // chunk of (level l, item t): record slot ((int64)l * n_items + t) * ITEM_RECS;
+    // segment table entry of (l, t, bucket b): ((int64)bstart[l] * n_items + (int64)t * nb[l] + b)
 };
 
 // sum of v over this lane's run, valid on the run's tail lane: difference of wave prefix sums
@@ -474,25 +521,16 @@ __device__ unsigned long long g_bin_stamps[16];
 
 // ---- pass 1: k_scatter_bin ---------------------------------------------------------------------------------------
 // A work item is BIN_T = 512 consecutive samples of ONE level; PERSISTENT workgroups (3 per CU) stride over the
-// tile-major (tile, level) list, the level rotated by one per round (every workgroup sees every level; the levels'
-// bucket cursors are hit evenly), and fetch the next item's inputs while the current one is processed.  rocprofv3
-// (profiles/r02_pmc_scatter*.json) shows the pass bound by vector-ALU issue -- ~590 VALU instructions per wavefront
-// and item in round 1's form, 73 % of the SIMD cycles -- and by the per-item chain of LDS / global round trips, not by
-// bytes.  Hence, in this form:
-//   * hashed levels (rows of a wavefront spread over all buckets): records ranked with LDS counters, grouped by
-//     bucket in an LDS stage (exact packing from a count scan), ONE returning global atomic per touched bucket
-//     reserves the span, coalesced copy-out; two barriers per item (counters double-buffered);
-//   * dense levels (rows = x + y s + z s^2: a wavefront of consecutive samples touches a handful of buckets): no
-//     stage, no count scan and no workgroup barrier -- every wavefront ranks its records with a private LDS
-//     histogram, reserves its own spans and stores the records directly (consecutive ranks = consecutive slots);
-//   * the level's largest |value| (fixed-point scale of pass 2) is bounded from |g| (weights <= 1, runs <= 64
-//     samples) instead of being measured on the 16 products, one LDS maximum per level and workgroup; records are
-//     packed with bit-field inserts; run sums use fused DPP adds.
-constexpr int BIN_T = 512;                 // threads per workgroup = samples per item
-constexpr int BIN_WAVES = BIN_T / 64;
-// dense levels with this many buckets take the direct path (fewer: every wavefront's reservation would hit the same
-// one or two cursor words -- one word takes ~88 returning atomics per microsecond; more: the per-wave histogram)
-constexpr int BIN_DIRECT_MIN = 8, BIN_DIRECT_NB = 64;
+// tile-major (tile, level) list, the level rotated by one per round, and fetch the next item's inputs while the current
+// one is processed.  Per item: cell, rows, runs -> every record ranked inside its bucket with a returning LDS counter
+// -> (the values w * g, run sums on coarse levels, are computed behind those atomics) -> barrier -> count scan (every
+// wave computes it: no idle waves, no extra barrier) -> records written to their slot of the LDS stage -> barrier ->
+// the stage copied out as the item's chunk, 16 bytes per lane, and the (first slot, count) of every bucket's segment
+// written to the segment table.  Nothing in the item waits for a global round trip: the only global accesses are the
+// prefetch of the next item's inputs and the two coalesced stores at the end.
+// The level's largest |value| (fixed-point scale of pass 2) is bounded from |g| (weights <= 1, runs <= 64 samples),
+// one LDS maximum per level and workgroup; records are packed with bit-field inserts; run sums use fused DPP adds.
+constexpr int BIN_T = ITEM_SAMPLES;        // threads per workgroup = samples per item
 
 // fast f32 -> 26-bit float (round to nearest, ties away from zero: one add on the sign-magnitude bits; symmetric in
 // the sign, and a tie is one value in 64), valid for finite values
@@ -564,38 +602,29 @@ __device__ __forceinline__ void wave_run_sums_x16(float (&a)[8], float (&b)[8], 
 // lambdas below take it by value, so the argument structs are never copied to scratch)
 struct BinLevel {
     float scale;
-    uint32_t res, hsize, off;
-    int level, nb, cap, b0;
-    long long rstart;
-    bool compact, direct;
+    uint32_t res, hsize;
+    int level, nb, b0;
+    bool compact;
 };
 #define LNERF_BIN_LEVEL(lv)                                                                                          \
     BinLevel {                                                                                                       \
-        meta.scales[lv], (uint32_t)meta.res[lv], (uint32_t)(meta.offsets[(lv) + 1] - meta.offsets[lv]),              \
-            (uint32_t)meta.offsets[lv], (lv), bm.nb[lv], bm.cap[lv], bm.bstart[lv], bm.rstart[lv], bm.compact[lv] != 0, \
-            (uint64_t)(meta.res[lv] + 1) * (meta.res[lv] + 1) * (meta.res[lv] + 1) <=                                 \
-                    (uint64_t)(meta.offsets[(lv) + 1] - meta.offsets[lv]) &&                                          \
-                bm.nb[lv] >= BIN_DIRECT_MIN && bm.nb[lv] <= BIN_DIRECT_NB                                             \
+        meta.scales[lv], (uint32_t)meta.res[lv], (uint32_t)(meta.offsets[(lv) + 1] - meta.offsets[lv]), (lv),        \
+            bm.nb[lv], bm.bstart[lv], bm.compact[lv] != 0                                                            \
     }
 
 template <typename REC>
 __global__ void __launch_bounds__(BIN_T, (sizeof(REC) == 8 ? 6 : 4))
 k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restrict__ dfeat, GridMeta meta, BucketMeta bm,
-              int64_t m_host, const int32_t *__restrict__ m_dev, int64_t level_stride, int32_t *__restrict__ cursor,
-              unsigned int *__restrict__ gmax, REC *__restrict__ recs, float *__restrict__ dtable, int skip_zero) {
-    __shared__ int s_cnt[2][BK_MAX_PER_LEVEL];  // records of the item per bucket (two sets: hashed items alternate)
-    __shared__ int s_base[BK_MAX_PER_LEVEL];    // first slot reserved in the bucket's global region
-    __shared__ int s_off[BK_MAX_PER_LEVEL];     // first slot of the bucket in the LDS stage
-    __shared__ int s_dest[BK_MAX_PER_LEVEL];    // global slot of the bucket's first staged record, minus its stage offset
-    __shared__ int s_ovf[2];                    // some bucket of this item ran past its region
-    __shared__ REC s_stage[BIN_T * 8];          // the item's records, grouped by bucket (48 KiB, 32 KiB packed)
-    __shared__ uint8_t s_bkt[REC::kPacked ? BIN_T * 8 : 4];  // packed records do not name their bucket: kept beside
-    __shared__ int s_wave[BIN_WAVES][BIN_DIRECT_NB];          // dense levels: per-wave histogram, then per-wave bases
+              int64_t m_host, const int32_t *__restrict__ m_dev, int64_t level_stride, unsigned int *__restrict__ gmax,
+              int32_t *__restrict__ items_out, uint32_t *__restrict__ segtab, REC *__restrict__ recs, int skip_zero) {
+    __shared__ int s_cnt[2][BK_MAX_PER_LEVEL];  // records of the item per bucket (two sets: items alternate)
+    __shared__ int s_off[BK_MAX_PER_LEVEL];     // first slot of the bucket's segment in the stage (= in the chunk)
+    __shared__ __attribute__((aligned(16))) REC s_stage[ITEM_RECS];  // the item's chunk (48 KiB, 32 KiB packed)
     __shared__ unsigned int s_lmax[LNERF_MAX_LEVELS];         // per level: bound of |value| seen by this workgroup
     int32_t M = (int32_t)m_host;
     if (m_dev) { const int32_t md = *m_dev; M = md < M ? md : M; }
     const int L = meta.num_levels;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     // item k of this workgroup: tile t0 + k * tstep, level (l0 + k) mod L   (gridDim.x is a multiple of L)
     const int tstep = gridDim.x / L;
     const float two_b = 2.0f * bound;
@@ -605,9 +634,8 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restri
     asm("v_readfirstlane_b32 %0, %1" : "=s"(inv_two_b) : "v"(1.0f / two_b));
     for (int i = tid; i < 2 * BK_MAX_PER_LEVEL; i += BIN_T) (&s_cnt[0][0])[i] = 0;
     if (tid < LNERF_MAX_LEVELS) s_lmax[tid] = 0u;
-    if (tid < 2) s_ovf[tid] = 0;
-    // ---- inputs of an item (5 dwords per lane), fetched while the previous item is processed (the pass waits on
-    // memory round trips, not on bytes)
+    if (blockIdx.x == 0 && tid == 0) *items_out = (M + BIN_T - 1) / BIN_T;  // pass 2 walks exactly these items
+    // ---- inputs of an item (5 dwords per lane), fetched while the previous item is processed
     float n_x = 0.f, n_y = 0.f, n_z = 0.f;
     float2 n_g = make_float2(0.f, 0.f);
     auto fetch = [&](int lv, int tl) __attribute__((always_inline)) {
@@ -619,24 +647,16 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restri
             n_x = xyzs[(int64_t)mm * 3]; n_y = xyzs[(int64_t)mm * 3 + 1]; n_z = xyzs[(int64_t)mm * 3 + 2];
         }
     };
-    // a record that cannot be placed in its bucket's region: finished with global float atomics
-    auto spill = [&](uint32_t level_off, const REC &r, int b) __attribute__((always_inline)) {
-        float *lt = dtable + (int64_t)level_off * 2;
-        const int64_t full_row = ((int64_t)b << BK_SHIFT) | r.row_in_bucket();
-        atomicAdd(lt + full_row * 2, r.a());
-        atomicAdd(lt + full_row * 2 + 1, r.b());
-    };
     int l = (int)(blockIdx.x % L);
     int tile = (int)(blockIdx.x / L);
     bool have = tile * BIN_T < M;
     if (have) fetch(l, tile);
     BIN_STAMP_INIT();
     __syncthreads();
-    int hk = 0;  // hashed items so far (selects the counter set)
+    int hk = 0;  // items so far (selects the counter set)
     while (have) {
         const BinLevel lv = LNERF_BIN_LEVEL(l);
-        const int nb = lv.nb, cap = lv.cap;
-        REC *lrec = recs + lv.rstart;
+        const int nb = lv.nb;
         const int l_next = l + 1 == L ? 0 : l + 1;
         const int tile_next = tile + tstep;
         const bool have_next = tile_next * BIN_T < M;
@@ -667,7 +687,7 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restri
                 p.gx = (uint32_t)(int)flx; p.gy = (uint32_t)(int)fly; p.gz = (uint32_t)(int)flz;
                 p.fx = px - flx; p.fy = py - fly; p.fz = pz - flz;
             }
-            corner_rows(p.gx, p.gy, p.gz, lv.res, lv.hsize, row);
+            corner_rows(p.gx, p.gy, p.gz, lv.res, lv.hsize, row, meta.blocked != 0);
             if (lv.compact) {  // wave-uniform: coarse level, merge runs of samples in the same cell first
                 // (the lane number is made opaque per item: the 64-bit lane masks derived from it are cheaper to
                 // recompute than to keep -- hoisted out of the item loop they were spilled to scratch)
@@ -684,8 +704,8 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restri
             for (int c = 0; c < 8; ++c) asm("" : "=v"(row[c]));
             asm("" : "=v"(p.gx), "=v"(p.gy), "=v"(p.gz), "=v"(p.fx), "=v"(p.fy), "=v"(p.fz));
         }
-        // ---- D (a lambda: placed behind the reservations on hashed levels): the values w * g (run sums on coarse
-        // levels), packed into records; the bound of |value| goes to the level's LDS maximum
+        // ---- D (a lambda: placed behind the ranking atomics): the values w * g (run sums on coarse levels), packed
+        // into records; the bound of |value| goes to the level's LDS maximum
         REC rec[8];
         auto values = [&]() __attribute__((always_inline)) {
             if (!wave_live) return;
@@ -719,8 +739,8 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restri
             }
         };
         // ranks the wavefront's records of corner c in `counters` (LDS): where the lanes of a wave mostly target one or
-        // two buckets (dense levels, tiny tables) one LDS atomic per (wave, bucket) instead of one per lane -- same-address
-        // LDS atomics serialise
+        // two buckets (tiny tables) one LDS atomic per (wave, bucket) instead of one per lane -- same-address LDS
+        // atomics serialise
         auto rank_by_ballot = [&](int *counters, int c) __attribute__((always_inline)) {
             const int b = (int)(row[c] >> BK_SHIFT);
             int rk = 0;
@@ -739,73 +759,26 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restri
         };
         BIN_STAMP(1);
         const int cur = hk & 1;
-        // the rank of a record inside its bucket -- among the item's records (hashed) / the wavefront's (dense), < 4096 --
-        // is kept in bits [20, 32) of its row (rows of a level are < 2^20: at most 256 buckets of 4096 rows)
+        ++hk;
+        // ---- B: the rank of a record inside its bucket, among the item's records (< 4096), is kept in bits [20, 32) of
+        // its row (rows of a level are < 2^20: at most 256 buckets of 4096 rows)
         constexpr uint32_t ROW_MASK = (1u << 20) - 1u;
-        int my_base = 0;   // hashed: thread b holds the reserved base of bucket b; dense: lane b the wave's span base
-        if (lv.direct) {
-            // ================= dense level: every wavefront places its own records, no workgroup barrier ==========
-            int *hist = s_wave[wave];
-            if (lane < BIN_DIRECT_NB) hist[lane] = 0;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (LDS is in order within a wave)
-            if (lv.compact) {  // few lanes emit (run tails): plain per-lane counter increments (measured 17 us faster)
-                if (emit) {
+        if (nb <= 32 && !lv.compact) {  // wave-uniform: every lane emits into one or two buckets
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) row[c] |= (uint32_t)atomicAdd(&hist[row[c] >> BK_SHIFT], 1) << 20;
-                }
-            } else {
+            for (int c = 0; c < 8; ++c) rank_by_ballot(s_cnt[cur], c);
+        } else if (emit) {
 #pragma unroll
-                for (int c = 0; c < 8; ++c) rank_by_ballot(hist, c);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane < nb) {
-                const int n = hist[lane];
-                if (n) my_base = atomicAdd(&cursor[(lv.b0 + lane) * CUR_STRIDE], n);  // the wave's span in bucket `lane`
-            }
-        } else {
-            // ================= hashed level ==================================================================
-            ++hk;
-            // ---- B: rank every record inside its bucket (item-local)
-            if (nb <= 32 && !lv.compact) {  // wave-uniform: every lane emits into one or two buckets
-#pragma unroll
-                for (int c = 0; c < 8; ++c) rank_by_ballot(s_cnt[cur], c);
-            } else if (emit) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) row[c] |= (uint32_t)atomicAdd(&s_cnt[cur][row[c] >> BK_SHIFT], 1) << 20;
-            }
-            BIN_STAMP(2);
-            __syncthreads();  // barrier 1: the item's bucket counts are final
-            BIN_STAMP(3);
-            // (the other set was last read before barrier 3 of the previous hashed item: clear it for the next one)
-            for (int i = tid; i < BK_MAX_PER_LEVEL; i += BIN_T) s_cnt[cur ^ 1][i] = 0;
-            if (tid == 0) s_ovf[cur ^ 1] = 0;
-            // ---- C: ONE returning global atomic per touched bucket reserves its span
-            if (tid < nb) {
-                const int c = s_cnt[cur][tid];
-                if (c) my_base = atomicAdd(&cursor[(lv.b0 + tid) * CUR_STRIDE], c);
-            }
+            for (int c = 0; c < 8; ++c) row[c] |= (uint32_t)atomicAdd(&s_cnt[cur][row[c] >> BK_SHIFT], 1) << 20;
         }
-        // the next item's inputs follow the reservations into the memory queue; both are consumed after the arithmetic
+        BIN_STAMP(2);
+        // the next item's inputs go into the memory queue now; they are consumed at the top of the next iteration
         if (have_next) fetch(l_next, tile_next);
         values();
         BIN_STAMP(4);
-        if (lv.direct) {
-            int *wbase = s_wave[wave];
-            if (lane < BIN_DIRECT_NB) wbase[lane] = my_base;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (emit) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const int b = (int)((row[c] & ROW_MASK) >> BK_SHIFT);
-                    const int pos = wbase[b] + (int)(row[c] >> 20);
-                    if (pos < cap) lrec[(int64_t)b * cap + pos] = rec[c];
-                    else spill(lv.off, rec[c], b);
-                }
-            }
-            BIN_STAMP(8);
-            l = l_next; tile = tile_next; have = have_next;
-            continue;
-        }
+        __syncthreads();  // barrier 1: the item's bucket counts are final
+        BIN_STAMP(3);
+        // (the other set was last read behind barrier 2 of the previous item: clear it for the next one)
+        for (int i = tid; i < BK_MAX_PER_LEVEL; i += BIN_T) s_cnt[cur ^ 1][i] = 0;
         // ---- E: exclusive scan of the bucket counts.  EVERY wave computes it (4 buckets per lane, one DPP scan) and
         // writes the same offsets: a wave reads s_off only after its own writes, so no barrier and no idle waves
         int total;
@@ -827,52 +800,34 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restri
             }
             total = __builtin_amdgcn_readlane(inc, 63);
         }
-        // ---- F: group the records by bucket in LDS
+        // ---- F: the records into their slot of the stage = of the chunk
         if (emit) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const int b = (int)((row[c] & ROW_MASK) >> BK_SHIFT);
-                const int slot = s_off[b] + (int)(row[c] >> 20);
-                s_stage[slot] = rec[c];
-                if (REC::kPacked) s_bkt[slot] = (uint8_t)b;
+                s_stage[s_off[b] + (int)(row[c] >> 20)] = rec[c];
             }
         }
         BIN_STAMP(5);
-        if (tid < nb) {  // waits for the reservations
-            s_base[tid] = my_base;
-            s_dest[tid] = tid * cap + my_base - s_off[tid];
-            if (my_base + s_cnt[cur][tid] > cap) s_ovf[cur] = 1;
-        }
-        BIN_STAMP(6);
-        __syncthreads();  // barrier 3: stage and destinations complete
+        __syncthreads();  // barrier 2: the stage is complete
         BIN_STAMP(7);
         // the prefetched inputs are pinned in registers here, so that the next item starts without waiting for the
         // stores below to be acknowledged (one in-order memory counter covers loads and stores)
         asm volatile("" : "+v"(n_g.x), "+v"(n_g.y), "+v"(n_x), "+v"(n_y), "+v"(n_z));
-        // ---- G: copy out: consecutive lanes -> consecutive slots of (mostly) the same bucket: coalesced
-        auto bucket_of = [&](const REC &r, int i) __attribute__((always_inline)) -> int {
-            if constexpr (REC::kPacked) return (int)s_bkt[i];
-            else return (int)(r.row >> BK_SHIFT);
-        };
-        if (!s_ovf[cur]) {  // uniform fast path: every record of the item has a slot
-            char *lbytes = reinterpret_cast<char *>(lrec);  // (a level's region is < 4 GiB: 32-bit byte offsets)
-            for (int i = tid; i < total; i += BIN_T) {
-                const REC r = s_stage[i];
-                const uint32_t at = (uint32_t)(s_dest[bucket_of(r, i)] + i) * (uint32_t)sizeof(REC);
-                *reinterpret_cast<REC *>(lbytes + at) = r;
-            }
-        } else {
-            for (int i = tid; i < total; i += BIN_T) {
-                const REC r = s_stage[i];
-                const int b = bucket_of(r, i);
-                const int slot = s_base[b] + (i - s_off[b]);
-                if (slot < cap) lrec[(int64_t)b * cap + slot] = r;
-                else spill(lv.off, r, b);   // bucket region full: finish this record with global atomics
-            }
+        // ---- G: the chunk, 16 bytes per lane (a chunk starts on a multiple of 16 bytes; the last unit may carry one
+        // stale record behind the item's last one: never read), and the segment table entries of the item
+        {
+            uint4 *dst = reinterpret_cast<uint4 *>(recs + ((int64_t)lv.level * bm.n_items + tile) * ITEM_RECS);
+            const uint4 *srcq = reinterpret_cast<const uint4 *>(s_stage);
+            const int n16 = (total * (int)sizeof(REC) + 15) >> 4;
+            for (int i = tid; i < n16; i += BIN_T) dst[i] = srcq[i];
+            if (tid < nb)
+                segtab[(int64_t)lv.b0 * bm.n_items + (int64_t)tile * nb + tid] =
+                    (uint32_t)s_off[tid] | ((uint32_t)s_cnt[cur][tid] << 16);
         }
         BIN_STAMP(8);
-        // (the next hashed item rewrites s_off / s_stage / s_dest only after ITS barrier 1, which every wave reaches
-        // after finishing the copy-out above)
+        // (the next item rewrites s_off / s_stage only behind ITS barrier 1, which every wave reaches after finishing
+        // the copy above; it clears this item's counter set behind that barrier too)
         l = l_next; tile = tile_next; have = have_next;
     }
     __syncthreads();
@@ -937,60 +892,169 @@ __device__ __forceinline__ int active_slices(int n, int smax) {
 // A bucket cut into slices (few, heavily loaded coarse buckets): every slice stores its EXACT 64-bit partial sums
 // as a tile of `partials`, and k_scatter_finish adds the tiles up -- integer addition, so the result does not depend
 // on how many slices there were or in which order they ran: the whole gradient is bitwise reproducible.
+//
+// The records of bucket b are the segments (first slot, count) = segtab entry of (item, b), one per item of pass 1, inside
+// the items' chunks.  Wave w of the workgroup takes items w, w + 16, ...: it reads 64 of its entries with one load and
+// walks the concatenation of those segments 64 records per round (see the loop).  LNERF_REDUCE_ROUNDS rounds of loads
+// are in flight per lane.  Built and measured on the way (profiles/r03_exp_scatter.jsonl): the segment of a lane found by
+// a binary search through ds_bpermute (+12 us: the permutes share the LDS pipe with the atomics); one segment per round
+// (half-empty waves: three times the instructions, 2-3x the time).
+#ifndef LNERF_REDUCE_ROUNDS
+#define LNERF_REDUCE_ROUNDS 8
+#endif
+#ifndef LNERF_REDUCE_XCD
+#define LNERF_REDUCE_XCD 1
+#endif
 template <int RT, typename REC, bool FUSE>
-__global__ void __launch_bounds__(RT)
-k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ cursor,
-                 const unsigned int *__restrict__ gmax, const REC *__restrict__ recs, float *__restrict__ dtable,
-                 long long *__restrict__ partials, int wg_lo, FusedUpdate fu) {
+__global__ void __launch_bounds__(RT, RT / 128)
+k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ items_dev, const uint32_t *__restrict__ segtab,
+                 int32_t *__restrict__ bucket_n, const unsigned int *__restrict__ gmax, const REC *__restrict__ recs,
+                 float *__restrict__ dtable, long long *__restrict__ partials, int wg_lo, FusedUpdate fu) {
     __shared__ long long acc[BK_ROWS * 2];  // [feature][row]: a wave's 64 random rows spread over 32 bank pairs
+    __shared__ int s_red[RT / 64];
+    constexpr int NW = RT / 64;
     // locate (level, bucket, slice) of this workgroup
     const int wg = (int)blockIdx.x + wg_lo;
     int l = 0;
     while (l + 1 < meta.num_levels && wg >= bm.wgstart[l + 1]) ++l;
     const int Smax = bm.slices[l];
     const int local = wg - bm.wgstart[l];
-    const int b = local / Smax, s = local - b * Smax;
-    const int cap = bm.cap[l];
-    const int n_raw = cursor[(bm.bstart[l] + b) * CUR_STRIDE];  // > cap: the excess records went to dtable with global atomics
-    const int n = n_raw < cap ? n_raw : cap;
-    const int S = active_slices(n, Smax);
-    if (s >= S) return;    // uniform per workgroup
+    int b = local / Smax;
+    const int s = local - b * Smax;
+    const int nb = bm.nb[l];
+    // Workgroups are dealt round-robin over the 8 XCDs (observed; used for speed only): on an un-sliced level whose
+    // bucket count is a multiple of 8 the workgroups of one XCD take CONTIGUOUS buckets.  The segments of neighbouring
+    // buckets are neighbours inside every chunk and share 128-byte lines at their seams: read by workgroups of one XCD at
+    // about the same time, those lines come from that XCD's L2 the second time instead of twice through the fabric.
+    if (LNERF_REDUCE_XCD && Smax == 1 && (nb & 7) == 0) b = (local & 7) * (nb >> 3) + (local >> 3);
+    const int tid = threadIdx.x, lane = tid & 63;
+    // (uniform, and known to be: everything derived from it -- the wave's items, their chunk addresses -- stays in
+    // scalar registers; as a function of threadIdx it was per-lane 64-bit address arithmetic and spilled)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int I = *items_dev;                       // items of the pass 1 that filled the workspace
+    I = I < bm.n_items ? I : bm.n_items;
+    const uint32_t *tab = segtab + (int64_t)bm.bstart[l] * bm.n_items + b;   // entry of item t: tab[t * nb]
+    int S = 1, i0 = 0, i1 = I;
+    if (Smax > 1) {  // (uniform per level) a level whose buckets MAY be sliced: count the bucket's records first
+        int cnt = 0;
+        for (int t = tid; t < I; t += RT) cnt += (int)(tab[(int64_t)t * nb] >> 16);
+        cnt = wave_inclusive_sum_i(cnt);
+        if (lane == 63) s_red[wave] = cnt;
+        __syncthreads();
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) n += s_red[k];
+        S = active_slices(n, Smax);
+        if (s == 0 && tid == 0) bucket_n[bm.bstart[l] + b] = n;   // for the finishing pass
+        if (s >= S) return;    // uniform per workgroup
+        i0 = (int)(((long long)I * s) / S);
+        i1 = (int)(((long long)I * (s + 1)) / S);
+    }
     const bool direct = S == 1;        // this workgroup sums the whole bucket: it finishes the rows itself
     const bool fuse = FUSE && direct;
-    const int lo = (int)(((long long)n * s) / S), hi = (int)(((long long)n * (s + 1)) / S);
-    const bool have = hi > lo;  // uniform
+    const bool have = i1 > i0;  // uniform
     if (!have && !fuse) return;  // (a fused bucket without records still owes its rows the Adam step, g = 0)
     constexpr int FB = FixBits<REC>::kBits;
     const FixScale fs = fix_scale<FB>(gmax[l * CUR_STRIDE]);  // from the bound of |value| of the LEVEL (found by pass 1)
-    const int tid = threadIdx.x;
     RED_STAMP_INIT();
     const int hsize = meta.offsets[l + 1] - meta.offsets[l];
     const int row0 = b << BK_SHIFT;
     int rows = hsize - row0;
     rows = rows < BK_ROWS ? rows : BK_ROWS;
     const int64_t R0 = (int64_t)meta.offsets[l] + row0;
+    // the usual fused case (full bucket, even first row): two rows per lane and access (16 B).  Their parameters and
+    // moments are requested BEHIND the record loop and IN FRONT of the barrier that ends it: a wave that is done with its
+    // records waits for the slowest wave anyway, and the loads travel meanwhile.  (Requested ahead of the record stream
+    // they were measured 35 us slower: the records queue behind them.)
+    constexpr int NQ = (BK_ROWS / 2 + RT - 1) / RT;  // row pairs per lane
+    const bool fast = fuse && !fu.grad_out && ((R0 | rows) & 1) == 0 && rows == BK_ROWS && (BK_ROWS / 2) % RT == 0;
+    float4 P[NQ], Mv[NQ], V[NQ];
+    float4 *p4 = reinterpret_cast<float4 *>(reinterpret_cast<float2 *>(fu.p) + R0);
+    float4 *m4 = reinterpret_cast<float4 *>(reinterpret_cast<float2 *>(fu.m) + R0);
+    float4 *v4 = reinterpret_cast<float4 *>(reinterpret_cast<float2 *>(fu.v) + R0);
     if (have) {
+        const int first = i0 + wave;                                  // this wave's items: first, first + NW, ...
+        const int nmy = first < i1 ? (i1 - first + NW - 1) / NW : 0;
+        // (the first 64 segment entries are requested before the accumulators are cleared: one round trip hidden)
+        uint32_t e_first = 0u;
+        if (lane < nmy) e_first = tab[(int64_t)(first + NW * lane) * nb];
         for (int i = tid; i < BK_ROWS * 2; i += RT) acc[i] = 0ll;
         __syncthreads();
         RED_STAMP(10);
-        const REC *rp = recs + bm.rstart[l] + (long long)b * cap;
+        const REC *lrec = recs + (int64_t)l * bm.n_items * ITEM_RECS;
         unsigned long long *ua = reinterpret_cast<unsigned long long *>(acc);
         auto add = [&](const REC &r) {
             const uint32_t a0 = r.row_in_bucket();
             atomicAdd(&ua[a0], (unsigned long long)to_fixed<FB>((r.a() * fs.sc_a) * fs.sc_b));
             atomicAdd(&ua[a0 + BK_ROWS], (unsigned long long)to_fixed<FB>((r.b() * fs.sc_a) * fs.sc_b));
         };
-        // the pass waits on its record loads (rocprofv3: 82 % of wave cycles parked): keep four loads in flight
-        // per lane
-        int i = lo + tid;
-        for (; i + 3 * RT < hi; i += 4 * RT) {
-            const REC r0 = rp[i], r1 = rp[i + RT], r2 = rp[i + 2 * RT], r3 = rp[i + 3 * RT];
-            add(r0); add(r1); add(r2); add(r3);
+        constexpr int U = LNERF_REDUCE_ROUNDS;                        // rounds of loads in flight per lane
+        for (int kb = 0; kb < nmy; kb += 64) {                        // (one pass for up to 64 x 16 = 1024 items)
+            uint32_t e = e_first;
+            if (kb > 0) e = kb + lane < nmy ? tab[(int64_t)(first + NW * (kb + lane)) * nb] : 0u;
+            const int cnt = nmy - kb < 64 ? nmy - kb : 64;            // segments held by the lanes (uniform)
+            const int T = __builtin_amdgcn_readlane(wave_inclusive_sum_i((int)(e >> 16)), 63);   // their records
+            // Walk the CONCATENATION of the segments 64 records per round: lane i of a round takes flat record f0 + i, so
+            // every lane carries a record whatever the segment sizes are (~32 on a hashed level, thousands on a
+            // one-bucket level).  Which segment a lane is in comes from a SCALAR walk: (sj, sp) = first segment that
+            // reaches into the round and its flat start; a round visits the 2-3 segments it spans, each visit two scalar
+            // readlanes and three vector instructions -- no cross-lane traffic on the LDS pipe, which the two 64-bit
+            // atomics of every record need (a binary search through ds_bpermute was 12 us slower).
+            int sj = 0, sp = 0;
+            // record index (inside the level's region) of flat record fb + lane; called with increasing fb
+            auto locate = [&](int fb) __attribute__((always_inline)) -> uint32_t {
+                const int f = fb + lane;
+                uint32_t at = 0u;
+                for (;;) {
+                    const uint32_t ej = (uint32_t)__builtin_amdgcn_readlane((int)e, sj);
+                    const int cj = (int)(ej >> 16);
+                    // (chunk of item `first + NW (kb + sj)`, its segment's first slot, minus the flat start)
+                    const uint32_t base = (uint32_t)(first + NW * (kb + sj)) * (uint32_t)ITEM_RECS + (ej & 0xFFFFu) -
+                                          (uint32_t)sp;
+                    at = (f >= sp && f < sp + cj) ? base + (uint32_t)f : at;
+                    if (sp + cj >= fb + 64 || sj + 1 >= cnt) break;   // the round ends inside this segment
+                    sp += cj;
+                    ++sj;
+                }
+                return f < T ? at : 0u;                               // (slot 0 exists: the load is unconditional)
+            };
+            // software pipeline over the rounds: U loads are in flight at ALL times -- a round's record is consumed and
+            // its register immediately re-armed with the load of the round U ahead (a plain "issue U, consume U" loop
+            // drains to zero loads in flight at the end of every batch)
+            const int nr = (T + 63) >> 6;                             // rounds (uniform)
+            REC r[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (u < nr) r[u] = lrec[locate(64 * u)];
+            for (int rb = 0; rb < nr; rb += U) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int rd = rb + u;                            // uniform
+                    if (rd < nr) {
+                        pin_record(r[u]);                             // (keeps the load outside the predicated block)
+                        const REC cur = r[u];
+                        if (rd + U < nr) r[u] = lrec[locate(64 * (rd + U))];
+                        if (64 * rd + lane < T) add(cur);
+                    }
+                }
+            }
         }
-        for (; i < hi; i += RT) add(rp[i]);
         RED_STAMP(11);
+        if (fast) {
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {  // all of the lane's loads: six 16-byte loads in flight behind the barrier
+                const int q = tid + j * RT;
+                P[j] = p4[q]; Mv[j] = m4[q]; V[j] = v4[q];
+            }
+        }
         __syncthreads();
         RED_STAMP(12);
+    } else if (fast) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int q = tid + j * RT;
+            P[j] = p4[q]; Mv[j] = m4[q]; V[j] = v4[q];
+        }
     }
     if (!direct) {  // sliced bucket: hand the exact sums to k_scatter_finish
         long long *pt = partials + ((int64_t)bm.pstart[l] + (int64_t)b * Smax + s) * (BK_ROWS * 2);
@@ -1002,7 +1066,6 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
         AdamArgs a = fu.a;
         adam_bias(a);
         a.zero_grad = 0;
-        const bool ovf = n_raw > cap;  // uniform
         float2 *p2 = reinterpret_cast<float2 *>(fu.p) + R0, *m2 = reinterpret_cast<float2 *>(fu.m) + R0;
         float2 *v2 = reinterpret_cast<float2 *>(fu.v) + R0;
         uint32_t *sh = fu.shadow ? reinterpret_cast<uint32_t *>(fu.shadow) + R0 : nullptr;
@@ -1011,12 +1074,6 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
             if (have) {
                 g0 = ((float)acc[r] * fs.un_a) * fs.un_b;
                 g1 = ((float)acc[r + BK_ROWS] * fs.un_a) * fs.un_b;
-            }
-            if (ovf) {  // what pass 1 could not place: consume it and leave dtable zero again
-                const float2 d = reinterpret_cast<float2 *>(dst)[r];
-                g0 = d.x + g0;
-                g1 = d.y + g1;
-                reinterpret_cast<float2 *>(dst)[r] = make_float2(0.f, 0.f);
             }
         };
         if (fu.grad_out) {  // gradient output in the wire format: one bf16 pair per row
@@ -1028,19 +1085,8 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
             }
             return;
         }
-        // usual case (full bucket, even first row): two rows per lane and access (16 B).  (Fetching the lane's
-        // parameters and moments ahead of the record stream was measured 35 us SLOWER.)
-        constexpr int NQ = (BK_ROWS / 2 + RT - 1) / RT;  // row pairs per lane
-        if (((R0 | rows) & 1) == 0 && rows == BK_ROWS && (BK_ROWS / 2) % RT == 0) {
-            float4 *p4 = reinterpret_cast<float4 *>(p2), *m4 = reinterpret_cast<float4 *>(m2);
-            float4 *v4 = reinterpret_cast<float4 *>(v2);
+        if (fast) {
             uint2 *sh2 = reinterpret_cast<uint2 *>(sh);
-            float4 P[NQ], Mv[NQ], V[NQ];
-#pragma unroll
-            for (int j = 0; j < NQ; ++j) {  // all of the lane's loads first: six 16-byte loads in flight
-                const int q = tid + j * RT;
-                P[j] = p4[q]; Mv[j] = m4[q]; V[j] = v4[q];
-            }
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
                 const int q = tid + j * RT;
@@ -1064,13 +1110,13 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
             return;
         }
         for (int r = tid; r < rows; r += RT) {
-            float2 P = p2[r], Mv = m2[r], V = v2[r];
+            float2 Pr = p2[r], Mr = m2[r], Vr = v2[r];
             float g0, g1;
             grad_of(r, g0, g1);
-            adam_one(P.x, g0, Mv.x, V.x, a);
-            adam_one(P.y, g1, Mv.y, V.y, a);
-            p2[r] = P; m2[r] = Mv; v2[r] = V;
-            if (sh) sh[r] = (uint32_t)f32_to_bf16(P.x) | ((uint32_t)f32_to_bf16(P.y) << 16);
+            adam_one(Pr.x, g0, Mr.x, Vr.x, a);
+            adam_one(Pr.y, g1, Mr.y, Vr.y, a);
+            p2[r] = Pr; m2[r] = Mr; v2[r] = Vr;
+            if (sh) sh[r] = (uint32_t)f32_to_bf16(Pr.x) | ((uint32_t)f32_to_bf16(Pr.y) << 16);
         }
         return;
     }
@@ -1086,54 +1132,59 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
 // Finishing pass of the sliced levels: one thread per table row adds the active slices' exact partial sums
 // (k_scatter_reduce), converts once and adds the result to dtable -- or applies the Adam step (FUSE).
 template <bool FUSE, int FB>
-__global__ void __launch_bounds__(256)
-k_scatter_finish(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ cursor, const unsigned int *__restrict__ gmax,
-                 const long long *__restrict__ partials, float *__restrict__ dtable, FusedUpdate fu, int lv_lo, int lv_hi) {
+__device__ __forceinline__ void scatter_finish_block(int block, const GridMeta &meta, const BucketMeta &bm,
+                                                     const int32_t *__restrict__ bucket_n,
+                                                     const unsigned int *__restrict__ gmax,
+                                                     const long long *__restrict__ partials, float *__restrict__ dtable,
+                                                     const FusedUpdate &fu, int lv_lo, int lv_hi) {
     constexpr int WG_PER_BUCKET = BK_ROWS / 256;
-    const int fb = blockIdx.x / WG_PER_BUCKET;  // index among the buckets of sliced levels
+    const int fb = block / WG_PER_BUCKET;  // index among the buckets of sliced levels
     int l = 0;
     while (l + 1 < meta.num_levels && (bm.slices[l] <= 1 || fb >= bm.fstart[l] + bm.nb[l])) ++l;
     if (bm.slices[l] <= 1) return;  // (cannot happen: the grid covers sliced buckets only)
     if (l < lv_lo || l >= lv_hi) return;  // a launch over a level range (pipelined data-parallel exchange)
     const int b = fb - bm.fstart[l];
-    const int Smax = bm.slices[l], cap = bm.cap[l];
-    const int n_raw = cursor[(bm.bstart[l] + b) * CUR_STRIDE];
-    const int n = n_raw < cap ? n_raw : cap;
-    const int S = active_slices(n, Smax);
-    if (S <= 1) return;  // the bucket was finished by its single pass-2 workgroup
-    const int r = (blockIdx.x % WG_PER_BUCKET) * 256 + threadIdx.x;
+    const int Smax = bm.slices[l];
+    const int r = (block % WG_PER_BUCKET) * 256 + threadIdx.x;
     const int hsize = meta.offsets[l + 1] - meta.offsets[l];
     const int row0 = b << BK_SHIFT;
-    if (row0 + r >= hsize) return;
+    const bool in_range = row0 + r < hsize;
+    const int64_t R = (int64_t)meta.offsets[l] + row0 + (in_range ? r : 0);
+    // everything that does not depend on the slice count is requested together with it (the pass is a chain of dependent
+    // round trips: record count -> partial tiles -> parameters; the first and the last now travel together)
+    const int n = bucket_n[bm.bstart[l] + b];   // written by the bucket's slice 0 in pass 2
+    const unsigned int gbits = gmax[l * CUR_STRIDE];
+    float2 P = make_float2(0.f, 0.f), Mv = P, V = P;
+    const bool adam = FUSE && !fu.grad_out;
+    if (adam) {
+        P = reinterpret_cast<float2 *>(fu.p)[R]; Mv = reinterpret_cast<float2 *>(fu.m)[R];
+        V = reinterpret_cast<float2 *>(fu.v)[R];
+    }
+    const int S = active_slices(n, Smax);
+    if (S <= 1) return;  // the bucket was finished by its single pass-2 workgroup
+    if (!in_range) return;
     const long long *pt = partials + ((int64_t)bm.pstart[l] + (int64_t)b * Smax) * (BK_ROWS * 2);
     long long q0 = 0ll, q1 = 0ll;
     int s = 0;
     for (; s + 4 <= S; s += 4) {   // eight loads in flight per lane: the slice count is dynamic, an un-unrolled loop pays
                                    // one memory round trip per slice (integer sums: the order is free)
-        long long a[4], b[4];
+        long long a[4], b4[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             a[k] = pt[(int64_t)(s + k) * (BK_ROWS * 2) + r];
-            b[k] = pt[(int64_t)(s + k) * (BK_ROWS * 2) + BK_ROWS + r];
+            b4[k] = pt[(int64_t)(s + k) * (BK_ROWS * 2) + BK_ROWS + r];
         }
         q0 += (a[0] + a[1]) + (a[2] + a[3]);
-        q1 += (b[0] + b[1]) + (b[2] + b[3]);
+        q1 += (b4[0] + b4[1]) + (b4[2] + b4[3]);
     }
     for (; s < S; ++s) {
         q0 += pt[(int64_t)s * (BK_ROWS * 2) + r];
         q1 += pt[(int64_t)s * (BK_ROWS * 2) + BK_ROWS + r];
     }
-    const FixScale fs = fix_scale<FB>(gmax[l * CUR_STRIDE]);
-    float g0 = ((float)q0 * fs.un_a) * fs.un_b, g1 = ((float)q1 * fs.un_a) * fs.un_b;
-    const int64_t R = (int64_t)meta.offsets[l] + row0 + r;
+    const FixScale fs = fix_scale<FB>(gbits);
+    const float g0 = ((float)q0 * fs.un_a) * fs.un_b, g1 = ((float)q1 * fs.un_a) * fs.un_b;
     float2 *d2 = reinterpret_cast<float2 *>(dtable) + R;
     if (FUSE) {
-        if (n_raw > cap) {  // overflow records of pass 1 sit in dtable: consume them, leave it zero
-            const float2 d = *d2;
-            g0 = d.x + g0;
-            g1 = d.y + g1;
-            *d2 = make_float2(0.f, 0.f);
-        }
         if (fu.grad_out) {
             reinterpret_cast<uint32_t *>(fu.grad_out)[R] = (uint32_t)f32_to_bf16(g0) | ((uint32_t)f32_to_bf16(g1) << 16);
             return;
@@ -1141,10 +1192,9 @@ k_scatter_finish(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
         AdamArgs a = fu.a;
         adam_bias(a);
         a.zero_grad = 0;
-        float2 P = reinterpret_cast<float2 *>(fu.p)[R], Mv = reinterpret_cast<float2 *>(fu.m)[R];
-        float2 V = reinterpret_cast<float2 *>(fu.v)[R];
-        adam_one(P.x, g0, Mv.x, V.x, a);
-        adam_one(P.y, g1, Mv.y, V.y, a);
+        float ga = g0, gb = g1;
+        adam_one(P.x, ga, Mv.x, V.x, a);
+        adam_one(P.y, gb, Mv.y, V.y, a);
         reinterpret_cast<float2 *>(fu.p)[R] = P;
         reinterpret_cast<float2 *>(fu.m)[R] = Mv;
         reinterpret_cast<float2 *>(fu.v)[R] = V;
@@ -1154,6 +1204,135 @@ k_scatter_finish(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ curso
         d.x += g0;
         d.y += g1;
         *d2 = d;
+    }
+}
+
+template <bool FUSE, int FB>
+__global__ void __launch_bounds__(256)
+k_scatter_finish(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ bucket_n, const unsigned int *__restrict__ gmax,
+                 const long long *__restrict__ partials, float *__restrict__ dtable, FusedUpdate fu, int lv_lo, int lv_hi) {
+    scatter_finish_block<FUSE, FB>((int)blockIdx.x, meta, bm, bucket_n, gmax, partials, dtable, fu, lv_lo, lv_hi);
+}
+
+// ---- the step's TAIL: everything that is left behind pass 2 of a single-GPU step, in ONE launch.  In a replayed graph a
+// dependent dispatch costs ~4.5 us whatever it computes, and three of them sat here for a few microseconds of work:
+// the finishing pass of the sliced buckets, the sum of the MLP's gradient slabs, the Adam step of the small parameters.
+//   blocks [0, n_finish)      scatter_finish_block: sliced buckets of the table (fused Adam step of their rows)
+//   blocks [n_finish, ...)    16 parameters of the MLP each: sum their column of the gradient slabs in a fixed order
+//                             (k_mlp_reduce_slabs' arithmetic: deterministic) and apply the Adam step straight from the
+//                             sum -- the weight gradients never exist in memory; updated weights are mirrored into the
+//                             bf16 weight fragments (lnerf_mlp_fragment_maps)
+//   last block to arrive      advances the device step counter and leaves the scatter's level maxima zero for the next
+//                             step (every other block has read both by then: the reads are waited for before a block's
+//                             arrival, the arrival is a device-scope atomic)
+struct SlabAdam {
+    const float *slabs;
+    int n_slabs, out_dim;
+    float *p[6], *m[6], *v[6];        // w1, b1, w2, b2, w3, b3
+    const int32_t *map[3];            // optional: fragment positions of w1, w2, w3 (two per weight)
+    uint16_t *shadow;                 // the bf16 fragment image the maps point into
+    float lr;
+};
+constexpr int TAIL_P = 16, TAIL_G = 16;   // parameters per block, slab groups (as k_mlp_reduce_slabs)
+
+constexpr int TAIL_SLABS_PER_LANE = MLP_BWD_MAX_BLOCKS / TAIL_G;   // 32: every slab load of a lane in flight at once
+constexpr int TAIL_SHARDS = 8;                                     // arrival counters (one 128-byte line each)
+
+template <int FB>
+__global__ void __launch_bounds__(256)
+k_step_tail(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ bucket_n, unsigned int *__restrict__ gmax,
+            const long long *__restrict__ partials, float *__restrict__ dtable, FusedUpdate fu, int n_finish,
+            SlabAdam sa, int32_t *__restrict__ tick, int32_t *__restrict__ arrive, int do_tick, int clear_gmax) {
+    // The launch is a handful of dependent round trips per block, so every load that depends on nothing is requested
+    // FIRST and together: the step counter (ONE device-scope atomic load per wave: the last block to arrive rewrites it,
+    // see k_adam_multi in optim.hip), a slab block's 32 slab values + its parameter, moments and fragment positions.
+    AdamArgs a = fu.a;
+    int32_t step_now = 0;
+    if (a.step_dev) step_now = __hip_atomic_load(a.step_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool is_finish = (int)blockIdx.x < n_finish;
+    __shared__ float part[TAIL_G][TAIL_P];
+    const int pi = threadIdx.x & (TAIL_P - 1), sg = threadIdx.x / TAIL_P;
+    const int p = ((int)blockIdx.x - n_finish) * TAIL_P + pi;
+    int k = -1, i = 0;   // slab column -> (tensor, element)
+    float vsl[TAIL_SLABS_PER_LANE];
+    float Pw = 0.f, Mw = 0.f, Vw = 0.f;
+    int2 at = make_int2(-1, -1);
+    if (!is_finish && sa.slabs) {
+        if (p < MLP_SLAB) {
+            if (p < MLP_SL_B1) { k = 0; i = p - MLP_SL_W1; }
+            else if (p < MLP_SL_W2) { k = 1; i = p - MLP_SL_B1; }
+            else if (p < MLP_SL_B2) { k = 2; i = p - MLP_SL_W2; }
+            else if (p < MLP_SL_W3) { k = 3; i = p - MLP_SL_B2; }
+            else if (p < MLP_SL_B3) { if ((p - MLP_SL_W3) / MLP_HID < sa.out_dim) { k = 4; i = p - MLP_SL_W3; } }
+            else { if (p - MLP_SL_B3 < sa.out_dim) { k = 5; i = p - MLP_SL_B3; } }
+#pragma unroll
+            for (int j = 0; j < TAIL_SLABS_PER_LANE; ++j) {
+                const int bsl = sg + TAIL_G * j;
+                vsl[j] = bsl < sa.n_slabs ? sa.slabs[(int64_t)bsl * MLP_SLAB + p] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TAIL_SLABS_PER_LANE; ++j) vsl[j] = 0.f;
+        }
+        if (sg == 0 && k >= 0) {
+            Pw = sa.p[k][i]; Mw = sa.m[k][i]; Vw = sa.v[k][i];
+            if (sa.shadow && !(k & 1)) at = reinterpret_cast<const int2 *>(sa.map[k >> 1])[i];
+        }
+    }
+    if (a.step_dev) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the counter has been READ: see the arrival below)
+        adam_bias_at(a, step_now);
+        a.step_dev = nullptr;   // (the bias corrections are final: nothing below re-reads the counter)
+    } else {
+        adam_bias(a);
+    }
+    a.zero_grad = 0;
+    if (is_finish) {
+        FusedUpdate f2 = fu;
+        f2.a = a;
+        scatter_finish_block<true, FB>((int)blockIdx.x, meta, bm, bucket_n, gmax, partials, dtable, f2, 0,
+                                       meta.num_levels);
+        // this block's read of the level maxima has returned before it arrives (the last arrival clears them)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (sa.slabs) {
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < TAIL_SLABS_PER_LANE; ++j) sum += vsl[j];   // (k_mlp_reduce_slabs' order: slabs sg, sg + 16, ...)
+        part[sg][pi] = sum;
+        __syncthreads();
+        if (sg == 0 && k >= 0) {
+            sum = part[0][pi];
+#pragma unroll
+            for (int g = 1; g < TAIL_G; ++g) sum += part[g][pi];
+            AdamArgs am = a;
+            am.lr = sa.lr;
+            adam_one(Pw, sum, Mw, Vw, am);
+            sa.p[k][i] = Pw; sa.m[k][i] = Mw; sa.v[k][i] = Vw;
+            const uint16_t h = f32_to_bf16(Pw);   // weights (k = 0, 2, 4) are mirrored into their two fragment positions
+            if (at.x >= 0) sa.shadow[at.x] = h;
+            if (at.y >= 0) sa.shadow[at.y] = h;
+        }
+    }
+    if (do_tick || clear_gmax) {
+        // arrival, two levels: 8 shard counters (a line each: ~600 arrivals on ONE word queue for 7 us at the memory
+        // side), the block that completes a shard arrives at the root, the block that completes the root is the last
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int total = (int)gridDim.x, sh = (int)blockIdx.x & (TAIL_SHARDS - 1);
+            const int mine = (total - sh + TAIL_SHARDS - 1) / TAIL_SHARDS;   // blocks of this shard
+            int32_t *cnt = arrive + (1 + sh) * CUR_STRIDE;
+            if (__hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine - 1) {
+                __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int shards = total < TAIL_SHARDS ? total : TAIL_SHARDS;
+                if (__hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1) {
+                    __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (do_tick) __hip_atomic_store(&tick[0], step_now + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (clear_gmax)
+                        for (int l = 0; l < LNERF_MAX_LEVELS; ++l)
+                            __hip_atomic_store(&gmax[l * CUR_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
     }
 }
 
@@ -1176,46 +1355,36 @@ static int g_skip_zero = 1;
 // threads per workgroup of the reduce pass (512 or 1024; two 64 KiB workgroups fit a CU either way)
 static int g_reduce_threads = 1024;
 
-// device header of the workspace: bucket cursors (int32) followed by the per-level maxima (uint32), CUR_STRIDE apart
-static size_t cursor_bytes(int n_buckets) {
-    return ((size_t)(n_buckets + LNERF_MAX_LEVELS) * CUR_STRIDE * sizeof(int32_t) + 4095) / 4096 * 4096;
+// workspace: [header: level maxima | item count | record count per bucket] [segment table] [record chunks] [partial tiles]
+static size_t header_bytes(int n_buckets) {
+    return (HDR_BUCKETN_OFF + (size_t)n_buckets * sizeof(int32_t) + 4095) / 4096 * 4096;
 }
 
 struct ScatterPlan {
-    int64_t recs;       // record slots
     int buckets, wgs;   // buckets / pass-2 workgroups over all levels
     int ptiles;         // partial-sum tiles (sliced levels: buckets x slices)
     int fbuckets;       // buckets of sliced levels (grid of the finishing pass)
-    size_t cursor_bytes, rec_bytes, partial_bytes;
-    size_t total() const { return cursor_bytes + rec_bytes + partial_bytes; }
+    size_t header_bytes, seg_bytes, rec_bytes, partial_bytes;
+    size_t total() const { return header_bytes + seg_bytes + rec_bytes + partial_bytes; }
 };
 
 static int fill_bucket_meta(const GridMeta &meta, int64_t m_host, BucketMeta &bm, ScatterPlan &plan) {
-    int64_t total_recs = 0;
     int total_buckets = 0, total_wgs = 0, total_ptiles = 0, total_fb = 0;
+    const int64_t n_items = m_host > 0 ? div_up(m_host, (int64_t)ITEM_SAMPLES) : 1;
+    if (n_items >= (1 << 19)) return -1;   // (pass 2 addresses a level's records with 32-bit record indices)
     for (int l = 0; l < meta.num_levels; ++l) {
         const int64_t hsize = meta.offsets[l + 1] - meta.offsets[l];
         const int nb = (int)div_up(hsize, BK_ROWS);
         if (nb > BK_MAX_PER_LEVEL) return -1;
-        const int64_t per_bucket = div_up(8 * m_host, nb);
-        // head-room over a uniform spread of the worst-case record count: 25 % on hashed levels (rows are spread
-        // by the hash), 100 % on levels with few buckets (dense levels: a bucket is a slab of z layers, a compact
-        // object loads the central slabs, and the last bucket of a level is only partly filled)
-        int64_t cap = per_bucket + (nb <= 64 ? per_bucket : per_bucket / 4) + 1024;
-        if (cap > 8 * m_host) cap = 8 * m_host;
-        if (cap < 64) cap = 64;
-        if (cap > 0x7FFFFFFF) return -1;
-        if ((int64_t)nb * cap * (int64_t)sizeof(Rec12) >= (1ll << 32)) return -1;  // (the copy-out uses 32-bit byte offsets)
+        const int64_t per_bucket = div_up(8 * m_host, nb);   // worst case under a uniform spread
         int slices = (int)((per_bucket + 65535) / 65536);    // <= ~64 Ki records per pass-2 workgroup
         if (slices < 1) slices = 1;
         if (slices > 64) slices = 64;
         bm.nb[l] = nb;
         bm.bstart[l] = total_buckets;
-        bm.cap[l] = (int)cap;
         bm.slices[l] = slices;
         bm.compact[l] = meta.res[l] <= g_compact_max_res ? 1 : 0;
         bm.wgstart[l] = total_wgs;
-        bm.rstart[l] = total_recs;
         bm.pstart[l] = slices > 1 ? total_ptiles : -1;
         bm.fstart[l] = slices > 1 ? total_fb : -1;
         if (slices > 1) {
@@ -1224,31 +1393,35 @@ static int fill_bucket_meta(const GridMeta &meta, int64_t m_host, BucketMeta &bm
         }
         total_buckets += nb;
         total_wgs += nb * slices;
-        total_recs += (int64_t)nb * cap;
     }
     bm.bstart[meta.num_levels] = total_buckets;
     bm.wgstart[meta.num_levels] = total_wgs;
-    plan.recs = total_recs;
+    bm.n_items = (int)n_items;
     plan.buckets = total_buckets;
     plan.wgs = total_wgs;
     plan.ptiles = total_ptiles;
     plan.fbuckets = total_fb;
-    plan.cursor_bytes = cursor_bytes(total_buckets);
-    plan.rec_bytes = ((size_t)total_recs * sizeof(Rec12) + 15) / 16 * 16;  // (packed records use two thirds of it)
+    plan.header_bytes = header_bytes(total_buckets);
+    plan.seg_bytes = ((size_t)total_buckets * (size_t)n_items * sizeof(uint32_t) + 4095) / 4096 * 4096;
+    // one chunk of ITEM_RECS slots per (level, item): exactly what the item's samples can emit (sized for the 12-byte
+    // records; the packed ones use two thirds of it)
+    plan.rec_bytes = (size_t)meta.num_levels * (size_t)n_items * ITEM_RECS * sizeof(Rec12);
     plan.partial_bytes = (size_t)total_ptiles * BK_ROWS * 2 * sizeof(long long);
     return 0;
 }
 
 static int fill_meta(const char *who, GridMeta &meta, int num_levels, int level_dim, const int32_t *offsets_host,
-                     const float *scales_host, const int32_t *res_host) {
+                     const float *scales_host, const int32_t *res_host, int blocked = 0) {
     LNERF_REQUIRE(num_levels >= 1 && num_levels <= LNERF_MAX_LEVELS, "%s: num_levels out of range (%d)", who,
                   num_levels);
     LNERF_REQUIRE(level_dim == 2, "%s: only level_dim == 2 is built (got %d)", who, level_dim);
     LNERF_REQUIRE(offsets_host && scales_host && res_host, "%s: null level metadata", who);
     meta.num_levels = num_levels;
+    meta.blocked = blocked ? 1 : 0;
     for (int l = 0; l <= num_levels; ++l) meta.offsets[l] = offsets_host[l];
     for (int l = 0; l < num_levels; ++l) {
         LNERF_REQUIRE(offsets_host[l + 1] > offsets_host[l], "%s: empty level %d", who, l);
+        LNERF_REQUIRE(!blocked || offsets_host[l + 1] - offsets_host[l] >= 16, "%s: blocked layout needs >= 16 rows per level", who);
         LNERF_REQUIRE(res_host[l] >= 1 && res_host[l] <= 1 << 20, "%s: bad resolution at level %d", who, l);
         meta.scales[l] = scales_host[l];
         meta.res[l] = res_host[l];
@@ -1281,7 +1454,9 @@ int lnerf_grid_encode_forward(const float *xyzs, float bound, const void *table,
                               const int32_t *res_host, int64_t m_host, const int32_t *m_dev, int64_t level_stride,
                               void *feat, int feat_dtype, int variant, lnerf_stream_t stream) {
     GridMeta meta;
-    int rc = fill_meta("grid_encode_forward", meta, num_levels, level_dim, offsets_host, scales_host, res_host);
+    const int blocked = variant & LNERF_GRID_BLOCKED;
+    variant &= ~LNERF_GRID_BLOCKED;
+    int rc = fill_meta("grid_encode_forward", meta, num_levels, level_dim, offsets_host, scales_host, res_host, blocked);
     if (rc) return rc;
     LNERF_REQUIRE(m_host >= 0 && level_stride >= m_host, "grid_encode_forward: need 0 <= m_host <= level_stride");
     LNERF_REQUIRE(bound > 0.f, "grid_encode_forward: bound must be > 0");
@@ -1408,24 +1583,26 @@ size_t lnerf_grid_scatter_clear_bytes(int num_levels, const int32_t *offsets_hos
     if (num_levels < 1 || num_levels > LNERF_MAX_LEVELS || !offsets_host || m_host < 0) return 0;
     GridMeta meta;
     meta.num_levels = num_levels;
+    meta.blocked = 0;
     for (int l = 0; l <= num_levels; ++l) meta.offsets[l] = offsets_host[l];
     for (int l = 0; l < num_levels; ++l) meta.res[l] = 0;
     BucketMeta bm;
     ScatterPlan plan;
     if (fill_bucket_meta(meta, m_host, bm, plan) != 0) return 0;
-    return plan.cursor_bytes;
+    return HDR_GMAX_BYTES;   // the level maxima (pass 1 raises them with atomicMax)
 }
 
 size_t lnerf_grid_encode_backward_workspace_bytes(int num_levels, const int32_t *offsets_host, int64_t m_host) {
     if (num_levels < 1 || num_levels > LNERF_MAX_LEVELS || !offsets_host || m_host < 0) return 0;
     GridMeta meta;
     meta.num_levels = num_levels;
+    meta.blocked = 0;
     for (int l = 0; l <= num_levels; ++l) meta.offsets[l] = offsets_host[l];
     for (int l = 0; l < num_levels; ++l) meta.res[l] = 0;
     BucketMeta bm;
     ScatterPlan plan;
     if (fill_bucket_meta(meta, m_host, bm, plan) != 0) return 0;
-    return plan.total();  // bucket cursors, the records, the partial-sum tiles of the sliced levels
+    return plan.total();  // header, segment table, record chunks, partial-sum tiles of the sliced levels
 }
 
 // fu == nullptr: dtable += scatter.  fu != nullptr: every row's Adam step is applied by whichever kernel finishes its
@@ -1439,12 +1616,16 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
     // LNERF_SCATTER_CLEARED: the caller zeroed the head of the workspace (lnerf_grid_scatter_clear_bytes()) with
     // something it was launching anyway -- the fill dispatch of this call is skipped
     const bool cleared = (variant & LNERF_SCATTER_CLEARED) != 0;
-    variant &= ~LNERF_SCATTER_CLEARED;
+    // LNERF_SCATTER_DEFER_FINISH: the finishing pass of the sliced buckets is left to lnerf_step_tail
+    const bool defer_finish = (variant & LNERF_SCATTER_DEFER_FINISH) != 0;
+    const int blocked = variant & LNERF_GRID_BLOCKED;
+    variant &= ~(LNERF_SCATTER_CLEARED | LNERF_SCATTER_DEFER_FINISH | LNERF_GRID_BLOCKED);
     GridMeta meta;
-    int rc = fill_meta("grid_encode_backward", meta, num_levels, level_dim, offsets_host, scales_host, res_host);
+    int rc = fill_meta("grid_encode_backward", meta, num_levels, level_dim, offsets_host, scales_host, res_host, blocked);
     if (rc) return rc;
     LNERF_REQUIRE(m_host >= 0 && level_stride >= m_host, "grid_encode_backward: need 0 <= m_host <= level_stride");
     LNERF_REQUIRE(m_host < (1ll << 30), "grid_encode_backward: m_host must be below 2^30 samples");
+    LNERF_REQUIRE(variant < 2 || m_host < (1ll << 28), "grid_encode_backward: the bucketed scatter takes m_host below 2^28");
     LNERF_REQUIRE(bound > 0.f, "grid_encode_backward: bound must be > 0");
     LNERF_REQUIRE(variant >= 0 && variant <= 3, "grid_encode_backward: unknown variant %d", variant);
     LNERF_REQUIRE(dfeat_dtype == LNERF_F32, "grid_encode_backward: dfeat must be f32");
@@ -1467,19 +1648,20 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
     ScatterPlan plan;
     LNERF_REQUIRE(fill_bucket_meta(meta, m_host, bm, plan) == 0,
                   "grid_encode_backward: level too large for the bucketed scatter (use variant 0/1)");
-    const int nbk = plan.buckets;
-    const size_t cbytes = plan.cursor_bytes;
     const size_t need = plan.total();
     LNERF_REQUIRE(workspace && workspace_bytes >= need, "grid_encode_backward: workspace too small (%zu < %zu)",
                   workspace_bytes, need);
     LNERF_REQUIRE(((uintptr_t)workspace & 15) == 0 && ((uintptr_t)dtable & 15) == 0,
                   "grid_encode_backward: workspace/dtable must be 16-byte aligned");
-    int32_t *cursor = (int32_t *)workspace;
-    unsigned int *gmax = (unsigned int *)workspace + (size_t)nbk * CUR_STRIDE;
-    void *rec = (char *)workspace + cbytes;
-    long long *partials = (long long *)((char *)workspace + cbytes + plan.rec_bytes);
+    char *wsb = (char *)workspace;
+    unsigned int *gmax = (unsigned int *)wsb;
+    int32_t *items_dev = (int32_t *)(wsb + HDR_ITEMS_OFF);
+    int32_t *bucket_n = (int32_t *)(wsb + HDR_BUCKETN_OFF);
+    uint32_t *segtab = (uint32_t *)(wsb + plan.header_bytes);
+    void *rec = wsb + plan.header_bytes + plan.seg_bytes;
+    long long *partials = (long long *)(wsb + plan.header_bytes + plan.seg_bytes + plan.rec_bytes);
     const bool packed = variant == 3;
-    if ((phases & 1) && !cleared && hipMemsetAsync(cursor, 0, cbytes, s) != hipSuccess) {
+    if ((phases & 1) && !cleared && hipMemsetAsync(gmax, 0, HDR_GMAX_BYTES, s) != hipSuccess) {
         set_error("grid_encode_backward: hipMemsetAsync failed");
         return LNERF_ERR_HIP;
     }
@@ -1493,10 +1675,10 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
         const dim3 g((unsigned)G, 1, 1);
         if (packed)
             hipLaunchKernelGGL((k_scatter_bin<Rec8>), g, dim3(BIN_T), 0, s, xyzs, bound, (const float *)dfeat, meta, bm,
-                               m_host, m_dev, level_stride, cursor, gmax, (Rec8 *)rec, dtable, g_skip_zero);
+                               m_host, m_dev, level_stride, gmax, items_dev, segtab, (Rec8 *)rec, g_skip_zero);
         else
             hipLaunchKernelGGL((k_scatter_bin<Rec12>), g, dim3(BIN_T), 0, s, xyzs, bound, (const float *)dfeat, meta, bm,
-                               m_host, m_dev, level_stride, cursor, gmax, (Rec12 *)rec, dtable, g_skip_zero);
+                               m_host, m_dev, level_stride, gmax, items_dev, segtab, (Rec12 *)rec, g_skip_zero);
     };
     FusedUpdate fu0;
     memset(&fu0, 0, sizeof(fu0));
@@ -1505,8 +1687,8 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
         const int w0 = bm.wgstart[l0], w1 = bm.wgstart[l1];
         if (w1 <= w0) return;
 #define LAUNCH_RED(T, REC, FUSE)                                                                                  \
-    hipLaunchKernelGGL((k_scatter_reduce<T, REC, FUSE>), dim3((unsigned)(w1 - w0)), dim3(T), 0, st, meta, bm, cursor, \
-                       gmax, (const REC *)rec, dtable, partials, w0, fu0)
+    hipLaunchKernelGGL((k_scatter_reduce<T, REC, FUSE>), dim3((unsigned)(w1 - w0)), dim3(T), 0, st, meta, bm, items_dev, \
+                       segtab, bucket_n, gmax, (const REC *)rec, dtable, partials, w0, fu0)
         if (fu && packed) LAUNCH_RED(1024, Rec8, true);
         else if (fu) LAUNCH_RED(1024, Rec12, true);
         else if (packed && g_reduce_threads == 512) LAUNCH_RED(512, Rec8, false);
@@ -1519,7 +1701,7 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
         if (plan.fbuckets == 0) return;
         const dim3 g((unsigned)(plan.fbuckets * (BK_ROWS / 256)));
 #define LAUNCH_FIN(FUSE, FB)                                                                                        \
-    hipLaunchKernelGGL((k_scatter_finish<FUSE, FB>), g, dim3(256), 0, s, meta, bm, cursor, gmax, partials, dtable, fu0,   \
+    hipLaunchKernelGGL((k_scatter_finish<FUSE, FB>), g, dim3(256), 0, s, meta, bm, bucket_n, gmax, partials, dtable, fu0, \
                        lv_lo, lv_hi)
         if (fu && packed) LAUNCH_FIN(true, 30);
         else if (fu) LAUNCH_FIN(true, 44);
@@ -1536,7 +1718,7 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
         LNERF_CHECK_LAUNCH("grid_encode_backward(reduce)");
         bool any_sliced = false;
         for (int l = lv_lo; l < lv_hi; ++l) any_sliced = any_sliced || bm.slices[l] > 1;
-        if (any_sliced) launch_finish();
+        if (any_sliced && !defer_finish) launch_finish();
         LNERF_CHECK_LAUNCH("grid_encode_backward(finish)");
     }
     return LNERF_OK;
@@ -1613,6 +1795,91 @@ int lnerf_grid_encode_backward_adam(const float *xyzs, float bound, const void *
     adam_host_args(fu.a, lr, beta1, beta2, eps, step, step_dev, grad_scale, 0);
     return scatter_backward(xyzs, bound, dfeat, dfeat_dtype, num_levels, level_dim, offsets_host, scales_host, res_host,
                             m_host, m_dev, level_stride, dtable_zero, variant, workspace, workspace_bytes, stream, &fu);
+}
+
+int lnerf_step_tail(int num_levels, int level_dim, const int32_t *offsets_host, const float *scales_host,
+                    const int32_t *res_host, int64_t m_host, int variant, void *scatter_workspace,
+                    size_t scatter_workspace_bytes, float *dtable_zero, float *table, float *exp_avg, float *exp_avg_sq,
+                    void *shadow_bf16, float table_lr, const void *mlp_workspace, size_t mlp_workspace_bytes,
+                    int mlp_precision, int out_dim, float *const *params_host, float *const *exp_avg_host,
+                    float *const *exp_avg_sq_host, float mlp_lr, const int32_t *const *maps_host, float beta1, float beta2,
+                    float eps, int step, int32_t *step_dev, float grad_scale, int flags, lnerf_stream_t stream) {
+    const bool with_scatter = num_levels > 0, with_mlp = mlp_workspace != nullptr;
+    LNERF_REQUIRE(with_scatter || with_mlp, "step_tail: nothing to do");
+    LNERF_REQUIRE(step_dev || step >= 1, "step_tail: step must be >= 1 (got %d)", step);
+    LNERF_REQUIRE(!(flags & (LNERF_TAIL_TICK | LNERF_TAIL_CLEAR_SCATTER)) || step_dev,
+                  "step_tail: the tick / the clearing epilogue need the device counter pair (int32[2])");
+    LNERF_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "step_tail: betas must be in [0,1)");
+    GridMeta meta;
+    BucketMeta bm;
+    ScatterPlan plan;
+    memset(&meta, 0, sizeof(meta));
+    memset(&bm, 0, sizeof(bm));
+    memset(&plan, 0, sizeof(plan));
+    FusedUpdate fu;
+    memset(&fu, 0, sizeof(fu));
+    adam_host_args(fu.a, table_lr, beta1, beta2, eps, step, step_dev, grad_scale, 0);
+    unsigned int *gmax = nullptr;
+    int32_t *bucket_n = nullptr, *arrive = nullptr;
+    long long *partials = nullptr;
+    int n_finish = 0;
+    const bool packed = (variant & 0xFF) == 3;
+    if (with_scatter) {
+        int rc = fill_meta("step_tail", meta, num_levels, level_dim, offsets_host, scales_host, res_host);
+        if (rc) return rc;
+        LNERF_REQUIRE(((variant & 0xFF) == 2 || packed) && m_host > 0, "step_tail: needs scatter variant 2 / 3 and m_host > 0");
+        LNERF_REQUIRE(fill_bucket_meta(meta, m_host, bm, plan) == 0, "step_tail: level too large for the bucketed scatter");
+        LNERF_REQUIRE(scatter_workspace && scatter_workspace_bytes >= plan.total(), "step_tail: scatter workspace too small");
+        LNERF_REQUIRE(table && exp_avg && exp_avg_sq && dtable_zero, "step_tail: null optimiser state");
+        LNERF_REQUIRE((((uintptr_t)table | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)scatter_workspace) & 15) == 0,
+                      "step_tail: buffers must be 16-byte aligned");
+        char *wsb = (char *)scatter_workspace;
+        gmax = (unsigned int *)wsb;
+        bucket_n = (int32_t *)(wsb + HDR_BUCKETN_OFF);
+        arrive = (int32_t *)(wsb + HDR_ARRIVE_OFF);
+        partials = (long long *)(wsb + plan.header_bytes + plan.seg_bytes + plan.rec_bytes);
+        fu.p = table; fu.m = exp_avg; fu.v = exp_avg_sq; fu.shadow = (uint16_t *)shadow_bf16;
+        n_finish = plan.fbuckets * (BK_ROWS / 256);
+    }
+    LNERF_REQUIRE(!(flags & (LNERF_TAIL_CLEAR_SCATTER | LNERF_TAIL_TICK)) || with_scatter,
+                  "step_tail: the tick / the clearing epilogue keep their arrival counters in the scatter workspace");
+    SlabAdam sa;
+    memset(&sa, 0, sizeof(sa));
+    int n_slab_blocks = 0;
+    if (with_mlp) {
+        LNERF_REQUIRE(out_dim >= 2 && out_dim <= 8, "step_tail: out_dim must be in [2,8]");
+        LNERF_REQUIRE(mlp_precision == LNERF_F32 || mlp_precision == LNERF_BF16, "step_tail: bad precision tag");
+        LNERF_REQUIRE(mlp_workspace_bytes >= lnerf_mlp_backward_workspace_bytes(out_dim), "step_tail: MLP workspace too small");
+        LNERF_REQUIRE(params_host && exp_avg_host && exp_avg_sq_host && m_host > 0, "step_tail: null MLP state");
+        for (int k = 0; k < 6; ++k) {
+            LNERF_REQUIRE(params_host[k] && exp_avg_host[k] && exp_avg_sq_host[k], "step_tail: null MLP tensor %d", k);
+            sa.p[k] = params_host[k]; sa.m[k] = exp_avg_host[k]; sa.v[k] = exp_avg_sq_host[k];
+        }
+        if (maps_host) {
+            for (int k = 0; k < 3; ++k) {
+                LNERF_REQUIRE(maps_host[k] && ((uintptr_t)maps_host[k] & 7) == 0, "step_tail: bad fragment map %d", k);
+                sa.map[k] = maps_host[k];
+            }
+            sa.shadow = (uint16_t *)const_cast<void *>(mlp_workspace);   // the fragment image heads the workspace
+        }
+        sa.slabs = reinterpret_cast<const float *>(static_cast<const char *>(mlp_workspace) + MLP_FRAG_BYTES);
+        sa.n_slabs = lnerf_mlp_backward_slabs(m_host, mlp_precision);
+        sa.out_dim = out_dim;
+        sa.lr = mlp_lr;
+        n_slab_blocks = (int)div_up(MLP_SLAB, TAIL_P);
+    }
+    const dim3 g((unsigned)(n_finish + n_slab_blocks));
+    if (g.x == 0) return LNERF_OK;
+    hipStream_t s = as_stream(stream);
+    const int do_tick = (flags & LNERF_TAIL_TICK) ? 1 : 0, clr = (flags & LNERF_TAIL_CLEAR_SCATTER) ? 1 : 0;
+    if (packed)
+        hipLaunchKernelGGL((k_step_tail<30>), g, dim3(256), 0, s, meta, bm, bucket_n, gmax, partials, dtable_zero, fu,
+                           n_finish, sa, step_dev, arrive, do_tick, clr);
+    else
+        hipLaunchKernelGGL((k_step_tail<44>), g, dim3(256), 0, s, meta, bm, bucket_n, gmax, partials, dtable_zero, fu,
+                           n_finish, sa, step_dev, arrive, do_tick, clr);
+    LNERF_CHECK_LAUNCH("step_tail");
+    return LNERF_OK;
 }
 
 }  // extern "C"

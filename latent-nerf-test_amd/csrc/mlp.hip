@@ -464,6 +464,13 @@ int lnerf_mlp_forward(const void *feat, int feat_dtype, int64_t level_stride, co
 int lnerf_debug_mlp_stamps(unsigned long long *out32) { return lnerf::mlp_stamps_read(out32); }
 #endif
 
+int lnerf_mlp_backward_slabs(int64_t m_host, int precision) {
+    int64_t blocks = div_up(m_host, (precision & 0xFF) == LNERF_BF16 ? 128 : 64);
+    if (blocks > BWD_MAX_BLOCKS) blocks = BWD_MAX_BLOCKS;
+    if (blocks > g_mlp_bwd_blocks) blocks = g_mlp_bwd_blocks;
+    return (int)(blocks < 0 ? 0 : blocks);
+}
+
 size_t lnerf_mlp_backward_workspace_bytes(int out_dim) {
     (void)out_dim;
     return MLP_FRAG_BYTES + (size_t)BWD_MAX_BLOCKS * SLAB * sizeof(float);  // fragment cache, then the slabs
@@ -476,13 +483,17 @@ int lnerf_mlp_backward(const void *feat, int feat_dtype, int64_t level_stride, c
                        float *db2, float *dw3, float *db3, int accumulate, void *workspace, size_t workspace_bytes,
                        int precision, void *clear_ptr, size_t clear_bytes, lnerf_stream_t stream) {
     const bool fragments_ready = (precision & LNERF_MLP_FRAGMENTS_READY) != 0;
-    precision &= ~LNERF_MLP_FRAGMENTS_READY;
+    // LNERF_MLP_DEFER_REDUCE: the per-workgroup gradient slabs stay in the workspace -- lnerf_step_tail sums them and
+    // applies the Adam step (the d* outputs are not written and may be NULL)
+    const bool defer_reduce = (precision & LNERF_MLP_DEFER_REDUCE) != 0;
+    precision &= ~(LNERF_MLP_FRAGMENTS_READY | LNERF_MLP_DEFER_REDUCE);
     int rc = mlp_common_checks("mlp_backward", feat, feat_dtype, level_stride, xyzs, w1, b1, w2, b2, w3, b3, out_dim,
                                blob_std, m_host, precision);
     if (rc) return rc;
     if (m_host == 0) return LNERF_OK;
-    LNERF_REQUIRE(sigmas && dsigmas && drgbs && dfeat && dw1 && db1 && dw2 && db2 && dw3 && db3,
+    LNERF_REQUIRE(sigmas && dsigmas && drgbs && dfeat && (defer_reduce || (dw1 && db1 && dw2 && db2 && dw3 && db3)),
                   "mlp_backward: null pointer");
+    LNERF_REQUIRE(!defer_reduce || clear_bytes == 0, "mlp_backward: the deferred form has no reduction launch to clear with");
     LNERF_REQUIRE(workspace && workspace_bytes >= lnerf_mlp_backward_workspace_bytes(out_dim),
                   "mlp_backward: workspace too small (%zu < %zu)", workspace_bytes,
                   lnerf_mlp_backward_workspace_bytes(out_dim));
@@ -493,9 +504,7 @@ int lnerf_mlp_backward(const void *feat, int feat_dtype, int64_t level_stride, c
                   "mlp_backward: drgbs must be 16-byte aligned (one row per load)");
     MlpArgs a{feat, feat_dtype == LNERF_BF16, level_stride, xyzs, w1, b1, w2, b2, w3, b3, out_dim, blob_scale,
               2.0f * blob_std * blob_std, m_host, m_dev, nullptr};
-    int64_t blocks = div_up(m_host, precision == LNERF_BF16 ? 128 : 64);
-    if (blocks > BWD_MAX_BLOCKS) blocks = BWD_MAX_BLOCKS;
-    if (blocks > g_mlp_bwd_blocks) blocks = g_mlp_bwd_blocks;
+    const int64_t blocks = lnerf_mlp_backward_slabs(m_host, precision);
     hipStream_t s = as_stream(stream);
     float *slabs = reinterpret_cast<float *>(static_cast<char *>(workspace) + MLP_FRAG_BYTES);
     if (precision == LNERF_BF16) {
@@ -509,6 +518,7 @@ int lnerf_mlp_backward(const void *feat, int feat_dtype, int64_t level_stride, c
                            dfeat, slabs);
         LNERF_CHECK_LAUNCH("mlp_backward");
     }
+    if (defer_reduce) return LNERF_OK;
     hipLaunchKernelGGL(k_mlp_reduce_slabs, dim3((unsigned)div_up(SLAB, RED_P)), dim3(256), 0, s,
                        (const float *)slabs, (int)blocks, out_dim, accumulate, dw1, db1, dw2, db2, dw3, db3,
                        (uint32_t *)clear_ptr, (int)(clear_bytes / 4));

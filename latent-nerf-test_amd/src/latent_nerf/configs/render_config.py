@@ -54,6 +54,11 @@ class RenderConfig:
     mlp_precision: str = "auto"
     # "f32": gather reads the master table, "bf16": gather reads a bf16 shadow (half the bytes); "auto" as above
     table_dtype: str = "auto"
+    # layout of the hashed levels of the table: "hash" = Instant-NGP's spatial hash of the vertex; "blocked" = opt-in
+    # variant that hashes 4 x 2 x 2 vertex BLOCKS and keeps a block's 16 rows in one 64-byte line of the bf16 table
+    # (2.8 instead of 4.25 cache lines per sample and level in the gather; a different collision pattern, so tables are
+    # not interchangeable between the two)
+    gridtype: str = "hash"
     # workgroup -> (level, tile) mapping of the gather/scatter: 0 = level on grid.y (measured 1.8x faster), 1 = XCD-pinned levels
     gather_variant: int = 0
     # hash-grid backward: 0/1 = global float atomics, 2 = two-pass bucketed scatter (LDS reduction, exact f32

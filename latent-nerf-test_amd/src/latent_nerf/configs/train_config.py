@@ -58,6 +58,9 @@ class OptimConfig:
     # replay the step from captured hipGraphs (graph F: render / eager guidance / graph B: backward + optimiser); the
     # first steps, and the step after every change of the sample budget, run eagerly.  One view per rank and step.
     graph_step: bool = True
+    # a guidance object that is itself capturable (guidance.capturable: device ops only, device-side RNG -- the synthetic
+    # one) is captured INSIDE the step graph: one graph launch per step.  False: graph F / eager guidance / graph B always
+    graph_guidance: bool = True
 
 
 @dataclass
@@ -70,6 +73,8 @@ class LogConfig:
     full_eval_size: int = 100
     save_mesh: bool = False
     max_keep_ckpts: int = 2
+    # no progress lines on stdout (log.txt in the experiment directory is still written)
+    quiet: bool = False
     # evaluation renders go through the guidance model's decoder (vae.decode) instead of the linear latent->RGB preview
     decode_eval: bool = False
 

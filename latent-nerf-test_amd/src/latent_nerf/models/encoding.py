@@ -16,7 +16,11 @@ class GridLevels:
     """Host-side level table shared with the kernels (offsets in rows, per-level scale, resolution)."""
 
     def __init__(self, num_levels=16, level_dim=2, base_resolution=16, desired_resolution=2048,
-                 log2_hashmap_size=19):
+                 log2_hashmap_size=19, gridtype="hash"):
+        if gridtype not in ("hash", "blocked"):
+            raise ValueError("gridtype must be 'hash' (Instant-NGP) or 'blocked' (4 x 2 x 2 vertex blocks per 64-byte line)")
+        # flag OR-ed into the `variant` of every gather / scatter call (include/lnerf_hip.h LNERF_GRID_BLOCKED)
+        self.gridtype, self.flag = gridtype, (_b.GRID_BLOCKED if gridtype == "blocked" else 0)
         if level_dim != 2:
             raise ValueError("only level_dim == 2 is built")
         if not (1 <= num_levels <= 32):
@@ -57,7 +61,7 @@ def grid_encode_forward(xyzs, bound, table, levels: GridLevels, m_host, m_dev, l
     _b.call("lnerf_grid_encode_forward", _chk(xyzs, "xyzs"), float(bound), _chk(table, "table", table.dtype), tdt,
             levels.num_levels, levels.level_dim, levels.c_offsets, levels.c_scales, levels.c_res, int(m_host),
             _chk(m_dev, "m_dev", torch.int32, allow_none=True), int(level_stride), _chk(out, "feat", out.dtype), odt,
-            int(variant), _stream())
+            int(variant) | levels.flag, _stream())
     return out
 
 
@@ -80,6 +84,7 @@ def scatter_workspace(levels: GridLevels, m_host, device):
             return ws
     size = max(need, (3 * have[-1].numel()) // 2 if have else 0)
     ws = torch.empty(size, device=device, dtype=torch.uint8)
+    ws[:4096].zero_()      # header: the level maxima start out clean
     have.append(ws)
     return ws
 
@@ -109,7 +114,7 @@ def grid_encode_backward(xyzs, bound, dfeat, levels: GridLevels, m_host, m_dev, 
     _b.call("lnerf_grid_encode_backward", _chk(xyzs, "xyzs"), float(bound), _chk(dfeat, "dfeat"), _b.F32,
             levels.num_levels, levels.level_dim, levels.c_offsets, levels.c_scales, levels.c_res, int(m_host),
             _chk(m_dev, "m_dev", torch.int32, allow_none=True), int(level_stride), _chk(dtable, "dtable"),
-            int(variant), ws, ws_bytes, _stream())
+            int(variant) | levels.flag, ws, ws_bytes, _stream())
     return dtable
 
 
@@ -123,9 +128,15 @@ class FusedTableUpdate:
         self.exp_avg, self.exp_avg_sq = exp_avg, exp_avg_sq
         self.lr, self.betas, self.eps = float(lr), betas, float(eps)
         self.optimizer = optimizer          # step number / device step counter live there
-        self.zero = torch.zeros_like(exp_avg)  # dtable scratch: zero between calls (coarse levels, overflow records)
+        self.zero = torch.zeros_like(exp_avg)  # dtable scratch argument of the fused entry points (never written)
         self.applied = 0                    # fused updates since the last optimizer.step()
         self.armed = False
+        # tail mode (FusedAdam(tail=True)): the armed backward leaves the finishing pass of the scatter and the sum of
+        # the MLP's gradient slabs to ONE launch in optimizer.step() (lnerf_step_tail), which also steps the MLP's
+        # parameters, ticks the step counter and leaves the scatter's level maxima zero for the next step
+        self.tail = False
+        self.pending_tail = None            # (levels, m_host, variant, scatter workspace, mlp workspace, precision, out_dim)
+        self.clean_ws = None                # data_ptr of the scatter workspace whose level maxima are known to be zero
 
     def take(self):
         """True once per arm(): the caller (a backward pass) then owes the fused update."""
@@ -139,7 +150,7 @@ def grid_encode_backward_adam(xyzs, bound, dfeat, encoder, m_host, m_dev, level_
     """Scatter of dfeat fused with the Adam step of encoder.embeddings (see include/lnerf_hip.h)."""
     fu = encoder.fused_update
     levels = encoder.levels
-    if variant < 2:
+    if (variant & 0xFF) < 2:
         raise _b.LnerfError("the fused table update needs the bucketed scatter (variant 2 or 3)")
     wst = scatter_workspace(levels, m_host, xyzs.device)
     opt = fu.optimizer
@@ -148,8 +159,8 @@ def grid_encode_backward_adam(xyzs, bound, dfeat, encoder, m_host, m_dev, level_
     b1, b2 = fu.betas
     _b.call("lnerf_grid_encode_backward_adam", _chk(xyzs, "xyzs"), float(bound), _chk(dfeat, "dfeat"), _b.F32,
             levels.num_levels, levels.level_dim, levels.c_offsets, levels.c_scales, levels.c_res, int(m_host),
-            _chk(m_dev, "m_dev", torch.int32, allow_none=True), int(level_stride), _p(fu.zero), int(variant), _p(wst),
-            wst.numel(), _p(table), _p(fu.exp_avg), _p(fu.exp_avg_sq), _p(shadow), fu.lr, b1, b2, fu.eps,
+            _chk(m_dev, "m_dev", torch.int32, allow_none=True), int(level_stride), _p(fu.zero), int(variant) | levels.flag,
+            _p(wst), wst.numel(), _p(table), _p(fu.exp_avg), _p(fu.exp_avg_sq), _p(shadow), fu.lr, b1, b2, fu.eps,
             opt.step_no + 1, _p(opt.step_dev), float(opt.grad_scale), _stream())
     fu.applied += 1
 
@@ -196,14 +207,14 @@ def grid_encode_backward_bf16(xyzs, bound, dfeat, encoder, m_host, m_dev, level_
     if sink.groups:   # pipelined: pass 1 now, pass 2 per level group inside GradSync.allreduce_pipelined()
         _b.call("lnerf_grid_scatter_bin", _chk(xyzs, "xyzs"), float(bound), _chk(dfeat, "dfeat"), _b.F32,
                 levels.num_levels, levels.level_dim, levels.c_offsets, levels.c_scales, levels.c_res, int(m_host),
-                _chk(m_dev, "m_dev", torch.int32, allow_none=True), int(level_stride), _p(sink.zero), int(variant),
-                _p(wst), wst.numel(), _stream())
+                _chk(m_dev, "m_dev", torch.int32, allow_none=True), int(level_stride), _p(sink.zero),
+                int(variant) | levels.flag, _p(wst), wst.numel(), _stream())
         sink.pending = (float(bound), levels, int(m_host), int(level_stride), int(variant), wst)
         return
     _b.call("lnerf_grid_encode_backward_bf16", _chk(xyzs, "xyzs"), float(bound), _chk(dfeat, "dfeat"), _b.F32,
             levels.num_levels, levels.level_dim, levels.c_offsets, levels.c_scales, levels.c_res, int(m_host),
-            _chk(m_dev, "m_dev", torch.int32, allow_none=True), int(level_stride), _p(sink.zero), int(variant), _p(wst),
-            wst.numel(), _p(sink.wire), _stream())
+            _chk(m_dev, "m_dev", torch.int32, allow_none=True), int(level_stride), _p(sink.zero),
+            int(variant) | levels.flag, _p(wst), wst.numel(), _p(sink.wire), _stream())
     sink.written += 1
 
 
@@ -251,6 +262,8 @@ class _GridEncode(torch.autograd.Function):
                                       variant)
             return (None,) * 12
         dtable = torch.zeros(shape, device=dev, dtype=torch.float32)
+        if enc is not None and enc.fused_update is not None:
+            enc.fused_update.clean_ws = None     # (this call leaves its level maxima in the shared workspace)
         grid_encode_backward(xyzs, bound, dfeat, levels, m_host, m_dev if ctx.has_mdev else None, level_stride,
                              dtable, variant)
         return None, dtable, None, None, None, None, None, None, None, None, None, None
@@ -262,9 +275,10 @@ class GridEncoder(nn.Module):
     the master changed (or explicitly by the fused Adam step)."""
 
     def __init__(self, num_levels=16, level_dim=2, base_resolution=16, desired_resolution=2048,
-                 log2_hashmap_size=19, table_dtype=torch.float32, variant=0, scatter_variant=2):
+                 log2_hashmap_size=19, table_dtype=torch.float32, variant=0, scatter_variant=2, gridtype="hash"):
         super().__init__()
-        self.levels = GridLevels(num_levels, level_dim, base_resolution, desired_resolution, log2_hashmap_size)
+        self.levels = GridLevels(num_levels, level_dim, base_resolution, desired_resolution, log2_hashmap_size,
+                                 gridtype=gridtype)
         self.out_dim = self.levels.out_dim
         self.variant = variant
         self.scatter_variant = scatter_variant

@@ -104,27 +104,48 @@ class _HashMLPField(torch.autograd.Function):
         dsigmas = torch.zeros_like(sigmas) if dsigmas is None else dsigmas.contiguous()
         drgbs = torch.zeros(level_stride, out_dim - 1, device=dev) if drgbs is None else drgbs.contiguous()
         dfeat = torch.empty(feat.shape, device=dev, dtype=torch.float32)
-        grads = [torch.empty_like(t) for t in (w1, b1, w2, b2, w3, b3)]  # overwritten (accumulate = 0)
         need = _b.get_lib().lnerf_mlp_backward_workspace_bytes(out_dim)
-        if workspace is None or workspace.numel() < need:
+        own_ws = workspace is not None and workspace.numel() >= need
+        base_precision = precision
+        if not own_ws:
             workspace = torch.empty(need, device=dev, dtype=torch.uint8)
         elif precision == _b.BF16:
             # this node's forward left the weight fragments at the head of the same workspace, and autograd's
             # version check on the saved weights guarantees they have not changed since
             precision |= _b.MLP_FRAGMENTS_READY
         fdt = _b.F32 if feat.dtype == torch.float32 else _b.BF16
-        # the bucketed scatter that follows needs its cursors cleared: the MLP's slab-reduction launch does it on the
+        fu = encoder.fused_update
+        sv = encoder.scatter_variant
+        # TAIL mode (FusedAdam(tail=True), armed, m_host > 0): the slab sum, the Adam step of the six MLP tensors and the
+        # scatter's finishing pass are left to ONE launch in optimizer.step() (lnerf_step_tail): no weight gradients here
+        tail = fu is not None and fu.armed and fu.tail and own_ws and sv >= 2 and m_host > 0
+        if tail:
+            wst = E.scatter_workspace(encoder.levels, m_host, dev)
+            _b.call("lnerf_mlp_backward", _p(feat), fdt, int(level_stride), _p(xyzs), _p(w1), _p(b1), _p(w2), _p(b2),
+                    _p(w3), _p(b3), out_dim, float(blob_scale), float(blob_std), int(m_host), _p(m_dev), _p(sigmas),
+                    _chk(dsigmas, "dsigmas"), _chk(drgbs, "drgbs"), _p(dfeat), None, None, None, None, None, None, 0,
+                    _p(workspace), workspace.numel(), precision | _b.MLP_DEFER_REDUCE, None, 0, _stream())
+            fu.take()
+            flags = _b.SCATTER_DEFER_FINISH | (_b.SCATTER_CLEARED if fu.clean_ws == wst.data_ptr() else 0)
+            fu.clean_ws = None
+            E.grid_encode_backward_adam(xyzs, bound, dfeat, encoder, m_host, m_dev, level_stride, sv | flags)
+            fu.pending_tail = (encoder.levels, int(m_host), int(sv), wst, workspace, int(base_precision), int(out_dim))
+            return (None,) * 19
+        grads = [torch.empty_like(t) for t in (w1, b1, w2, b2, w3, b3)]  # overwritten (accumulate = 0)
+        # the bucketed scatter that follows needs its level maxima cleared: the MLP's slab-reduction launch does it on the
         # side (one dispatch less per step than the scatter's own fill)
-        sv, clear_ptr, clear_bytes = encoder.scatter_variant, None, 0
+        clear_ptr, clear_bytes = None, 0
         if sv >= 2 and m_host > 0:
             wst = E.scatter_workspace(encoder.levels, m_host, dev)
             clear_bytes = E.scatter_clear_bytes(encoder.levels, m_host)
             clear_ptr, sv = _p(wst), sv | _b.SCATTER_CLEARED
+            if fu is not None:
+                fu.clean_ws = None
         _b.call("lnerf_mlp_backward", _p(feat), fdt, int(level_stride), _p(xyzs), _p(w1), _p(b1), _p(w2), _p(b2),
                 _p(w3), _p(b3), out_dim, float(blob_scale), float(blob_std), int(m_host), _p(m_dev), _p(sigmas),
                 _chk(dsigmas, "dsigmas"), _chk(drgbs, "drgbs"), _p(dfeat), *[_p(g) for g in grads], 0, _p(workspace),
                 workspace.numel(), precision, clear_ptr, clear_bytes, _stream())
-        if encoder.fused_update is not None and encoder.fused_update.take():  # armed: the scatter applies the table's Adam step
+        if fu is not None and fu.take():  # armed: the scatter applies the table's Adam step
             E.grid_encode_backward_adam(xyzs, bound, dfeat, encoder, m_host, m_dev, level_stride, sv)
             dtable = None
         elif encoder.grad_sink is not None:  # data parallel: the gradient goes straight into the bf16 wire buffer
@@ -149,7 +170,8 @@ class NeRFNetwork(NeRFRenderer):
         self.encoder = GridEncoder(num_levels, level_dim, base_resolution, 2048 * self.bound, log2_hashmap_size,
                                    table_dtype=table_dtype, variant=cfg.gather_variant,
                                    scatter_variant=(cfg.scatter_variant if cfg.scatter_variant >= 0
-                                                    else (3 if self.precision == "bf16" else 2)))
+                                                    else (3 if self.precision == "bf16" else 2)),
+                                   gridtype=getattr(cfg, "gridtype", "hash"))
         in_dim, out_dim = self.encoder.out_dim, 1 + self.img_dims
         # nn.Linear default init, kept as bare parameters: the fused kernel takes all six at once
         self.w1 = nn.Parameter(torch.empty(hidden_dim, in_dim))

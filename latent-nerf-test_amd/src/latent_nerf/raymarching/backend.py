@@ -16,6 +16,10 @@ LNERF_OK = 0
 F32, BF16 = 0, 1
 MLP_FRAGMENTS_READY = 0x100   # flag on lnerf_mlp_backward's precision tag (include/lnerf_hip.h)
 MLP_FRAGMENT_BYTES = 36 * 1024  # LNERF_MLP_FRAGMENT_BYTES: the bf16 weight-fragment image at the head of the MLP workspace
+SCATTER_DEFER_FINISH = 0x200  # flag on the scatter's variant: lnerf_step_tail runs the finishing pass
+MLP_DEFER_REDUCE = 0x200      # flag on lnerf_mlp_backward's precision tag: lnerf_step_tail sums the slabs
+TAIL_TICK, TAIL_CLEAR_SCATTER = 1, 2
+GRID_BLOCKED = 0x400          # flag on the gather's / scatter's variant: blocked layout of the hashed levels
 SCATTER_CLEARED = 0x100       # flag on the scatter's variant: the caller cleared the cursors (lnerf_grid_scatter_clear_bytes)
 
 
@@ -96,6 +100,9 @@ _SIGNATURES = {
     "lnerf_adam_step_multi_shadow": [_I, _P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _F, _I, _P, _P, _P],
     "lnerf_mlp_fragment_maps": [_I, _P, _P, _P, _P],
     "lnerf_cast_f32_to_bf16": [_P, _P, _L, _P],
+    "lnerf_mlp_backward_slabs": [_L, _I],
+    "lnerf_step_tail": [_I, _I, _P, _P, _P, _L, _I, _P, _Z, _P, _P, _P, _P, _P, _F, _P, _Z, _I, _I, _P, _P, _P, _F, _P,
+                        _F, _F, _F, _I, _P, _F, _I, _P],
 }
 _RESTYPES = {
     "lnerf_last_error": _c.c_char_p,

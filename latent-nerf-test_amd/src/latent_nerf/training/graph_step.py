@@ -127,3 +127,26 @@ class GraphedRenderStep:
     def backward(self):
         self.graph_b.replay()
         return self.static_grads
+
+
+class GraphedWholeStep:
+    """One captured graph for a step whose guidance is itself capturable (device ops on static shapes, device-side RNG:
+    the seeded synthetic guidance): render -> guidance -> backward -> optimiser, ONE graph launch per step.  `fn()` runs
+    the whole step and returns (out dict, pred)."""
+
+    def __init__(self, fn, params, stream):
+        self.stream = stream
+        self.params = list(params)
+        for p in self.params:
+            p.grad = None
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=stream):
+            self.out, self.pred = fn()
+        self.static_grads = [p.grad for p in self.params]
+        for p in self.params:
+            p.grad = None
+
+    def replay(self):
+        self.graph.replay()
+        return self.static_grads

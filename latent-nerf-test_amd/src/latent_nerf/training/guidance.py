@@ -90,6 +90,24 @@ class SyntheticGuidance(Guidance):
         """Stand-in for the VAE decoder: the linear preview (see linear_decode_latents)."""
         return linear_decode_latents(latents)
 
+    # Every op of train_step_device is a device op on static shapes with device-side RNG: the trainer captures it INSIDE
+    # its step graph (one graph launch per step instead of graph / eager launches / graph)
+    capturable = True
+
+    @torch.no_grad()
+    def train_step_device(self, latents, dir_index):
+        """train_step with the view bucket as a DEVICE int32 tensor [B] (no host value anywhere): same arithmetic, same
+        random draws in the same order."""
+        target = torch.index_select(self.targets, 0, dir_index)
+        if target.shape[-2:] != latents.shape[-2:]:
+            target = torch.nn.functional.interpolate(target, size=latents.shape[-2:], mode="bilinear",
+                                                     align_corners=False)
+        t = torch.randint(self.min_step, self.max_step + 1, [1], device=latents.device)
+        w = self.weights[t]
+        grad = torch.randn_like(latents).mul_(self.noise_scale)
+        grad.add_(latents - target)
+        return grad.mul_(w)
+
     @torch.no_grad()
     def train_step(self, text_z, latents, dirs=None):
         """(few launches: the trainer's step is a graph replay either side of this call, every eager launch here is on

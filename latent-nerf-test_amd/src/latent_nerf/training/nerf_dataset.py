@@ -7,7 +7,7 @@ import math
 import numpy as np
 import torch
 
-from ...utils import get_view_direction
+from ...utils import get_view_direction, view_direction_index
 from ..models.nerf_utils import intrinsics_from_fov, pose_from_angles
 from ..raymarching import raymarching as rm
 
@@ -34,8 +34,10 @@ class NeRFDataset:
             phi = math.radians((index / self.size) * 360.0)
             fov = 0.5 * (cfg.fovy_range[0] + cfg.fovy_range[1])
         theta = max(theta, 1e-3)
-        dirs = get_view_direction(torch.tensor([theta]), torch.tensor([phi]), np.deg2rad(cfg.angle_overhead),
-                                  np.deg2rad(cfg.angle_front))
+        # (the reference's callers pass already-converted radians for the two cone angles, src/utils.py:8-27 as called
+        # from src/latent_paint/training/views_dataset.py:12-22; scalar form of get_view_direction for the one view)
+        dirs = torch.tensor([view_direction_index(theta, phi, np.deg2rad(cfg.angle_overhead),
+                                                  np.deg2rad(cfg.angle_front))], dtype=torch.long)
         return {"theta": theta, "phi": phi, "radius": radius, "fov": fov, "dir": dirs}
 
     def collate(self, index=0, generator=None, device_pose=True):

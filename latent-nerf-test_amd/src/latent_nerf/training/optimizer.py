@@ -13,7 +13,7 @@ from ..raymarching.raymarching import _p, _stream
 
 class FusedAdam:
     def __init__(self, param_groups, betas=(0.9, 0.99), eps=1e-15, encoder=None, capturable=False,
-                 fuse_table_update=False, mlp=None):
+                 fuse_table_update=False, mlp=None, tail=None):
         """param_groups: [{'params': [...], 'lr': float}, ...] (as NeRFNetwork.get_params(lr)).
         encoder: the GridEncoder whose `embeddings` are in the groups (for the bf16 shadow refresh).
         fuse_table_update: the hash table's Adam step can be applied by the scatter of the backward pass
@@ -22,7 +22,12 @@ class FusedAdam:
         whose backward was not armed takes the ordinary path.
         mlp: the NeRFNetwork whose w1 / w2 / w3 are in the groups (bf16 MLP): the multi-tensor launch then also writes
         the updated weights into the network's bf16 weight fragments (lnerf_adam_step_multi_shadow), and the network's
-        forward stops rebuilding them every step (one dispatch less)."""
+        forward stops rebuilding them every step (one dispatch less).
+        tail (default: on whenever fuse_table_update and mlp are given): an ARMED step ends with ONE launch
+        (lnerf_step_tail) that runs the scatter's finishing pass, sums the MLP's gradient slabs and steps its six
+        tensors straight from the sums, advances the device step counter and leaves the scatter's level maxima clean for
+        the next step -- instead of the slab-sum launch inside the backward pass, the scatter's finishing launch and the
+        multi-tensor Adam launch.  The six tensors then never get a `.grad` on armed steps."""
         self.betas, self.eps = betas, eps
         self.encoder = encoder
         self.step_no = 0
@@ -88,6 +93,28 @@ class FusedAdam:
                     encoder.fused_update = self.fused
             if self.fused is None:
                 raise ValueError("fuse_table_update: encoder.embeddings is not among the parameters")
+        self._tail = None
+        if tail is None:
+            tail = self.fused is not None and mlp is not None
+        if tail:
+            if self.fused is None or mlp is None:
+                raise ValueError("FusedAdam(tail=True) needs fuse_table_update=True and mlp=<the network>")
+            six = [getattr(mlp, k) for k in ("w1", "b1", "w2", "b2", "w3", "b3")]
+            idx = []
+            for q in six:
+                hit = [k for k, e in enumerate(self.small) if e[0] is q]
+                if not hit:
+                    raise ValueError("FusedAdam(tail=True): the MLP's six tensors must be among the small parameters")
+                idx.append(hit[0])
+            lrs = {self.small[k][3] for k in idx}
+            if len(lrs) != 1:
+                raise ValueError("FusedAdam(tail=True): the MLP's six tensors must share one learning rate")
+            self._tail = {"idx": idx, "lr": lrs.pop(), "net": mlp,
+                          "p": (ctypes.c_void_p * 6)(), "m": (ctypes.c_void_p * 6)(*[self.small[k][1].data_ptr() for k in idx]),
+                          "v": (ctypes.c_void_p * 6)(*[self.small[k][2].data_ptr() for k in idx]),
+                          "maps": None if self._map_tensors is None else
+                          (ctypes.c_void_p * 3)(*[self._map_tensors[n].data_ptr() for n in ("w1", "w2", "w3")])}
+            self.fused.tail = True
 
     def arm(self):
         """Let the NEXT backward through the encoder apply the table's Adam step (no-op without fuse_table_update)."""
@@ -137,7 +164,10 @@ class FusedAdam:
                 _b.call("lnerf_adam_step", _p(p.data[sl]), _p(g[sl]), gdt, _p(m[sl]), _p(v[sl]),
                         None if shadow is None else _p(shadow[sl]), p.data[sl].numel(), lr, b1, b2, self.eps,
                         self.step_no, _p(self.step_dev), float(grad_scale), 0, _stream())
-        if self.small:
+        pend = self.fused.pending_tail if self.fused is not None else None
+        if pend is not None:
+            self._step_tail(pend, float(grad_scale))
+        elif self.small:
             for k, (p, m, v, lr) in enumerate(self.small):
                 g = p.grad if grads is None else grads.get(p, p.grad)
                 if g is None:
@@ -165,6 +195,41 @@ class FusedAdam:
         if set_to_none:
             for p, *_ in self.big + self.small:
                 p.grad = None
+
+    def _step_tail(self, pend, grad_scale):
+        """The armed step's last launch (see __init__): lnerf_step_tail.  Small parameters outside the MLP (a background
+        net) take the ordinary multi-tensor launch first; the tail ticks the step counter, so it goes last."""
+        t = self._tail
+        levels, m_host, variant, wst, mlp_ws, precision, out_dim = pend
+        b1, b2 = self.betas
+        rest = [k for k in range(len(self.small)) if k not in t["idx"]]
+        if rest:
+            n = len(rest)
+            pp, gp = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
+            mp, vp = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
+            nn, lr = (ctypes.c_int64 * n)(), (ctypes.c_float * n)()
+            for j, k in enumerate(rest):
+                p, m, v, lr_k = self.small[k]
+                if p.grad is None:
+                    raise RuntimeError("FusedAdam: parameter %d has no gradient" % k)
+                pp[j], gp[j], mp[j], vp[j] = p.data.data_ptr(), p.grad.data_ptr(), m.data_ptr(), v.data_ptr()
+                nn[j], lr[j] = p.numel(), lr_k
+            _b.call("lnerf_adam_step_multi_shadow", n, pp, gp, mp, vp, nn, lr, b1, b2, self.eps, self.step_no,
+                    _p(self.step_dev), grad_scale, 0, None, None, _stream())
+        for j, k in enumerate(t["idx"]):
+            t["p"][j] = self.small[k][0].data.data_ptr()
+        fu = self.fused
+        enc = self.encoder
+        # (tick and clearing epilogue need the device counter pair: without it -- capturable=False -- the next scatter
+        # call clears its level maxima itself)
+        flags = (_b.TAIL_CLEAR_SCATTER | _b.TAIL_TICK) if self.step_dev is not None else 0
+        _b.call("lnerf_step_tail", levels.num_levels, levels.level_dim, levels.c_offsets, levels.c_scales, levels.c_res,
+                int(m_host), int(variant), _p(wst), wst.numel(), _p(fu.zero), _p(enc.embeddings.data), _p(fu.exp_avg),
+                _p(fu.exp_avg_sq), _p(enc.shadow()), fu.lr, _p(mlp_ws), mlp_ws.numel(), int(precision), int(out_dim),
+                t["p"], t["m"], t["v"], float(t["lr"]), t["maps"], b1, b2, self.eps, self.step_no, _p(self.step_dev),
+                grad_scale, flags, _stream())
+        fu.pending_tail = None
+        fu.clean_ws = wst.data_ptr() if flags & _b.TAIL_CLEAR_SCATTER else None
 
     def note_replayed_step(self):
         """A captured graph that contains step() was replayed: the device counter advanced, the host mirror follows

@@ -68,9 +68,11 @@ class Trainer:
         self.optimizer = FusedAdam(self.nerf.get_params(cfg.optim.lr), betas=(0.9, 0.99), eps=1e-15,
                                    encoder=self.nerf.encoder, fuse_table_update=fuse, mlp=self.nerf, capturable=True)
         # the whole loop (eager steps, captures, replays, collectives) runs on ONE non-default stream: autograd pins a
-        # parameter's gradient accumulation to the stream it first ran on, and the legacy default stream cannot capture
+        # parameter's gradient accumulation to the stream it first ran on, and the legacy default stream cannot capture.
+        # Code that back-propagates through `self.nerf` outside train() must do so under
+        # `torch.cuda.stream(trainer.stream)` (or set optim.graph_step = false).
         self.stream = torch.cuda.Stream(device=self.device)
-        self._gstep, self._gstep_capacity, self._static = None, None, None
+        self._gstep, self._gstep_capacity, self._static, self._whole = None, None, None, False
         self.graph_stats = {"captures": 0, "replayed_steps": 0, "eager_steps": 0}
         small = [p for p in self.nerf.parameters() if p is not self.nerf.encoder.embeddings]
         # exchange: bf16 on the wire with the bf16 configuration (f32 otherwise); with one view per rank and step the
@@ -94,7 +96,8 @@ class Trainer:
     # ------------------------------------------------------------------ set-up
     def log(self, msg):
         if self.rank == 0:
-            print("[trainer] " + msg, flush=True)
+            if not getattr(self.cfg.log, "quiet", False):
+                print("[trainer] " + msg, flush=True)
             with open(self.exp_path / "log.txt", "a") as f:
                 f.write(msg + "\n")
 
@@ -209,8 +212,9 @@ class Trainer:
                             "grad": torch.zeros(1, C, H, W, device=self.device),
                             # ring of pinned upload slots: the host runs steps ahead of the GPU, a slot is rewritten
                             # only after the copy that read it has executed (event per slot)
-                            "host": torch.zeros(64, 20, dtype=torch.float32).pin_memory(), "events": [None] * 64,
-                            "cam": torch.zeros(20, device=self.device)}
+                            # (16 pose + 4 intrinsics + the view bucket as an int32 bit pattern)
+                            "host": torch.zeros(64, 21, dtype=torch.float32).pin_memory(), "events": [None] * 64,
+                            "cam": torch.zeros(21, device=self.device)}
         st = self._static
         solo = not self.exchange
         opt = self.optimizer
@@ -227,7 +231,26 @@ class Trainer:
             if solo:
                 opt.step(grad_scale=1.0)
 
-        self._gstep = GraphedRenderStep(forward, backward, list(self.nerf.parameters()), self.stream)
+        # a guidance that is itself capturable (the synthetic one) goes INSIDE the graph: one launch per step
+        self._whole = bool(getattr(self.diffusion, "capturable", False)) and hasattr(self.diffusion, "train_step_device") \
+            and bool(getattr(self.cfg.optim, "graph_guidance", True))
+        if self._whole:
+            from .graph_step import GraphedWholeStep
+            dir_dev = st["cam"][20:21].view(torch.int32)
+
+            def whole():
+                out, pred = forward()
+                grad = self.diffusion.train_step_device(pred, dir_dev)
+                if solo:
+                    opt.arm()
+                self._backward(out, pred, grad)
+                if solo:
+                    opt.step(grad_scale=1.0)
+                return out, pred
+
+            self._gstep = GraphedWholeStep(whole, list(self.nerf.parameters()), self.stream)
+        else:
+            self._gstep = GraphedRenderStep(forward, backward, list(self.nerf.parameters()), self.stream)
         opt.step_no, self.nerf.local_step = keep   # host-side counters the captured Python advanced
         self._gstep_capacity = self.nerf._march.capacity
         self.graph_stats["captures"] += 1
@@ -240,13 +263,17 @@ class Trainer:
         host = st["host"][slot]
         host[:16] = data["pose"].reshape(-1)
         host[16:20] = torch.tensor(data["camera"][1], dtype=torch.float32)
+        host[20:21].view(torch.int32)[0] = int(data["dir"][0])
         st["cam"].copy_(host, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         st["events"][slot] = ev
-        out, pred = g.forward()
-        st["grad"].copy_(self._guidance_grad(pred, data["dir"]))
-        grads = g.backward()
+        if self._whole:
+            grads = g.replay()
+        else:
+            out, pred = g.forward()
+            st["grad"].copy_(self._guidance_grad(pred, data["dir"]))
+            grads = g.backward()
         self.nerf.local_step += 1
         if not self.exchange:
             self.optimizer.note_replayed_step()

@@ -36,6 +36,34 @@ def get_view_direction(elev, azim, top=30, front=0, angle=45):
     return view
 
 
+def view_direction_index(elev, azim, top=30, front=0, angle=45) -> int:
+    """get_view_direction for ONE view given as Python floats: the same comparisons on the same float32-rounded values
+    (a float32 tensor compared with a Python scalar compares in float32), without building one-element tensors -- this
+    runs once per training step on the host.  Checked against the tensor form in tests/test_utils_golden.py."""
+    f32 = np.float32
+    two_pi = f32(_TWO_PI)
+    az = np.fmod(f32(azim), two_pi)
+    az = az + two_pi if az < 0 else az
+    el = np.fmod(f32(elev), two_pi)
+    el = el + two_pi if el < 0 else el
+    lo_front, hi_front = f32(_deg_wrapped(front - angle)), f32(_deg_wrapped(front + angle))
+    lo_back, hi_back = f32(_deg_wrapped(front + 180 - angle)), f32(_deg_wrapped(front + 180 + angle))
+    view = 0
+    if az >= lo_front or az < hi_front:
+        view = 0
+    if az >= hi_back and az < lo_front:
+        view = 1
+    if az >= lo_back and az < hi_back:
+        view = 2
+    if az >= hi_front and az < lo_back:
+        view = 3
+    if el < f32(_deg_wrapped(top)):
+        view = 4
+    if el > f32(_deg_wrapped(180 - top)):
+        view = 5
+    return view
+
+
 def tensor2numpy(tensor: torch.Tensor) -> np.ndarray:
     arr = tensor.detach().cpu().numpy()
     if arr.min() < 0:

@@ -339,6 +339,7 @@ class GridLevels:
     offsets: list          # L+1 entry offsets (in table rows)
     scales: list           # float32 per-level scale  (exp2(l*S)*base - 1)
     resolutions: list      # ceil(scale)+1
+    blocked: bool = False  # opt-in layout of the hashed levels (grid_corner_indices)
 
     @property
     def n_rows(self) -> int:
@@ -346,7 +347,7 @@ class GridLevels:
 
 
 def make_grid_levels(num_levels=16, level_dim=2, base_resolution=16, desired_resolution=2048,
-                     log2_hashmap_size=19) -> GridLevels:
+                     log2_hashmap_size=19, blocked=False) -> GridLevels:
     """Level table of the Instant-NGP hash grid (align_corners=False convention: a level with
     resolution R stores (R+1)^3 vertices, capped at 2^log2_hashmap_size, rounded up to 8)."""
     max_params = 2 ** log2_hashmap_size
@@ -365,15 +366,22 @@ def make_grid_levels(num_levels=16, level_dim=2, base_resolution=16, desired_res
         scales.append(scale)
         ress.append(int(math.ceil(scale)) + 1)
     return GridLevels(num_levels, level_dim, base_resolution, desired_resolution, log2_hashmap_size,
-                      offsets, scales, ress)
+                      offsets, scales, ress, bool(blocked))
 
 
 _PRIMES = (1, 2654435761, 805459861)
 
 
-def grid_corner_indices(pos_grid: torch.Tensor, res: int, hashmap_size: int) -> torch.Tensor:
-    """pos_grid int64 [...,3] -> row index inside the level (uint32 arithmetic)."""
+def grid_corner_indices(pos_grid: torch.Tensor, res: int, hashmap_size: int, blocked: bool = False) -> torch.Tensor:
+    """pos_grid int64 [...,3] -> row index inside the level (uint32 arithmetic).
+    blocked (our own opt-in variant, include/lnerf_hip.h LNERF_GRID_BLOCKED; dense levels unchanged): on a hashed level
+    the lattice is cut into blocks of 4 x 2 x 2 vertices, the block coordinate is hashed, a block's 16 rows are
+    consecutive: row = (hash(x >> 2, y >> 1, z >> 1) mod (hashmap_size // 16)) * 16 + (x & 3) + 4 (y & 1) + 8 (z & 1)."""
     m = 0xFFFFFFFF
+    if blocked and (res + 1) ** 3 > hashmap_size:
+        x, y, z = pos_grid[..., 0], pos_grid[..., 1], pos_grid[..., 2]
+        h = (((x >> 2) * _PRIMES[0]) & m) ^ (((y >> 1) * _PRIMES[1]) & m) ^ (((z >> 1) * _PRIMES[2]) & m)
+        return (h % (hashmap_size // 16)) * 16 + ((x & 3) | ((y & 1) << 2) | ((z & 1) << 3))
     stride = 1
     index = torch.zeros(pos_grid.shape[:-1], dtype=torch.int64)
     d = 0
@@ -387,9 +395,42 @@ def grid_corner_indices(pos_grid: torch.Tensor, res: int, hashmap_size: int) -> 
     return index % hashmap_size
 
 
-def grid_encode(x01: torch.Tensor, table: torch.Tensor, lv: GridLevels) -> torch.Tensor:
+def f26_round(v: torch.Tensor) -> torch.Tensor:
+    """Value format of the packed 8-byte scatter records (csrc/grid.hip Rec8 / f26_round; our own definition): sign, 8
+    exponent and 17 mantissa bits -- the f32 bit pattern plus 0x20 (round to nearest, ties away from zero) with the low
+    6 bits dropped.  Relative rounding 2^-18 per addend."""
+    bits = v.contiguous().view(torch.int32)
+    finite = (bits & 0x7F800000) != 0x7F800000
+    bits = torch.where(finite, bits + 0x20, bits) & ~0x3F
+    return bits.view(torch.float32)
+
+
+class _CornerGather(torch.autograd.Function):
+    """w * table[idx] of one cell corner.  Backward: the records of the bucketed scatter -- one contribution w * g per
+    (sample, corner), rounded to the 26-bit record format when `rec8` (scatter variant 3, the bf16 configuration), summed
+    per table row.  (The kernel sums in 64-bit fixed point at 2^-30 of the level's largest value and, on levels whose
+    cells hold runs of samples, rounds the run's f32 sum instead of each addend: both below 2^-18 relative.)"""
+
+    @staticmethod
+    def forward(ctx, table, idx, w, rec8):
+        ctx.save_for_backward(idx, w)
+        ctx.meta = (table.shape, rec8)
+        return w[:, None] * table[idx]
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, w = ctx.saved_tensors
+        shape, rec8 = ctx.meta
+        contrib = w[:, None] * g
+        if rec8:
+            contrib = f26_round(contrib)
+        return torch.zeros(shape, dtype=g.dtype).index_add_(0, idx, contrib), None, None, None
+
+
+def grid_encode(x01: torch.Tensor, table: torch.Tensor, lv: GridLevels, rec8: bool = False) -> torch.Tensor:
     """H5.  x01 [M,3] in [0,1]; table [n_rows, F] -> features [M, L*F] (level-major columns:
-    column l*F+f).  Differentiable w.r.t. `table` (H6 = autograd of the index ops)."""
+    column l*F+f).  Differentiable w.r.t. `table` (H6 = autograd of the index ops; `rec8`: with the record rounding of
+    scatter variant 3, see _CornerGather)."""
     M = x01.shape[0]
     outs = []
     for l in range(lv.num_levels):
@@ -409,8 +450,8 @@ def grid_encode(x01: torch.Tensor, table: torch.Tensor, lv: GridLevels) -> torch
             wz = frac[:, 2] if bz else 1.0 - frac[:, 2]
             w = (wx * wy) * wz
             corner = pg + torch.tensor([bx, by, bz], dtype=torch.int64)
-            idx = grid_corner_indices(corner, res, hsize) + lv.offsets[l]
-            acc = acc + w[:, None] * table[idx]
+            idx = grid_corner_indices(corner, res, hsize, getattr(lv, "blocked", False)) + lv.offsets[l]
+            acc = acc + (_CornerGather.apply(table, idx, w, True) if rec8 else w[:, None] * table[idx])
         outs.append(acc)
     return torch.cat(outs, dim=-1)
 
@@ -444,18 +485,43 @@ def _bf16r(t: torch.Tensor) -> torch.Tensor:
     return t.to(torch.bfloat16).to(torch.float32)
 
 
+class _Bf16Linear(torch.autograd.Function):
+    """One layer of the bf16 MFMA path (csrc/mlp_bf16.hip), forward AND backward: every MFMA operand is a bf16 value,
+    every accumulation is f32.
+        forward :  y = r(x) r(W)^T + b
+        backward:  the upstream gradient dZ is rounded ONCE (the packed B fragment the kernel builds from it) and that
+                   rounded value feeds all three products: dX = r(dZ) r(W),  dW = r(dZ)^T r(x),  db = sum r(dZ)
+    (relu's mask is the sign of the rounded activation, i.e. of the activation itself.)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        xr, wr = _bf16r(x), _bf16r(w)
+        ctx.save_for_backward(xr, wr)
+        return xr @ wr.t() + b
+
+    @staticmethod
+    def backward(ctx, g):
+        xr, wr = ctx.saved_tensors
+        gr = _bf16r(g)
+        return gr @ wr, gr.t() @ xr, gr.sum(0)
+
+
 def sigma_latent_mlp(feat: torch.Tensor, xyz: torch.Tensor, params: dict, blob_scale=5.0, blob_std=0.2,
                      bf16: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """H7.  feat [M,32] -> h = W3 relu(W2 relu(W1 feat + b1) + b2) + b3  (32 -> 64 -> 64 -> 1+C);
     sigma = trunc_exp(h[:,0] + blob(xyz)); latent = h[:,1:]  (no squashing in latent mode).
-    `bf16=True` rounds the operands of every product (features, weights, hidden activations) to
-    bfloat16 and accumulates in fp32 -- the arithmetic of the bf16 MFMA path."""
-    r = _bf16r if bf16 else (lambda t: t)
-    h = F.linear(r(feat), r(params["w1"]), params["b1"])
+    `bf16=True`: the arithmetic of the bf16 MFMA path in both directions (_Bf16Linear) -- the operands of every product
+    (features, weights, hidden activations; in the backward pass the pre-activation gradients) are rounded to bfloat16,
+    accumulation is fp32."""
+    if bf16:
+        lin = _Bf16Linear.apply
+    else:
+        lin = F.linear
+    h = lin(feat, params["w1"], params["b1"])
     h = F.relu(h)
-    h = F.linear(r(h), r(params["w2"]), params["b2"])
+    h = lin(h, params["w2"], params["b2"])
     h = F.relu(h)
-    h = F.linear(r(h), r(params["w3"]), params["b3"])
+    h = lin(h, params["w3"], params["b3"])
     sigma = trunc_exp(h[:, 0] + density_blob(xyz, blob_scale, blob_std))
     return sigma, h[:, 1:]
 
@@ -613,9 +679,13 @@ def init_bg_params(in_dim=39, hidden=64, out_dim=4, seed=1) -> dict:
 # --------------------------------------------------------------------------------------
 def render_frame(rays_o, rays_d, table, mlp_params, lv: GridLevels, bitfield, *, bound=1.0, cascade=1,
                  G=128, min_near=0.1, max_steps=1024, dt_gamma=0.0, noises=None, bg_color=None,
-                 T_thresh=1e-4, bf16_mlp=False, bf16_table=False, blob_scale=5.0, blob_std=0.2):
+                 T_thresh=1e-4, bf16_mlp=False, bf16_table=False, blob_scale=5.0, blob_std=0.2, rec8=None):
     """rays [N,3] -> {'image' [N,C], 'depth' [N], 'weights_sum' [N], 'xyzs', 'sigmas', ...}.
-    Differentiable w.r.t. `table` and the entries of `mlp_params`."""
+    Differentiable w.r.t. `table` and the entries of `mlp_params`.
+    rec8 (default: follows bf16_mlp, as the renderer's scatter variant does): table gradient with the rounding of the
+    packed 8-byte scatter records."""
+    if rec8 is None:
+        rec8 = bool(bf16_mlp)
     aabb = [-bound, -bound, -bound, bound, bound, bound]
     with torch.no_grad():
         nears, fars = near_far_from_aabb(rays_o, rays_d, aabb, min_near)
@@ -625,7 +695,7 @@ def render_frame(rays_o, rays_d, table, mlp_params, lv: GridLevels, bitfield, *,
     tab = table
     if bf16_table:
         tab = table + (_bf16r(table) - table).detach()  # bf16 shadow, straight-through to the master
-    feat = grid_encode(x01, tab, lv)
+    feat = grid_encode(x01, tab, lv, rec8=rec8)
     sigmas, rgbs = sigma_latent_mlp(feat, xyzs, mlp_params, blob_scale, blob_std, bf16=bf16_mlp)
     ws, depth, image = composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh, bg_color)
     return {"image": image, "depth": depth, "weights_sum": ws, "xyzs": xyzs, "dirs": dirs, "deltas": deltas,

@@ -31,6 +31,12 @@ def main():
         "optim.views_per_step": world, "optim.exchange_groups": groups})
     tr = Trainer(cfg, device=dev)
     table0 = tr.nerf.encoder.embeddings.detach().clone()
+    if save:   # the table after the FIRST step too (Adam's first step is lr * sign(g): an exact comparison point)
+        import numpy as np
+        tr.full_eval = lambda: None
+        tr.train(iters=1)
+        torch.cuda.synchronize()
+        np.save(os.path.join(out_dir, "table1_rank%d.npy" % rank), tr.nerf.encoder.embeddings.detach().cpu().numpy())
     tr.train()
     torch.cuda.synchronize()
     res = {"rank": rank, "world": world, "pipelined": bool(tr.pipelined), "steps": tr.train_step,

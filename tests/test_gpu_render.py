@@ -102,8 +102,12 @@ def test_render_train_matches_oracle(dev, size):
 
 
 def test_render_train_bf16_matches_bf16_oracle(dev):
-    """BASELINE config 2 precision (bf16 shadow table, bf16 features, bf16 MFMA MLP, f32 compositing)
-    against the oracle with the same roundings.  Discrete outputs stay bit-exact; images within 2e-2."""
+    """BASELINE config 2 precision (bf16 shadow table, bf16 features, bf16 MFMA MLP, 8-byte scatter records, f32
+    compositing) against the oracle with the SAME roundings in both directions: bf16 operands of every forward product,
+    and in the backward pass the pre-activation gradients rounded once to bf16 before they feed dX / dW / db
+    (oracle _Bf16Linear), the table gradient's addends rounded to the 26-bit record format (oracle _CornerGather).  With
+    the rounding points restated, what is left is f32 summation order: discrete outputs bit-exact, images within 2e-2 of
+    the value range (a bf16 feature is 2^-9), every gradient within 1e-2 of its maximum."""
     G, HW, log2_T, base = 64, 32, 14, 16
     net, cfg, lv, table, params, grid = _make(dev, G, HW, log2_T, base, seed=2, mlp_precision="bf16", table_dtype="bf16")
     net.train()
@@ -123,10 +127,10 @@ def test_render_train_bf16_matches_bf16_oracle(dev):
     e, s = _err(out["weights_sum"][0], ref["weights_sum"])
     assert e <= 2e-2, ("weights_sum", e)
     e, s = _err(net.encoder.embeddings.grad, table.grad)
-    assert e <= 5e-2 * s, ("dtable", e, s)
+    assert e <= 1e-2 * s, ("dtable", e, s)
     for k in ("w1", "b1", "w2", "b2", "w3", "b3"):
         e, s = _err(getattr(net, k).grad, params[k].grad)
-        assert e <= 5e-2 * s + 1e-7, ("d" + k, e, s)
+        assert e <= 1e-2 * s + 1e-7, ("d" + k, e, s)
 
 
 def test_render_contract_and_properties(dev):
@@ -365,13 +369,14 @@ def test_prepared_rays_and_two_step_graph(dev):
     torch.cuda.synchronize()
 
 
-def _run_steps(dev, fuse, precision, log2_T, steps=3):
+def _run_steps(dev, fuse, precision, log2_T, steps=3, tail=None, capturable=False, full=False):
     from src.latent_nerf.training.optimizer import FusedAdam
     G, HW = 64, 32
     net, cfg, lv, table, params, grid = _make(dev, G, HW, log2_T, 16, seed=7, mlp_precision=precision,
                                               table_dtype=precision)
     net.train()
-    opt = FusedAdam(net.get_params(1e-2), encoder=net.encoder, fuse_table_update=fuse)
+    opt = FusedAdam(net.get_params(1e-2), encoder=net.encoder, fuse_table_update=fuse, capturable=capturable,
+                    mlp=net if tail is not None else None, tail=tail)
     gen = torch.Generator().manual_seed(3)
     bg = torch.rand(HW * HW, 4, generator=gen).to(dev)
     for k in range(steps):
@@ -385,6 +390,13 @@ def _run_steps(dev, fuse, precision, log2_T, steps=3):
     emb = net.encoder.embeddings
     m, v = [(e[1], e[2]) for e in opt.big if e[0] is emb][0]
     sh = net.encoder.shadow()
+    if full:   # every parameter, every moment, the MLP's bf16 weight fragments, the device step counter
+        small = {k: (getattr(net, k).detach().clone(),) + tuple(t.clone() for e in opt.small if e[0] is getattr(net, k)
+                                                                for t in e[1:3]) for k in ("w1", "b1", "w2", "b2", "w3", "b3")}
+        frag = net.mlp_workspace(dev)[:30 * 1024].clone() if precision == "bf16" else None   # the 30 weight fragments (F_ALL)
+        return {"table": emb.detach().clone(), "m": m.clone(), "v": v.clone(), "shadow": None if sh is None else sh.clone(),
+                "small": small, "frag": frag, "step_dev": None if opt.step_dev is None else opt.step_dev.clone(),
+                "frag_current": net.fragments_current(), "grad_w2": net.w2.grad}
     return (emb.detach().clone(), m.clone(), v.clone(), None if sh is None else sh.clone(), net.w2.detach().clone(),
             emb.grad)
 
@@ -411,9 +423,10 @@ def test_fused_table_update_is_bit_identical(dev, precision, log2_T):
 def test_full_size_bf16_step_with_fused_adam_matches_oracle(dev):
     """BASELINE config 2 at full size (64x64 rays, 128^3 grid, L = 16, T = 2^19; bf16 table + features + MFMA MLP,
     8-byte scatter records, table Adam step fused into the scatter): ONE optimisation step against the oracle's
-    render_frame (same bf16 roundings) + adam_step.  First-step Adam moments are (1-b1) g and (1-b2) g^2, so they carry
-    the gradient's bf16 tolerance (5e-2 of the maximum, squared for v); the parameter moves by lr * sign(g) wherever
-    |g| is clearly non-zero, and rows no sample touched keep their bits."""
+    render_frame (same bf16 roundings, forward and backward, and the record rounding of the scatter) + adam_step.
+    First-step Adam moments are (1-b1) g and (1-b2) g^2, so they carry the gradient's tolerance (1e-2 of the maximum;
+    2.1e-2 for v = g^2); the parameter moves by lr * sign(g) wherever |g| is clearly non-zero, and rows no sample touched
+    keep their bits."""
     from src.latent_nerf.training.optimizer import FusedAdam
     G, HW, log2_T = 128, 64, 19
     net, cfg, lv, table, params, grid = _make(dev, G, HW, log2_T, 16, seed=11, mlp_precision="bf16", table_dtype="bf16")
@@ -445,15 +458,43 @@ def test_full_size_bf16_step_with_fused_adam_matches_oracle(dev):
     emb = net.encoder.embeddings.detach().cpu()
     m_got, v_got = [(e_[1].cpu(), e_[2].cpu()) for e_ in opt.big if e_[0] is net.encoder.embeddings][0]
     gmax = float(gt.abs().max())
-    assert float((m_got - m1).abs().max()) <= 5e-2 * 0.1 * gmax, "exp_avg"
-    assert float((v_got - v1).abs().max()) <= 1.1e-1 * 0.01 * gmax * gmax, "exp_avg_sq"
-    sure = gt.abs() > 6e-2 * gmax                        # sign of g beyond the stated bf16 tolerance: the step is lr * sign(g)
+    e_m = float((m_got - m1).abs().max()) / (0.1 * gmax)
+    e_v = float((v_got - v1).abs().max()) / (0.01 * gmax * gmax)
+    print("full-size bf16 step: exp_avg error %.3e of (1-b1) max|g|, exp_avg_sq error %.3e of (1-b2) max|g|^2" % (e_m, e_v))
+    assert e_m <= 1e-2, ("exp_avg", e_m)
+    assert e_v <= 2.1e-2, ("exp_avg_sq", e_v)
+    sure = gt.abs() > 2e-2 * gmax                        # sign of g beyond the stated tolerance: the step is lr * sign(g)
     assert int(sure.sum()) > 1000
     assert float((emb - p1)[sure].abs().max()) < 1e-4 * lr + 1e-7
     untouched = (gt == 0) & (m_got == 0)
     assert int(untouched.sum()) > 0 and torch.equal(emb[untouched], t0[untouched])
     moved = (emb != t0)
     assert float(((emb - t0)[moved]).abs().max()) <= lr * 1.001     # |Adam step| <= lr on the first step
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,log2_T,capturable", [("bf16", 19, True), ("bf16", 14, True), ("f32", 19, False)])
+def test_step_tail_is_bit_identical_to_the_separate_launches(dev, precision, log2_T, capturable):
+    """lnerf_step_tail -- ONE launch for the scatter's finishing pass, the sum of the MLP's gradient slabs + the Adam
+    step of its six tensors, the step-counter tick and the clearing of the scatter's level maxima -- against the
+    separate launches (slab sum inside the backward pass, finishing kernel, multi-tensor Adam): table, every MLP tensor,
+    every moment, the bf16 weight fragments and the device step counter agree BIT FOR BIT after four steps.  2^14 rows per
+    level: every level's buckets are sliced, so the tail's finishing blocks do the table's whole Adam step."""
+    ref = _run_steps(dev, True, precision, log2_T, steps=4, tail=False, capturable=capturable, full=True)
+    got = _run_steps(dev, True, precision, log2_T, steps=4, tail=True, capturable=capturable, full=True)
+    assert got["grad_w2"] is None                      # tail mode: the weight gradients never exist
+    for k in ("table", "m", "v", "shadow", "frag", "step_dev"):
+        a, b = got[k], ref[k]
+        assert (a is None) == (b is None), k
+        if a is not None:
+            assert torch.equal(a, b), (k, float((a.float() - b.float()).abs().max()))
+    for k, (p, m, v) in got["small"].items():
+        rp, rm_, rv = ref["small"][k]
+        assert torch.equal(p, rp) and torch.equal(m, rm_) and torch.equal(v, rv), k
+    if precision == "bf16":
+        assert got["frag_current"] and ref["frag_current"]
+    if capturable:
+        assert int(got["step_dev"][0]) == 5 and int(got["step_dev"][1]) == 0
 
 
 @pytest.mark.gpu

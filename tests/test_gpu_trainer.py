@@ -154,12 +154,17 @@ def test_mesh_winding_distance_and_shape_guidance(dev, tmp_path):
     tr.nerf.train()
     data = tr.dataloaders["train"].collate(0)
     assert data["rays_o"] is None     # training views hand over the camera; the rays are generated inside the march
-    out = tr.nerf.render(None, None, camera=data["camera"], perturb=True)
-    loss = tr.shape_loss(out["xyzs"], out["sigmas"], out["counter"])
-    loss.backward()
+    # (on the trainer's stream: autograd pins a parameter's gradient accumulation to the stream of its first backward, and
+    # the captured step cannot accumulate on the legacy default stream)
+    with torch.cuda.stream(tr.stream):
+        out = tr.nerf.render(None, None, camera=data["camera"], perturb=True)
+        loss = tr.shape_loss(out["xyzs"], out["sigmas"], out["counter"])
+        loss.backward()
+    tr.stream.synchronize()
     assert float(loss) > 0 and float(tr.nerf.w3.grad.abs().sum()) > 0
     for p in tr.nerf.parameters():
         p.grad = None
+    del out, loss
     tr.train()
     assert tr.train_step == 5
 
@@ -173,10 +178,12 @@ def test_graphed_trainer_matches_eager_trainer_bit_for_bit(dev, tmp_path):
     from src.latent_nerf.training.trainer import Trainer
     for fp16 in (False, True):
         states = []
-        for graph in (True, False):
+        # whole: ONE graph per step (the synthetic guidance is capturable and sits inside it); split: graph F / eager
+        # guidance / graph B (what a real diffusion model gets); eager: no graphs
+        for mode in ("whole", "split", "eager"):
             cfg = _cfg(tmp_path, **{"optim.iters": 20, "log.save_interval": 1000, "optim.fp16": fp16,
-                                    "log.exp_name": "g%d%d" % (fp16, graph), "optim.graph_step": graph,
-                                    "log.full_eval_size": 1})
+                                    "log.exp_name": "g%d%s" % (fp16, mode), "optim.graph_step": mode != "eager",
+                                    "optim.graph_guidance": mode == "whole", "log.full_eval_size": 1})
             torch.manual_seed(7)
             torch.cuda.manual_seed(7)
             tr = Trainer(cfg, device=dev)
@@ -184,8 +191,9 @@ def test_graphed_trainer_matches_eager_trainer_bit_for_bit(dev, tmp_path):
             torch.cuda.manual_seed(11)
             tr.train()
             assert tr.train_step == 20
-            if graph:
+            if mode != "eager":
                 assert tr.graph_stats["captures"] >= 1 and tr.graph_stats["replayed_steps"] >= 15, tr.graph_stats
+                assert tr._whole == (mode == "whole")
             else:
                 assert tr.graph_stats["replayed_steps"] == 0 and tr.graph_stats["eager_steps"] == 20
             opt = tr.optimizer
@@ -195,22 +203,32 @@ def test_graphed_trainer_matches_eager_trainer_bit_for_bit(dev, tmp_path):
                            "b2": tr.nerf.b2.detach().clone(), "grid": tr.nerf.density_grid.clone(),
                            "bits": tr.nerf.density_bitfield.clone(), "step": opt.step_no,
                            "step_dev": int(opt.step_dev[0].item())})
-        a, b = states
-        assert a["step"] == b["step"] == 20 and a["step_dev"] == b["step_dev"] == 21
-        for k in ("table", "m", "v", "w1", "w3", "b2", "grid", "bits"):
-            assert torch.equal(a[k], b[k]), (fp16, k, float((a[k].float() - b[k].float()).abs().max()))
-        assert float((a["table"] - 0).abs().max()) > 0
+        b = states[-1]
+        for a in states[:-1]:
+            assert a["step"] == b["step"] == 20 and a["step_dev"] == b["step_dev"] == 21
+            for k in ("table", "m", "v", "w1", "w3", "b2", "grid", "bits"):
+                assert torch.equal(a[k], b[k]), (fp16, k, float((a[k].float() - b[k].float()).abs().max()))
+        assert float((b["table"] - 0).abs().max()) > 0
 
 
 def test_graphed_trainer_recaptures_when_the_sample_budget_moves(dev, tmp_path):
     """The refresh re-derives the sample capacity from observed marches; a change means new sample buffers, so the
-    trainer drops its graphs, runs one step eagerly and captures again."""
+    trainer drops its graphs, runs one step eagerly and captures again.  Forced here by shrinking the occupied region
+    between two stretches of training: the marches of steps 21..32 are small, the refresh of step 33 moves the budget."""
     from src.latent_nerf.training.trainer import Trainer
-    cfg = _cfg(tmp_path, **{"optim.iters": 40, "log.save_interval": 1000, "optim.fp16": True, "log.exp_name": "rc",
+    cfg = _cfg(tmp_path, **{"optim.iters": 20, "log.save_interval": 1000, "optim.fp16": True, "log.exp_name": "rc",
                             "log.full_eval_size": 1})
     tr = Trainer(cfg, device=dev)
     tr.train()
-    assert tr.train_step == 40 and tr.graph_stats["captures"] >= 2, tr.graph_stats   # worst case -> budgeted capacity
+    assert tr.train_step == 20 and tr.graph_stats["captures"] == 1, tr.graph_stats
+    cap0 = tr._gstep_capacity
+    with torch.cuda.stream(tr.stream):
+        tr.nerf.seed_density_grid(lambda x: (x.norm(dim=-1) < 0.2).float() * 100.0)
+        tr.nerf._m_peak.zero_()
+    tr.stream.synchronize()
+    tr.train(iters=40)
+    assert tr.train_step == 40 and tr.graph_stats["captures"] >= 2, tr.graph_stats
+    assert tr._gstep_capacity < cap0, (tr._gstep_capacity, cap0)
     assert tr.graph_stats["replayed_steps"] + tr.graph_stats["eager_steps"] == 40
     assert bool(torch.isfinite(tr.nerf.encoder.embeddings).all())
 

@@ -44,3 +44,19 @@ def test_survey_known_answers():
 def test_tensor2numpy_matches_reference(impl):
     for case in GOLD["tensor2numpy"]:
         assert impl(torch.tensor(case["input"])).tolist() == case["expect"]
+
+
+def test_scalar_view_direction_matches_reference_vectors():
+    """view_direction_index (the per-step scalar form the NeRF dataset uses) on every golden vector of the reference's
+    get_view_direction, one view at a time."""
+    n = 0
+    for case in GOLD["view_direction"]:
+        for th, ph, want in zip(case["thetas"], case["phis"], case["expect"]):
+            th32, ph32 = float(np.float32(th)), float(np.float32(ph))
+            if case["kind"] == "defaults":
+                got = U.view_direction_index(th32, ph32)
+            else:
+                got = U.view_direction_index(th32, ph32, np.deg2rad(case["overhead_deg"]), np.deg2rad(case["front_deg"]))
+            assert got == want, (case["kind"], th, ph)
+            n += 1
+    assert n > 900
