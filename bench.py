@@ -269,6 +269,23 @@ def log(msg):
     print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
+class stdout_to_stderr:
+    """File descriptor 1 points at stderr inside the block.  RCCL prints a version banner on STDOUT when its first
+    communicator is created; rank 0's stdout must carry the ONE JSON line and nothing else."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def cpu_baseline(frames):
     """The oracle's pure-PyTorch fp32 step (render fwd+bwd + Adam) on the host cores."""
     from oracle import nerf_oracle as O
@@ -387,7 +404,7 @@ def companion_f32(dev, rank, steps=40, warmup=6):
                     "configuration the fp32-tolerance parity tests run"}
 
 
-def trainer_companion(dev, steps, precision):
+def trainer_companion(dev, steps, precision, fixed_pose=False):
     """The product entry point on the bench configuration: `Trainer(cfg).train()` (scripts/train_latent_nerf.py) with
     the seeded synthetic guidance, 64x64x4 / 128^3, bf16, one view per step -- captured step (graph F: render / eager
     guidance / graph B: backward + optimiser), a new random pose and field of view every step, an occupancy refresh
@@ -405,6 +422,9 @@ def trainer_companion(dev, steps, precision):
             "render.grid_size": GRID, "render.eval_h": 8, "render.eval_w": 8, "log.eval_size": 1, "log.full_eval_size": 1,
             "log.save_interval": 10 ** 9, "log.quiet": True, "optim.lr": LR, "optim.fp16": precision == "bf16", "guide.text": "bench",
             "optim.iters": warm})
+        if fixed_pose:   # the bench's own view (theta 60, phi 0, r 1.25, fovy 55) and sample capacity: same GPU work per
+            cfg.render.train_pose = (60.0, 0.0, 1.25, FOVY)   # step as the headline + guidance + sparsity term + real refreshes
+            cfg.render.max_samples = BENCH_CAPACITY
         tr = Trainer(cfg, device=dev)
         sphere_scene(tr.nerf)
         tr.nerf.iter_density = 16          # steady-state refreshes (G^3/4 random + G^3/4 occupied cells)
@@ -425,9 +445,11 @@ def trainer_companion(dev, steps, precision):
                 "replayed_steps": tr.graph_stats["replayed_steps"] - c0["replayed_steps"],
                 "eager_steps": tr.graph_stats["eager_steps"] - c0["eager_steps"],
                 "captures_total": tr.graph_stats["captures"], "samples_per_view_last": M,
-                "sample_capacity": tr.nerf._march.capacity,
-                "what": "Trainer.train() (src/latent_nerf/training/trainer.py), SyntheticGuidance, random poses / fov, "
-                        "sparsity term, occupancy refresh every %d steps, sample budget from observed marches" % iv}
+                "sample_capacity": tr.nerf._march.capacity, "whole_step_graph": bool(tr._whole),
+                "what": ("Trainer.train() (src/latent_nerf/training/trainer.py), SyntheticGuidance, %s, sparsity term, "
+                         "occupancy refresh every %d steps feeding the march%s"
+                         % ("the bench's fixed view and sample capacity" if fixed_pose else "random poses / fov", iv,
+                            "" if fixed_pose else ", sample budget from observed marches"))}
     finally:
         shutil.rmtree(root, ignore_errors=True)
 
@@ -456,10 +478,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        with stdout_to_stderr():   # (the communicator is created by the first collective: do one here)
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
+            dist.barrier()
+            torch.cuda.synchronize()
 
     from src.latent_nerf.raymarching import backend as B
     B.get_lib()  # no fallback: raise here if the HIP library is missing
@@ -713,8 +738,11 @@ def main():
             res["tuning_overrides"] = tuned
         if not args.no_extras and not dist_on and args.gridtype == "hash":
             if args.trainer_steps > 0:
-                res["trainer"] = trainer_companion(dev, args.trainer_steps, args.precision)
+                # the product loop twice: on the bench's own view (same GPU work per step as the headline: what the loop
+                # itself costs) and on the training pose distribution (random radius / angles / field of view per step)
+                res["trainer"] = trainer_companion(dev, args.trainer_steps, args.precision, fixed_pose=True)
                 res["trainer"]["frac_of_value"] = res["trainer"]["value"] / res["value"]
+                res["trainer_random_views"] = trainer_companion(dev, args.trainer_steps, args.precision)
             res["blocked"] = companion_blocked(dev, rank, args.precision)
             res["f32"] = companion_f32(dev, rank)
         if not args.no_cpu_baseline and not dist_on:

@@ -330,6 +330,12 @@ int lnerf_occ_sample(const float *grid_level, int64_t n_cells, int cascade_level
 int lnerf_occ_update(float *grid_level, const uint32_t *indices, int64_t n, const float *new_sigmas, float decay,
                      uint32_t *scratch_cells, lnerf_stream_t stream);
 /* mean of max(grid,0) over n cells -> *mean_dev ; scratch256: 256 floats of device scratch */
+/* lnerf_occ_update + lnerf_occ_mean of ONE cascade level in three launches instead of four, the apply pass streaming over
+ * the CELLS (n_cells) instead of exchanging one scratch word per candidate: same grid, same mean, bit for bit.  For a
+ * renderer with a single cascade (bound <= 1). */
+int lnerf_occ_update_mean(float *grid_level, int64_t n_cells, const uint32_t *indices, int64_t n, const float *new_sigmas,
+                          float decay, uint32_t *scratch_cells, float *mean_dev, float *scratch256,
+                          lnerf_stream_t stream);
 int lnerf_occ_mean(const float *grid, int64_t n, float *mean_dev, float *scratch256, lnerf_stream_t stream);
 
 /* ---- H11: background net, frequency encoding (degree 6: 39 dims) -> 64 -> C, one thread per ray. */

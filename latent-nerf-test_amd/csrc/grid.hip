@@ -616,16 +616,17 @@ template <typename REC>
 __global__ void __launch_bounds__(BIN_T, (sizeof(REC) == 8 ? 6 : 4))
 k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restrict__ dfeat, GridMeta meta, BucketMeta bm,
               int64_t m_host, const int32_t *__restrict__ m_dev, int64_t level_stride, unsigned int *__restrict__ gmax,
-              int32_t *__restrict__ items_out, uint32_t *__restrict__ segtab, REC *__restrict__ recs, int skip_zero) {
+              int32_t *__restrict__ items_out, uint32_t *__restrict__ segtab, REC *__restrict__ recs, int skip_zero,
+              int lv_lo, int lv_hi) {
     __shared__ int s_cnt[2][BK_MAX_PER_LEVEL];  // records of the item per bucket (two sets: items alternate)
     __shared__ int s_off[BK_MAX_PER_LEVEL];     // first slot of the bucket's segment in the stage (= in the chunk)
     __shared__ __attribute__((aligned(16))) REC s_stage[ITEM_RECS];  // the item's chunk (48 KiB, 32 KiB packed)
     __shared__ unsigned int s_lmax[LNERF_MAX_LEVELS];         // per level: bound of |value| seen by this workgroup
     int32_t M = (int32_t)m_host;
     if (m_dev) { const int32_t md = *m_dev; M = md < M ? md : M; }
-    const int L = meta.num_levels;
+    const int L = lv_hi - lv_lo;   // levels of this launch: [lv_lo, lv_hi)
     const int tid = threadIdx.x, lane = tid & 63;
-    // item k of this workgroup: tile t0 + k * tstep, level (l0 + k) mod L   (gridDim.x is a multiple of L)
+    // item k of this workgroup: tile t0 + k * tstep, level lv_lo + (l0 + k) mod L   (gridDim.x is a multiple of L)
     const int tstep = gridDim.x / L;
     const float two_b = 2.0f * bound;
     const bool pow2_bound = (__float_as_uint(two_b) & 0x007FFFFFu) == 0u;
@@ -647,7 +648,7 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restri
             n_x = xyzs[(int64_t)mm * 3]; n_y = xyzs[(int64_t)mm * 3 + 1]; n_z = xyzs[(int64_t)mm * 3 + 2];
         }
     };
-    int l = (int)(blockIdx.x % L);
+    int l = lv_lo + (int)(blockIdx.x % L);
     int tile = (int)(blockIdx.x / L);
     bool have = tile * BIN_T < M;
     if (have) fetch(l, tile);
@@ -657,7 +658,7 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restri
     while (have) {
         const BinLevel lv = LNERF_BIN_LEVEL(l);
         const int nb = lv.nb;
-        const int l_next = l + 1 == L ? 0 : l + 1;
+        const int l_next = l + 1 == lv_hi ? lv_lo : l + 1;
         const int tile_next = tile + tstep;
         const bool have_next = tile_next * BIN_T < M;
         BIN_STAMP(0);
@@ -831,7 +832,7 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restri
         l = l_next; tile = tile_next; have = have_next;
     }
     __syncthreads();
-    if (tid < L && s_lmax[tid] != 0u) atomicMax(&gmax[tid * CUR_STRIDE], s_lmax[tid]);  // one value per LEVEL and workgroup
+    if (tid >= lv_lo && tid < lv_hi && s_lmax[tid] != 0u) atomicMax(&gmax[tid * CUR_STRIDE], s_lmax[tid]);  // one value per LEVEL and workgroup
     BIN_STAMP_FLUSH();
 }
 #undef LNERF_BIN_LEVEL
@@ -906,15 +907,18 @@ __device__ __forceinline__ int active_slices(int n, int smax) {
 #define LNERF_REDUCE_XCD 1
 #endif
 template <int RT, typename REC, bool FUSE>
-__global__ void __launch_bounds__(RT, RT / 128)
-k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ items_dev, const uint32_t *__restrict__ segtab,
-                 int32_t *__restrict__ bucket_n, const unsigned int *__restrict__ gmax, const REC *__restrict__ recs,
-                 float *__restrict__ dtable, long long *__restrict__ partials, int wg_lo, FusedUpdate fu) {
+__device__ __forceinline__ void scatter_reduce_one(int wg, const GridMeta &meta, const BucketMeta &bm,
+                                                   const int32_t *__restrict__ items_dev,
+                                                   const uint32_t *__restrict__ segtab, int32_t *__restrict__ bucket_n,
+                                                   const unsigned int *__restrict__ gmax, const REC *__restrict__ recs,
+                                                   float *__restrict__ dtable, long long *__restrict__ partials,
+                                                   const FusedUpdate &fu) {
+    // (declared HERE, not passed in: a pointer parameter loses the LDS address space and every ds_add_u64 becomes a
+    // flat atomic -- measured 0.211 -> 0.275 ms for the scatter call)
     __shared__ long long acc[BK_ROWS * 2];  // [feature][row]: a wave's 64 random rows spread over 32 bank pairs
     __shared__ int s_red[RT / 64];
     constexpr int NW = RT / 64;
-    // locate (level, bucket, slice) of this workgroup
-    const int wg = (int)blockIdx.x + wg_lo;
+    // locate (level, bucket, slice) of this work unit
     int l = 0;
     while (l + 1 < meta.num_levels && wg >= bm.wgstart[l + 1]) ++l;
     const int Smax = bm.slices[l];
@@ -967,7 +971,11 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ items
     // records waits for the slowest wave anyway, and the loads travel meanwhile.  (Requested ahead of the record stream
     // they were measured 35 us slower: the records queue behind them.)
     constexpr int NQ = (BK_ROWS / 2 + RT - 1) / RT;  // row pairs per lane
+#ifdef LNERF_EXP_RED_NOADAM     // timing-only experiment build: the workgroup ends behind its record loop
+    const bool fast = false;
+#else
     const bool fast = fuse && !fu.grad_out && ((R0 | rows) & 1) == 0 && rows == BK_ROWS && (BK_ROWS / 2) % RT == 0;
+#endif
     float4 P[NQ], Mv[NQ], V[NQ];
     float4 *p4 = reinterpret_cast<float4 *>(reinterpret_cast<float2 *>(fu.p) + R0);
     float4 *m4 = reinterpret_cast<float4 *>(reinterpret_cast<float2 *>(fu.m) + R0);
@@ -989,7 +997,11 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ items
             atomicAdd(&ua[a0 + BK_ROWS], (unsigned long long)to_fixed<FB>((r.b() * fs.sc_a) * fs.sc_b));
         };
         constexpr int U = LNERF_REDUCE_ROUNDS;                        // rounds of loads in flight per lane
+#ifdef LNERF_EXP_RED_NOREC   // timing-only experiment build: no record loop
+        for (int kb = 0; kb < 0; kb += 64) {
+#else
         for (int kb = 0; kb < nmy; kb += 64) {                        // (one pass for up to 64 x 16 = 1024 items)
+#endif
             uint32_t e = e_first;
             if (kb > 0) e = kb + lane < nmy ? tab[(int64_t)(first + NW * (kb + lane)) * nb] : 0u;
             const int cnt = nmy - kb < 64 ? nmy - kb : 64;            // segments held by the lanes (uniform)
@@ -1062,6 +1074,9 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ items
         return;
     }
     float *dst = dtable + R0 * 2;
+#ifdef LNERF_EXP_RED_NOADAM
+    if (fuse) return;
+#endif
     if (fuse) {
         AdamArgs a = fu.a;
         adam_bias(a);
@@ -1127,6 +1142,18 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ items
         d.y += ((float)acc[r + BK_ROWS] * fs.un_a) * fs.un_b;
         reinterpret_cast<float2 *>(dst)[r] = d;
     }
+}
+
+// One workgroup per (bucket, slice) unit.  (PERSISTENT workgroups striding over the units were built and measured: the
+// loop keeps the three kernel-argument structs live across iterations, 77 VGPRs spill at the 64 the two-workgroups-per-CU
+// occupancy allows, and the pass went from 0.211 to 0.27 ms per scatter call: profiles/r03_exp_scatter.jsonl.)
+template <int RT, typename REC, bool FUSE>
+__global__ void __launch_bounds__(RT, RT / 128)
+k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ items_dev, const uint32_t *__restrict__ segtab,
+                 int32_t *__restrict__ bucket_n, const unsigned int *__restrict__ gmax, const REC *__restrict__ recs,
+                 float *__restrict__ dtable, long long *__restrict__ partials, int wg_lo, FusedUpdate fu) {
+    scatter_reduce_one<RT, REC, FUSE>((int)blockIdx.x + wg_lo, meta, bm, items_dev, segtab, bucket_n, gmax, recs, dtable,
+                                      partials, fu);
 }
 
 // Finishing pass of the sliced levels: one thread per table row adds the active slices' exact partial sums
@@ -1354,6 +1381,8 @@ static int g_bin_wgs = 0;
 static int g_skip_zero = 1;
 // threads per workgroup of the reduce pass (512 or 1024; two 64 KiB workgroups fit a CU either way)
 static int g_reduce_threads = 1024;
+// level groups of the whole-frame scatter: bin(group) -> reduce(group) per group (1 = bin everything, then reduce)
+static int g_scatter_groups = 1;
 
 // workspace: [header: level maxima | item count | record count per bucket] [segment table] [record chunks] [partial tiles]
 static size_t header_bytes(int n_buckets) {
@@ -1556,6 +1585,11 @@ int lnerf_set_tuning(const char *key, int value) {
         g_mlp_fwd_blocks = value;
         return LNERF_OK;
     }
+    if (strcmp(key, "scatter_level_groups") == 0) {
+        LNERF_REQUIRE(value >= 1 && value <= LNERF_MAX_LEVELS, "set_tuning: scatter_level_groups out of range");
+        g_scatter_groups = value;
+        return LNERF_OK;
+    }
     if (strcmp(key, "scatter_skip_zero") == 0) {
         g_skip_zero = value ? 1 : 0;
         return LNERF_OK;
@@ -1665,20 +1699,21 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
         set_error("grid_encode_backward: hipMemsetAsync failed");
         return LNERF_ERR_HIP;
     }
-    auto launch_bin = [&]() {
-        // persistent: G workgroups, G a multiple of the level count (item k of a workgroup: next tile group, next level)
+    auto launch_bin = [&](int l0, int l1) {
+        // persistent: G workgroups, G a multiple of the launch's level count (item k of a workgroup: next tile group, next level)
+        const int nl = l1 - l0;
         const int wgs = g_bin_wgs > 0 ? g_bin_wgs : 256 * g_bin_per_cu;
-        int64_t G = (int64_t)(wgs / num_levels) * num_levels;
-        const int64_t items = div_up(m_host, (int64_t)BIN_T) * num_levels;
+        int64_t G = (int64_t)(wgs / nl) * nl;
+        const int64_t items = div_up(m_host, (int64_t)BIN_T) * nl;
         if (G > items) G = items;
-        if (G < num_levels) G = num_levels;
+        if (G < nl) G = nl;
         const dim3 g((unsigned)G, 1, 1);
         if (packed)
             hipLaunchKernelGGL((k_scatter_bin<Rec8>), g, dim3(BIN_T), 0, s, xyzs, bound, (const float *)dfeat, meta, bm,
-                               m_host, m_dev, level_stride, gmax, items_dev, segtab, (Rec8 *)rec, g_skip_zero);
+                               m_host, m_dev, level_stride, gmax, items_dev, segtab, (Rec8 *)rec, g_skip_zero, l0, l1);
         else
             hipLaunchKernelGGL((k_scatter_bin<Rec12>), g, dim3(BIN_T), 0, s, xyzs, bound, (const float *)dfeat, meta, bm,
-                               m_host, m_dev, level_stride, gmax, items_dev, segtab, (Rec12 *)rec, g_skip_zero);
+                               m_host, m_dev, level_stride, gmax, items_dev, segtab, (Rec12 *)rec, g_skip_zero, l0, l1);
     };
     FusedUpdate fu0;
     memset(&fu0, 0, sizeof(fu0));
@@ -1709,8 +1744,26 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
         else LAUNCH_FIN(false, 44);
 #undef LAUNCH_FIN
     };
+    if (phases == 3 && g_scatter_groups > 1 && lv_lo == 0 && lv_hi == num_levels) {
+        // level GROUPS: bin(group) -> reduce(group) -> bin(next group) ...  A group's records (1/groups of the 216 MB a
+        // frame writes) are read back right behind their writes, while they still sit in the 256 MiB Infinity Cache:
+        // the whole-frame form streams them out to HBM and back
+        const int ng = g_scatter_groups < num_levels ? g_scatter_groups : num_levels;
+        for (int gi = 0; gi < ng; ++gi) {
+            const int l0 = (int)((int64_t)num_levels * gi / ng), l1 = (int)((int64_t)num_levels * (gi + 1) / ng);
+            launch_bin(l0, l1);
+            LNERF_CHECK_LAUNCH("grid_encode_backward(bin)");
+            launch_reduce(s, l0, l1);
+            LNERF_CHECK_LAUNCH("grid_encode_backward(reduce)");
+        }
+        bool any_sliced = false;
+        for (int l = 0; l < num_levels; ++l) any_sliced = any_sliced || bm.slices[l] > 1;
+        if (any_sliced && !defer_finish) launch_finish();
+        LNERF_CHECK_LAUNCH("grid_encode_backward(finish)");
+        return LNERF_OK;
+    }
     if (phases & 1) {
-        launch_bin();
+        launch_bin(0, num_levels);
         LNERF_CHECK_LAUNCH("grid_encode_backward(bin)");
     }
     if (phases & 2) {

@@ -751,6 +751,31 @@ __global__ void __launch_bounds__(256) k_occ_mean_partial(const float *__restric
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
 }
+// apply + mean in ONE pass over the CELLS (not the candidates): a cell whose scratch word is marked takes
+// grid = max(grid * decay, maximum) and the word goes back to zero; every thread adds max(grid, 0) of its cells in the
+// slice order of k_occ_mean_partial, so the mean is the one the two separate launches give, bit for bit.  Streaming
+// (16 B per cell) instead of one atomicExch per candidate: 58 + 9 us -> 8 us for 2 M cells / 1 M candidates.
+__global__ void __launch_bounds__(256) k_occ_apply_mean(float *__restrict__ grid, unsigned int *__restrict__ scratch,
+                                                        int64_t n, float decay, float *__restrict__ partial) {
+    __shared__ float s_w[4];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float g = grid[i];
+        const unsigned int m = scratch[i];
+        if (m & 0x80000000u) {
+            scratch[i] = 0u;
+            if (g >= 0.f) {
+                g = fmaxf(g * decay, __uint_as_float(m & 0x7FFFFFFFu));
+                grid[i] = g;
+            }
+        }
+        s += fmaxf(g, 0.f);
+    }
+    s = wave_sum(s);
+    if (lane_id() == 0) s_w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
+}
 __global__ void __launch_bounds__(64) k_occ_mean_final(const float *__restrict__ partial, int blocks, float n,
                                                        float *__restrict__ mean) {
     if (threadIdx.x == 0) {
@@ -1059,6 +1084,25 @@ int lnerf_occ_update(float *grid_level, const uint32_t *indices, int64_t n, cons
     LNERF_CHECK_LAUNCH("occ_update(max)");
     hipLaunchKernelGGL(k_occ_update_apply, dim3(grid_for(n)), dim3(256), 0, s, grid_level, scratch_cells, indices, n, decay);
     LNERF_CHECK_LAUNCH("occ_update(apply)");
+    return LNERF_OK;
+}
+
+int lnerf_occ_update_mean(float *grid_level, int64_t n_cells, const uint32_t *indices, int64_t n, const float *new_sigmas,
+                          float decay, uint32_t *scratch_cells, float *mean_dev, float *scratch256,
+                          lnerf_stream_t stream) {
+    LNERF_REQUIRE(n >= 0 && n_cells > 0, "occ_update_mean: bad sizes");
+    LNERF_REQUIRE(grid_level && scratch_cells && mean_dev && scratch256 && (n == 0 || new_sigmas),
+                  "occ_update_mean: null pointer");
+    hipStream_t s = as_stream(stream);
+    if (n > 0) {
+        hipLaunchKernelGGL(k_occ_update_max, dim3(grid_for(n)), dim3(256), 0, s, scratch_cells, indices, n, new_sigmas);
+        LNERF_CHECK_LAUNCH("occ_update_mean(max)");
+    }
+    hipLaunchKernelGGL(k_occ_apply_mean, dim3(OCC_MEAN_BLOCKS), dim3(256), 0, s, grid_level, scratch_cells, n_cells, decay,
+                       scratch256);
+    LNERF_CHECK_LAUNCH("occ_update_mean(apply)");
+    hipLaunchKernelGGL(k_occ_mean_final, dim3(1), dim3(64), 0, s, scratch256, OCC_MEAN_BLOCKS, (float)n_cells, mean_dev);
+    LNERF_CHECK_LAUNCH("occ_update_mean(final)");
     return LNERF_OK;
 }
 

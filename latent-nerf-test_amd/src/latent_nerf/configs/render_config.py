@@ -39,6 +39,9 @@ class RenderConfig:
     min_near: float = 0.1
     radius_range: Tuple[float, float] = (1.0, 1.5)
     fovy_range: Tuple[float, float] = (40.0, 70.0)
+    # fixed training view (theta deg, phi deg, radius, fovy deg) instead of the random pose distribution: benchmarking
+    # and debugging only (bench.py's trainer companion uses it to put the trainer on the bench's own view)
+    train_pose: Optional[Tuple[float, float, float, float]] = None
     dir_text: bool = True
     angle_overhead: float = 30.0
     angle_front: float = 60.0

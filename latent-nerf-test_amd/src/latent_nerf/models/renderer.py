@@ -419,6 +419,7 @@ class NeRFRenderer(nn.Module):
         chunk = 1 << 20
         if self._occ_cells is None or self._occ_cells.device != dev:
             self._occ_cells = torch.zeros(G3, device=dev, dtype=torch.int32)   # scratch of lnerf_occ_update, zero between calls
+        fused_mean = False
         for cas in range(self.cascade):
             if self.iter_density >= 16 and getattr(self.cfg, "occ_device_sampling", True):
                 # steady state: G^3/4 random + G^3/4 occupied cells, drawn on the device (lnerf_occ_sample): no
@@ -435,7 +436,15 @@ class NeRFRenderer(nn.Module):
                 _b.call("lnerf_occ_sample", _p(level), G3, cas, G, self.bound, n_rand, self._occ_seed & 0xFFFFFFFF,
                         (self.iter_density * 8 + cas) & 0xFFFFFFFF, _p(scratch), _p(idx), _p(xyzs), _stream())
                 sigmas, _ = self.field(xyzs, 2 * n_rand)
-                sigmas = (sigmas * self.density_scale).contiguous()
+                sigmas = sigmas.contiguous() if self.density_scale == 1.0 else (sigmas * self.density_scale).contiguous()
+                if self.cascade == 1:
+                    # one cascade: update + mean together, the apply pass streaming over the cells
+                    if self._occ_scratch is None or self._occ_scratch.device != dev:
+                        self._occ_scratch = torch.zeros(256, device=dev)
+                    _b.call("lnerf_occ_update_mean", _p(level), G3, _p(idx), 2 * n_rand, _p(sigmas), float(decay),
+                            _p(self._occ_cells), _p(self.mean_density_dev), _p(self._occ_scratch), _stream())
+                    fused_mean = True
+                    continue
                 _b.call("lnerf_occ_update", _p(level), _p(idx), 2 * n_rand, _p(sigmas), float(decay), _p(self._occ_cells),
                         _stream())
                 continue
@@ -466,10 +475,11 @@ class NeRFRenderer(nn.Module):
                 sigmas = (sigmas * self.density_scale).contiguous()
                 _b.call("lnerf_occ_update", _p(level), _p(idx), e - s, _p(sigmas), float(decay), _p(self._occ_cells),
                         _stream())
-        if self._occ_scratch is None or self._occ_scratch.device != dev:
-            self._occ_scratch = torch.zeros(256, device=dev)
-        _b.call("lnerf_occ_mean", _p(self.density_grid), self.density_grid.numel(), _p(self.mean_density_dev),
-                _p(self._occ_scratch), _stream())
+        if not fused_mean:
+            if self._occ_scratch is None or self._occ_scratch.device != dev:
+                self._occ_scratch = torch.zeros(256, device=dev)
+            _b.call("lnerf_occ_mean", _p(self.density_grid), self.density_grid.numel(), _p(self.mean_density_dev),
+                    _p(self._occ_scratch), _stream())
         self.iter_density += 1
         rm.packbits(self.density_grid, self.density_thresh, self.density_bitfield, self.mean_density_dev)
 

@@ -84,6 +84,7 @@ _SIGNATURES = {
     "lnerf_occ_cell_points": [_P, _L, _I, _I, _F, _P, _P, _P],
     "lnerf_occ_update": [_P, _P, _L, _P, _F, _P, _P],
     "lnerf_occ_mean": [_P, _L, _P, _P, _P],
+    "lnerf_occ_update_mean": [_P, _L, _P, _L, _P, _F, _P, _P, _P, _P],
     "lnerf_bg_forward": [_P, _L, _P, _P, _P, _P, _I, _P, _P],
     "lnerf_bg_backward": [_P, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P],
     "lnerf_mesh_winding_number": [_P, _L, _P, _I, _P, _P],

@@ -8,6 +8,11 @@ the RCCL all-reduce stays OUTSIDE the graphs (graph A: render + backward, eager 
 static gradient tensors, graph B: optimiser): collectives are then launched exactly as in eager mode."""
 import torch
 
+# hipStreamCaptureModeThreadLocal: only the capturing thread is restricted.  Under the default (global) mode RCCL's
+# process-group watchdog thread, which polls the events of outstanding collectives, turns a capture into
+# hipErrorStreamCaptureUnsupported whenever its poll lands inside one.
+CAPTURE_MODE = "thread_local"
+
 
 class GraphedTrainStep:
     def __init__(self, fwd_bwd, opt_step, params, sync=None, world=1, warmup=3, stream=None, opt_in_graph=True,
@@ -51,7 +56,7 @@ class GraphedTrainStep:
         self.graph_a = torch.cuda.CUDAGraph()
         self.graph_b = None
         if world == 1:
-            with torch.cuda.graph(self.graph_a, stream=stream):
+            with torch.cuda.graph(self.graph_a, stream=stream, capture_error_mode=CAPTURE_MODE):
                 for _ in range(self.steps_per_call):
                     self.out = fwd_bwd()
                     self.static_grads = [p.grad for p in self.params]  # graph-pool tensors, rewritten by every replay
@@ -60,12 +65,12 @@ class GraphedTrainStep:
                         for p in self.params:   # the next step's backward creates its gradients anew
                             p.grad = None
         else:
-            with torch.cuda.graph(self.graph_a, stream=stream):
+            with torch.cuda.graph(self.graph_a, stream=stream, capture_error_mode=CAPTURE_MODE):
                 self.out = fwd_bwd()
             self.static_grads = [p.grad for p in self.params]
             if opt_in_graph:
                 self.graph_b = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), stream=stream):
+                with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), stream=stream, capture_error_mode=CAPTURE_MODE):
                     opt_step()
             else:
                 self.graph_b = False
@@ -111,10 +116,10 @@ class GraphedRenderStep:
             p.grad = None
         torch.cuda.synchronize()
         self.graph_f = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_f, stream=stream):
+        with torch.cuda.graph(self.graph_f, stream=stream, capture_error_mode=CAPTURE_MODE):
             self.out, self.pred = forward()
         self.graph_b = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_b, pool=self.graph_f.pool(), stream=stream):
+        with torch.cuda.graph(self.graph_b, pool=self.graph_f.pool(), stream=stream, capture_error_mode=CAPTURE_MODE):
             backward(self.out, self.pred)
         self.static_grads = [p.grad for p in self.params]   # graph-pool tensors (None where the step consumed them itself)
         for p in self.params:
@@ -141,7 +146,7 @@ class GraphedWholeStep:
             p.grad = None
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=stream):
+        with torch.cuda.graph(self.graph, stream=stream, capture_error_mode=CAPTURE_MODE):
             self.out, self.pred = fn()
         self.static_grads = [p.grad for p in self.params]
         for p in self.params:

@@ -22,7 +22,10 @@ class NeRFDataset:
     def sample_pose(self, index=0, generator=None):
         cfg = self.cfg
         g = self.gen if generator is None else generator
-        if self.training:
+        if self.training and getattr(cfg, "train_pose", None) is not None:
+            th, ph, radius, fov = [float(v) for v in cfg.train_pose]
+            theta, phi = math.radians(th), math.radians(ph)
+        elif self.training:
             u = torch.rand(4, generator=g)
             radius = float(cfg.radius_range[0] + u[0] * (cfg.radius_range[1] - cfg.radius_range[0]))
             theta = float(math.radians(0.0) + u[1] * (math.radians(150.0) - math.radians(0.0)))

@@ -718,6 +718,16 @@ def test_occupancy_helpers(dev):
         means.append(float(mean))
     assert abs(means[0] - float(ref_g.clamp(min=0).mean())) < 1e-5 * max(means[0], 1.0)
     assert means[0] == means[1] == means[2]
+    # lnerf_occ_update_mean (apply pass over the CELLS + mean in the same pass): the same grid and the same mean, bit
+    # for bit, scratch left zero
+    for perm in (torch.arange(3000), torch.randperm(3000)):
+        g2, sig_d, idx_d = grid.to(dev), sig[perm].to(dev), idx[perm].to(dev)
+        cells = torch.zeros(G ** 3, dtype=torch.int32, device=dev)
+        mean2, scratch2 = torch.zeros(1, device=dev), torch.zeros(256, device=dev)
+        B.call("lnerf_occ_update_mean", _p(g2[0]), G ** 3, _p(idx_d), 3000, _p(sig_d), 0.95, _p(cells), _p(mean2),
+               _p(scratch2), _stream())
+        assert int(cells.abs().sum()) == 0
+        assert torch.equal(g2.cpu(), ref_g) and float(mean2) == means[0]
 
 
 def test_scatter_bf16_gradient_output_matches_f32_path(dev):

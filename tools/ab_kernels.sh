@@ -7,7 +7,7 @@ k=0
 for lib in "$@"; do
   k=$((k+1))
   rm -rf $R/gpurun_out/abk_$k
-  LNERF_HIP_LIB=$R/$lib timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/abk_$k -- python3 $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extras > $R/gpurun_out/abk_$k.log 2>&1 || { tail -5 $R/gpurun_out/abk_$k.log; exit 1; }
+  LNERF_HIP_LIB=$R/$lib timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/abk_$k -- python3 $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extras --refresh 0 > $R/gpurun_out/abk_$k.log 2>&1 || { tail -5 $R/gpurun_out/abk_$k.log; exit 1; }
   cp $R/gpurun_out/abk_$k/*/*kernel_stats.csv $R/gpurun_out/abk_${k}_kernel_stats.csv
   echo "== $lib"
   python3 - $R/gpurun_out/abk_${k}_kernel_stats.csv <<'PY'

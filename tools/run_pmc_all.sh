@@ -4,9 +4,11 @@
 # profiles/pmc_latest.json (and profiles/<round>_pmc_all.json).
 set -u
 R=$GRAFT_REPO_ROOT
-NAME=${1:-r02_pmc_all}
+NAME=${1:-r03_pmc_all}
+EXTRA=${2:-}   # e.g. "--gridtype blocked"
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --graph 0 --steps 6 --warmup 2 --no-cpu-baseline --no-extras"
+# (--refresh 0: the occupancy refresh launches the gather on 1 M unrelated points; it must stay out of the per-kernel means)
+CMD="python3 $R/bench.py --graph 0 --steps 6 --warmup 2 --no-cpu-baseline --no-extras --refresh 0 $EXTRA"
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" \
            "TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_ACCESSES_sum GRBM_GUI_ACTIVE" \
