@@ -110,6 +110,9 @@ def parse():
                     help="run the N > 1 step at N = 1: process group (RCCL, communicator of one rank) initialised before any "
                          "GPU call, bf16 gradient sink, pipelined per-group all-reduce, row-group Adam, graph A + eager "
                          "exchange -- the un-fused path the driver's 8-GPU run takes, measured on one card")
+    ap.add_argument("--graph-collectives", type=int, default=1,
+                    help="N > 1 (or --force-dist) on RCCL: 1 = the exchange and the optimiser are captured into the step "
+                         "graph (one graph launch per step and rank); 0 = graph A + eager exchange + eager optimiser")
     ap.add_argument("--refresh", type=int, default=1,
                     help="1: the occupancy refresh runs inside the timed region every update_extra_interval steps (shadow "
                          "state: the analytic scene stays pinned); 0: the refresh-free step only")
@@ -530,9 +533,11 @@ def main():
     if args.graph:
         from src.latent_nerf.training.graph_step import GraphedTrainStep
         # (a capture failure raises: the line must not silently describe eager launches; use --graph 0 for those)
+        in_graph = bool(dist_on and args.graph_collectives and dist.get_backend() == "nccl")
         gstep = GraphedTrainStep(fwd_bwd, opt_step, list(net.parameters()), sync=sync, world=2 if dist_on else 1, warmup=3,
-                                 stream=main_stream, opt_in_graph=not groups, steps_per_graph=2 if prefetch else 1)
-        launch = "hipgraph"
+                                 stream=main_stream, opt_in_graph=not groups, steps_per_graph=2 if prefetch else 1,
+                                 sync_in_graph=in_graph)
+        launch = "hipgraph (exchange + optimiser captured)" if in_graph else "hipgraph"
     emb0 = net.encoder.embeddings.detach().clone()
     spg = gstep.steps_per_call if gstep is not None else 1
     # occupancy refresh (H10) at the trainer's cadence, inside the timed region: update_extra_state() in its

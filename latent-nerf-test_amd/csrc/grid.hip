@@ -417,6 +417,19 @@ struct Rec12 {
     __device__ __forceinline__ float a() const { return v0; }
     __device__ __forceinline__ float b() const { return v1; }
 };
+// (native vector types: what __builtin_nontemporal_load / _store take)
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+typedef float nt_f2 __attribute__((ext_vector_type(2)));
+typedef uint32_t nt_u2 __attribute__((ext_vector_type(2)));
+typedef uint32_t nt_u4 __attribute__((ext_vector_type(4)));
+// LNERF_BIN_NT (bit mask): non-temporal policy in the binning pass -- 1: dfeat loads (read once per step),
+// 2: record stores (216 MB per frame: more than the Infinity Cache keeps until pass 2 reads them).  Measured together
+// with LNERF_REDUCE_NT below, same box, three interleaved rounds (profiles/r03_exp_scatter.jsonl, steps Q / R):
+// 2411 -> 2548 frames/s; bin 94.1 -> 86.5 us, reduce 124.5 -> 117.3, and the GATHER 78.5 -> 75.1 (its 24 MB table
+// is no longer pushed out of the caches by the scatter's streams between two frames)
+#ifndef LNERF_BIN_NT
+#define LNERF_BIN_NT 3
+#endif
 struct alignas(8) Rec8 {
     uint32_t lo, hi;  // bits [0,12) row in bucket, [12,38) value 0, [38,64) value 1
     static constexpr bool kPacked = true;
@@ -644,7 +657,13 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restri
         n_x = n_y = n_z = 0.f;
         n_g = make_float2(0.f, 0.f);
         if (mm < M) {
-            n_g = reinterpret_cast<const float2 *>(dfeat)[(int64_t)lv * level_stride + mm];
+            const float2 *gp = reinterpret_cast<const float2 *>(dfeat) + ((int64_t)lv * level_stride + mm);
+            if (LNERF_BIN_NT & 1) {   // (read once per step: keep it out of the caches the table and the records use)
+                const nt_f2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f2 *>(gp));
+                n_g = make_float2(v.x, v.y);
+            } else {
+                n_g = *gp;
+            }
             n_x = xyzs[(int64_t)mm * 3]; n_y = xyzs[(int64_t)mm * 3 + 1]; n_z = xyzs[(int64_t)mm * 3 + 2];
         }
     };
@@ -821,7 +840,15 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restri
             uint4 *dst = reinterpret_cast<uint4 *>(recs + ((int64_t)lv.level * bm.n_items + tile) * ITEM_RECS);
             const uint4 *srcq = reinterpret_cast<const uint4 *>(s_stage);
             const int n16 = (total * (int)sizeof(REC) + 15) >> 4;
-            for (int i = tid; i < n16; i += BIN_T) dst[i] = srcq[i];
+            for (int i = tid; i < n16; i += BIN_T) {
+                if (LNERF_BIN_NT & 2) {
+                    const uint4 q = srcq[i];
+                    nt_u4 v = {q.x, q.y, q.z, q.w};
+                    __builtin_nontemporal_store(v, reinterpret_cast<nt_u4 *>(dst + i));
+                } else {
+                    dst[i] = srcq[i];
+                }
+            }
             if (tid < nb)
                 segtab[(int64_t)lv.b0 * bm.n_items + (int64_t)tile * nb + tid] =
                     (uint32_t)s_off[tid] | ((uint32_t)s_cnt[cur][tid] << 16);
@@ -906,6 +933,38 @@ __device__ __forceinline__ int active_slices(int n, int smax) {
 #ifndef LNERF_REDUCE_XCD
 #define LNERF_REDUCE_XCD 1
 #endif
+// LNERF_REDUCE_NT (bit mask): non-temporal policy on the once-per-step streams of the reduce pass -- 1: parameter /
+// moment loads, 2: their stores (the bf16 shadow the gather reads keeps the default policy), 4: the record loads
+// (measured: the gather gains 1.5 us more, the reduce pass loses 8 -- off)
+#ifndef LNERF_REDUCE_NT
+#define LNERF_REDUCE_NT 3
+#endif
+__device__ __forceinline__ float4 ld_f4(const float4 *p) {
+    if (LNERF_REDUCE_NT & 1) {
+        const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4 *>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    return *p;
+}
+__device__ __forceinline__ void st_f4(float4 *p, const float4 &x) {
+    if (LNERF_REDUCE_NT & 2) {
+        nt_f4 v = {x.x, x.y, x.z, x.w};
+        __builtin_nontemporal_store(v, reinterpret_cast<nt_f4 *>(p));
+    } else {
+        *p = x;
+    }
+}
+template <typename REC> __device__ __forceinline__ REC ld_rec(const REC *p) { return *p; }
+template <> __device__ __forceinline__ Rec8 ld_rec<Rec8>(const Rec8 *p) {
+    if (LNERF_REDUCE_NT & 4) {
+        const nt_u2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u2 *>(p));
+        Rec8 r;
+        r.lo = v.x; r.hi = v.y;
+        return r;
+    }
+    return *p;
+}
+
 template <int RT, typename REC, bool FUSE>
 __device__ __forceinline__ void scatter_reduce_one(int wg, const GridMeta &meta, const BucketMeta &bm,
                                                    const int32_t *__restrict__ items_dev,
@@ -1037,7 +1096,7 @@ __device__ __forceinline__ void scatter_reduce_one(int wg, const GridMeta &meta,
             REC r[U];
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (u < nr) r[u] = lrec[locate(64 * u)];
+                if (u < nr) r[u] = ld_rec(lrec + locate(64 * u));
             for (int rb = 0; rb < nr; rb += U) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -1045,7 +1104,7 @@ __device__ __forceinline__ void scatter_reduce_one(int wg, const GridMeta &meta,
                     if (rd < nr) {
                         pin_record(r[u]);                             // (keeps the load outside the predicated block)
                         const REC cur = r[u];
-                        if (rd + U < nr) r[u] = lrec[locate(64 * (rd + U))];
+                        if (rd + U < nr) r[u] = ld_rec(lrec + locate(64 * (rd + U)));
                         if (64 * rd + lane < T) add(cur);
                     }
                 }
@@ -1056,7 +1115,7 @@ __device__ __forceinline__ void scatter_reduce_one(int wg, const GridMeta &meta,
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {  // all of the lane's loads: six 16-byte loads in flight behind the barrier
                 const int q = tid + j * RT;
-                P[j] = p4[q]; Mv[j] = m4[q]; V[j] = v4[q];
+                P[j] = ld_f4(p4 + q); Mv[j] = ld_f4(m4 + q); V[j] = ld_f4(v4 + q);
             }
         }
         __syncthreads();
@@ -1065,7 +1124,7 @@ __device__ __forceinline__ void scatter_reduce_one(int wg, const GridMeta &meta,
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             const int q = tid + j * RT;
-            P[j] = p4[q]; Mv[j] = m4[q]; V[j] = v4[q];
+            P[j] = ld_f4(p4 + q); Mv[j] = ld_f4(m4 + q); V[j] = ld_f4(v4 + q);
         }
     }
     if (!direct) {  // sliced bucket: hand the exact sums to k_scatter_finish
@@ -1112,7 +1171,7 @@ __device__ __forceinline__ void scatter_reduce_one(int wg, const GridMeta &meta,
                 adam_one(P[j].y, gb, Mv[j].y, V[j].y, a);
                 adam_one(P[j].z, gc, Mv[j].z, V[j].z, a);
                 adam_one(P[j].w, gd, Mv[j].w, V[j].w, a);
-                p4[q] = P[j]; m4[q] = Mv[j]; v4[q] = V[j];
+                st_f4(p4 + q, P[j]); st_f4(m4 + q, Mv[j]); st_f4(v4 + q, V[j]);
                 if (sh) {
                     uint2 w;
                     w.x = (uint32_t)f32_to_bf16(P[j].x) | ((uint32_t)f32_to_bf16(P[j].y) << 16);
@@ -1747,7 +1806,8 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
     if (phases == 3 && g_scatter_groups > 1 && lv_lo == 0 && lv_hi == num_levels) {
         // level GROUPS: bin(group) -> reduce(group) -> bin(next group) ...  A group's records (1/groups of the 216 MB a
         // frame writes) are read back right behind their writes, while they still sit in the 256 MiB Infinity Cache:
-        // the whole-frame form streams them out to HBM and back
+        // the whole-frame form streams them out to HBM and back.  Measured slower at every group count, and slower
+        // still with reduce(g) on a side stream beside bin(g + 1): default 1
         const int ng = g_scatter_groups < num_levels ? g_scatter_groups : num_levels;
         for (int gi = 0; gi < ng; ++gi) {
             const int l0 = (int)((int64_t)num_levels * gi / ng), l1 = (int)((int64_t)num_levels * (gi + 1) / ng);

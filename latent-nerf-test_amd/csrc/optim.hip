@@ -25,6 +25,18 @@ template <> struct Grad4<uint16_t> {
     static __device__ __forceinline__ void zero1(uint16_t *g, int64_t t) { g[t] = 0; }
 };
 
+// parameters and moments pass through once per step: non-temporal both ways, so that they do not push the table's bf16
+// shadow (what the gather reads) and the gradients out of the caches (same policy as the fused update in grid.hip)
+typedef float adam_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_once(const float *base, int64_t i) {
+    const adam_f4 v = __builtin_nontemporal_load(reinterpret_cast<const adam_f4 *>(base) + i);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st_once(float *base, int64_t i, const float4 &x) {
+    adam_f4 v = {x.x, x.y, x.z, x.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<adam_f4 *>(base) + i);
+}
+
 template <typename TG>
 __global__ void __launch_bounds__(256)
 k_adam(float *__restrict__ p, TG *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
@@ -34,15 +46,15 @@ k_adam(float *__restrict__ p, TG *__restrict__ g, float *__restrict__ m, float *
     a.zero_grad = 0;  // (adam_one works on a register copy of g; the buffer is cleared below)
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        float4 P = reinterpret_cast<float4 *>(p)[i], G = Grad4<TG>::load(g, i);
-        float4 Mv = reinterpret_cast<float4 *>(m)[i], V = reinterpret_cast<float4 *>(v)[i];
+        float4 P = ld_once(p, i), G = Grad4<TG>::load(g, i);
+        float4 Mv = ld_once(m, i), V = ld_once(v, i);
         adam_one(P.x, G.x, Mv.x, V.x, a);
         adam_one(P.y, G.y, Mv.y, V.y, a);
         adam_one(P.z, G.z, Mv.z, V.z, a);
         adam_one(P.w, G.w, Mv.w, V.w, a);
-        reinterpret_cast<float4 *>(p)[i] = P;
-        reinterpret_cast<float4 *>(m)[i] = Mv;
-        reinterpret_cast<float4 *>(v)[i] = V;
+        st_once(p, i, P);
+        st_once(m, i, Mv);
+        st_once(v, i, V);
         if (zero_grad) Grad4<TG>::zero(g, i);
         if (shadow) {
             uint2 s;

@@ -61,6 +61,11 @@ class OptimConfig:
     # a guidance object that is itself capturable (guidance.capturable: device ops only, device-side RNG -- the synthetic
     # one) is captured INSIDE the step graph: one graph launch per step.  False: graph F / eager guidance / graph B always
     graph_guidance: bool = True
+    # data parallel on RCCL: the gradient exchange (per-group sums + all-reduces, flat bucket) and the optimiser are
+    # captured INTO the step graph (RCCL's collectives are capturable; one graph launch per step on every rank, no eager
+    # launches between the ranks' graphs).  False, or a backend that stages through the host (gloo): graph / eager
+    # exchange + optimiser
+    graph_collectives: bool = True
 
 
 @dataclass

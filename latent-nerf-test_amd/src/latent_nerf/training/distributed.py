@@ -33,6 +33,13 @@ def exchange_active(group=None) -> bool:
     return dist.get_world_size(group) > 1 or force_exchange()
 
 
+def backend_name(group=None) -> str:
+    """"nccl" (= RCCL), "gloo", ... of the initialised process group; "" without one."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return ""
+    return str(dist.get_backend(group))
+
+
 def init_distributed():
     """Call FIRST in a training process, before anything touches the GPU: binds this rank to its device and, when
     the launcher (`python -m torch.distributed.run --nproc-per-node N ...`) set WORLD_SIZE > 1 (or LNERF_FORCE_DIST=1,

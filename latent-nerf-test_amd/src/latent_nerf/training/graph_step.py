@@ -4,8 +4,9 @@ graph, so the host cost of a step is one graph launch instead of ~40 Python/ctyp
 Every C-ABI entry point only enqueues work on the current stream and never synchronises or allocates
 (include/lnerf_hip.h), data-dependent sizes stay on the device, and the optimiser keeps its step counter
 on the device (`FusedAdam(capturable=True)`), so the step is capturable as is.  With more than one rank
-the RCCL all-reduce stays OUTSIDE the graphs (graph A: render + backward, eager collectives on the
-static gradient tensors, graph B: optimiser): collectives are then launched exactly as in eager mode."""
+the exchange is captured too where the backend's collectives can be (RCCL: `sync_in_graph=True`, one graph
+launch per step and rank); otherwise (gloo stages through the host) it stays OUTSIDE the graphs: graph A
+(render + backward), eager collectives on the static gradient tensors, graph B / eager optimiser."""
 import torch
 
 # hipStreamCaptureModeThreadLocal: only the capturing thread is restricted.  Under the default (global) mode RCCL's
@@ -16,7 +17,7 @@ CAPTURE_MODE = "thread_local"
 
 class GraphedTrainStep:
     def __init__(self, fwd_bwd, opt_step, params, sync=None, world=1, warmup=3, stream=None, opt_in_graph=True,
-                 steps_per_graph=1):
+                 steps_per_graph=1, sync_in_graph=False):
         """fwd_bwd() -> dict of output tensors (leaves `.grad` set on `params`);
         opt_step() consumes the gradients; sync() all-reduces `.grad` in place (world > 1).
 
@@ -24,8 +25,11 @@ class GraphedTrainStep:
         `stream` (or make it current): autograd pins each parameter's gradient accumulation to the stream
         it first ran on, and accumulation on the legacy default stream cannot be captured.
 
-        opt_in_graph=False (world > 1, pipelined exchange): the optimiser step stays eager -- it waits for one level
-        group's all-reduce at a time (FusedAdam.step(row_groups=...)), which a captured graph cannot express.
+        opt_in_graph=False (world > 1, exchange outside the graphs, pipelined): the optimiser step stays eager -- it
+        waits for one level group's eagerly launched all-reduce at a time (FusedAdam.step(row_groups=...)).
+
+        sync_in_graph=True (world > 1, RCCL): sync() and opt_step() are captured behind fwd_bwd() in the SAME graph --
+        the collectives' launches on RCCL's stream, the optimiser's waits on them and the hand-offs become graph edges.
 
         steps_per_graph (world == 1): that many whole steps per captured graph -- 2 for a `fwd_bwd` that alternates
         between two buffer sets (rays of step k+1 marched on a side stream while step k is shaded), whose pointers a
@@ -55,7 +59,15 @@ class GraphedTrainStep:
             p.grad = None
         self.graph_a = torch.cuda.CUDAGraph()
         self.graph_b = None
-        if world == 1:
+        if world > 1 and sync_in_graph:
+            with torch.cuda.graph(self.graph_a, stream=stream, capture_error_mode=CAPTURE_MODE):
+                self.out = fwd_bwd()
+                self.static_grads = [p.grad for p in self.params]
+                if sync is not None:
+                    sync()
+                opt_step()
+            self.graph_b = None
+        elif world == 1:
             with torch.cuda.graph(self.graph_a, stream=stream, capture_error_mode=CAPTURE_MODE):
                 for _ in range(self.steps_per_call):
                     self.out = fwd_bwd()

@@ -81,6 +81,9 @@ class Trainer:
         self.grad_sync = D.GradSync([self.nerf.encoder.embeddings], small,
                                     transport=torch.bfloat16 if bf16 else torch.float32)
         self.pipelined = self.exchange and bf16 and n_views == 1
+        # the exchange goes into the captured step where the collectives can be captured (RCCL; not gloo's host staging)
+        self.capture_exchange = (self.exchange and bool(getattr(cfg.optim, "graph_collectives", True))
+                                 and D.backend_name() == "nccl")
         if self.pipelined:
             self.grad_sync.attach_sink(self.nerf.encoder, pipeline_groups=max(1, cfg.optim.exchange_groups))
         self.dataloaders = self.init_dataloaders()
@@ -217,6 +220,7 @@ class Trainer:
                             "cam": torch.zeros(21, device=self.device)}
         st = self._static
         solo = not self.exchange
+        inline = self.capture_exchange
         opt = self.optimizer
         keep = (opt.step_no, self.nerf.local_step)
 
@@ -230,6 +234,8 @@ class Trainer:
             self._backward(out, pred, st["grad"])
             if solo:
                 opt.step(grad_scale=1.0)
+            elif inline:
+                self._exchange_and_step(1)   # collectives and the optimiser's waits on them are captured
 
         # a guidance that is itself capturable (the synthetic one) goes INSIDE the graph: one launch per step
         self._whole = bool(getattr(self.diffusion, "capturable", False)) and hasattr(self.diffusion, "train_step_device") \
@@ -246,6 +252,8 @@ class Trainer:
                 self._backward(out, pred, grad)
                 if solo:
                     opt.step(grad_scale=1.0)
+                elif inline:
+                    self._exchange_and_step(1)
                 return out, pred
 
             self._gstep = GraphedWholeStep(whole, list(self.nerf.parameters()), self.stream)
@@ -275,9 +283,9 @@ class Trainer:
             st["grad"].copy_(self._guidance_grad(pred, data["dir"]))
             grads = g.backward()
         self.nerf.local_step += 1
-        if not self.exchange:
+        if not self.exchange or self.capture_exchange:
             self.optimizer.note_replayed_step()
-        else:   # data parallel: the captured backward left this rank's gradients; exchange + optimiser stay eager
+        else:   # exchange outside the graphs: the captured backward left this rank's gradients; the rest is eager
             for p, gr in zip(g.params, grads):
                 p.grad = gr
             self._exchange_and_step(1)
