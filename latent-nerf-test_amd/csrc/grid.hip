@@ -933,6 +933,10 @@ __device__ __forceinline__ int active_slices(int n, int smax) {
 #ifndef LNERF_REDUCE_XCD
 #define LNERF_REDUCE_XCD 1
 #endif
+// how a lane of the record loop finds its record: 0 = scalar walk over the segments a round spans, 1 = start bitmap
+#ifndef LNERF_REDUCE_WALK
+#define LNERF_REDUCE_WALK 1
+#endif
 // LNERF_REDUCE_NT (bit mask): non-temporal policy on the once-per-step streams of the reduce pass -- 1: parameter /
 // moment loads, 2: their stores (the bf16 shadow the gather reads keeps the default policy), 4: the record loads
 // (measured: the gather gains 1.5 us more, the reduce pass loses 8 -- off)
@@ -976,6 +980,10 @@ __device__ __forceinline__ void scatter_reduce_one(int wg, const GridMeta &meta,
     // flat atomic -- measured 0.211 -> 0.275 ms for the scatter call)
     __shared__ long long acc[BK_ROWS * 2];  // [feature][row]: a wave's 64 random rows spread over 32 bank pairs
     __shared__ int s_red[RT / 64];
+#if LNERF_REDUCE_WALK
+    __shared__ uint32_t s_bmp[RT / 64][128];            // per wave: segment-start bitmap of a sub-batch (4096 records)
+    __shared__ uint32_t s_soff[RT / 64][64];            // per wave: (chunk slot - flat start) of its non-empty segments
+#endif
     constexpr int NW = RT / 64;
     // locate (level, bucket, slice) of this work unit
     int l = 0;
@@ -1071,6 +1079,7 @@ __device__ __forceinline__ void scatter_reduce_one(int wg, const GridMeta &meta,
             // reaches into the round and its flat start; a round visits the 2-3 segments it spans, each visit two scalar
             // readlanes and three vector instructions -- no cross-lane traffic on the LDS pipe, which the two 64-bit
             // atomics of every record need (a binary search through ds_bpermute was 12 us slower).
+#if LNERF_REDUCE_WALK == 0
             int sj = 0, sp = 0;
             // record index (inside the level's region) of flat record fb + lane; called with increasing fb
             auto locate = [&](int fb) __attribute__((always_inline)) -> uint32_t {
@@ -1109,6 +1118,80 @@ __device__ __forceinline__ void scatter_reduce_one(int wg, const GridMeta &meta,
                     }
                 }
             }
+#else
+            // Which segment a lane's record is in comes from a BITMAP of the segment starts: bit p = "flat record p is the
+            // first of its segment"; lane k keeps bits [64 k, 64 k + 64).  A round reads its 64 bits with two scalar
+            // readlanes; a lane's segment is the number of starts at or below its position (mbcnt), its record's slot
+            // one LDS read of that segment's (chunk slot - flat start) plus its position: ~10 instructions per round
+            // instead of a scalar walk over the 2-3 segments a round spans (~150: the pass was bound by instruction issue,
+            // not by HBM -- without the Adam phase it took 87 us for 240 MB).  The bitmap covers SUB = 4096 records (64
+            // rounds): a window of 64 segments is taken in sub-batches of whole segments with at most SUB records.
+            (void)cnt;
+            constexpr int SUB = 4096;
+            static_assert(ITEM_RECS <= SUB, "a segment must fit a sub-batch");
+            const int c = (int)(e >> 16);                             // records of the lane's segment
+            const int inc = wave_inclusive_sum_i(c);
+            int a = 0, a_base = 0;                                    // first lane / flat start of the sub-batch (uniform)
+            while (a_base < T) {
+                const bool in = lane >= a && inc - a_base <= SUB;     // (inc is monotone: a contiguous run from lane a)
+                const int bnd = a + (int)__popcll(__ballot(in));      // one past the sub-batch's last lane, > a
+                const int Ts = __builtin_amdgcn_readlane(inc, bnd - 1) - a_base;   // its records
+                const bool seg = in && c > 0;
+                const int ci = (int)mbcnt(__ballot(seg));             // index among the non-empty segments
+                const int start = inc - c - a_base;                   // flat start inside the sub-batch
+                s_bmp[wave][2 * lane] = 0u;
+                s_bmp[wave][2 * lane + 1] = 0u;
+                if (seg) {
+                    atomicOr(&s_bmp[wave][start >> 5], 1u << (start & 31));
+                    s_soff[wave][ci] = (uint32_t)(first + NW * (kb + lane)) * (uint32_t)ITEM_RECS + (e & 0xFFFFu) -
+                                       (uint32_t)start;
+                }
+                // the lanes exchange data through LDS: a wave's LDS operations execute in order, but the COMPILER reasons
+                // per thread -- without the fence pair a lane that set no bit "knows" its words are still zero and never
+                // reads them back (measured: the read was sunk into the `if (seg)` block above)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int bm_lo = (int)s_bmp[wave][2 * lane], bm_hi = (int)s_bmp[wave][2 * lane + 1];
+                int nstart = 0;                                       // segment starts before the round (uniform)
+                // record index (inside the level's region) of flat record fb + lane; called with increasing fb
+                auto locate = [&](int fb) __attribute__((always_inline)) -> uint32_t {
+                    const int k = __builtin_amdgcn_readfirstlane(fb >> 6);
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(bm_lo, k);
+                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane(bm_hi, k);
+                    const unsigned long long m1 = (((unsigned long long)hi << 32) | lo) >> 1;
+                    // starts at positions 1..lane = bits below `lane` of (M >> 1); position 0 = bit 0 of M
+                    const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32),
+                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+                    const int j = nstart + (int)(lo & 1u) - 1 + below;
+                    nstart += __popc(lo) + __popc(hi);
+                    const int f = fb + lane;
+                    const uint32_t at = s_soff[wave][j < 0 ? 0 : j] + (uint32_t)f;
+                    return f < Ts ? at : 0u;                          // (slot 0 exists: the load is unconditional)
+                };
+                // software pipeline over the rounds: U loads are in flight at ALL times -- a round's record is consumed
+                // and its register immediately re-armed with the load of the round U ahead
+                const int nr = (Ts + 63) >> 6;                        // rounds (uniform)
+                REC r[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (u < nr) r[u] = ld_rec(lrec + locate(64 * u));
+                for (int rb = 0; rb < nr; rb += U) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int rd = rb + u;                        // uniform
+                        if (rd < nr) {
+                            pin_record(r[u]);                         // (keeps the load outside the predicated block)
+                            const REC cur = r[u];
+                            if (rd + U < nr) r[u] = ld_rec(lrec + locate(64 * (rd + U)));
+                            if (64 * rd + lane < Ts) add(cur);
+                        }
+                    }
+                }
+                a = bnd;
+                a_base += Ts;
+            }
+#endif
         }
         RED_STAMP(11);
         if (fast) {
