@@ -534,10 +534,19 @@ def main():
         from src.latent_nerf.training.graph_step import GraphedTrainStep
         # (a capture failure raises: the line must not silently describe eager launches; use --graph 0 for those)
         in_graph = bool(dist_on and args.graph_collectives and dist.get_backend() == "nccl")
-        gstep = GraphedTrainStep(fwd_bwd, opt_step, list(net.parameters()), sync=sync, world=2 if dist_on else 1, warmup=3,
-                                 stream=main_stream, opt_in_graph=not groups, steps_per_graph=2 if prefetch else 1,
-                                 sync_in_graph=in_graph)
-        launch = "hipgraph (exchange + optimiser captured)" if in_graph else "hipgraph"
+        kw = dict(sync=sync, world=2 if dist_on else 1, warmup=3, stream=main_stream, opt_in_graph=not groups,
+                  steps_per_graph=2 if prefetch else 1)
+        launch = "hipgraph"
+        if in_graph:
+            try:
+                gstep = GraphedTrainStep(fwd_bwd, opt_step, list(net.parameters()), sync_in_graph=True, **kw)
+                launch = "hipgraph (exchange + optimiser captured)"
+            except RuntimeError as e:   # a collective the backend cannot capture: every rank takes the same turn
+                log("capture with collectives failed (%s): graph A + eager exchange" % str(e).splitlines()[0])
+                torch.cuda.synchronize()
+                launch = "hipgraph (exchange eager: capture with collectives failed)"
+        if gstep is None:
+            gstep = GraphedTrainStep(fwd_bwd, opt_step, list(net.parameters()), **kw)
     emb0 = net.encoder.embeddings.detach().clone()
     spg = gstep.steps_per_call if gstep is not None else 1
     # occupancy refresh (H10) at the trainer's cadence, inside the timed region: update_extra_state() in its

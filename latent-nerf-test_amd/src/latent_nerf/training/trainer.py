@@ -256,9 +256,20 @@ class Trainer:
                     self._exchange_and_step(1)
                 return out, pred
 
-            self._gstep = GraphedWholeStep(whole, list(self.nerf.parameters()), self.stream)
+            build = lambda: GraphedWholeStep(whole, list(self.nerf.parameters()), self.stream)
         else:
-            self._gstep = GraphedRenderStep(forward, backward, list(self.nerf.parameters()), self.stream)
+            build = lambda: GraphedRenderStep(forward, backward, list(self.nerf.parameters()), self.stream)
+        try:
+            self._gstep = build()
+        except RuntimeError as e:
+            opt.step_no, self.nerf.local_step = keep
+            if not inline:
+                raise
+            # a collective the backend cannot capture (every rank takes the same turn): exchange + optimiser stay eager
+            self.log("capture with collectives failed (%s): the exchange stays outside the graphs" % str(e).splitlines()[0])
+            torch.cuda.synchronize()
+            self.capture_exchange = False
+            return self._capture()
         opt.step_no, self.nerf.local_step = keep   # host-side counters the captured Python advanced
         self._gstep_capacity = self.nerf._march.capacity
         self.graph_stats["captures"] += 1

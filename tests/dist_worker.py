@@ -28,7 +28,8 @@ def main():
         "render.eval_h": 32, "render.eval_w": 32, "render.grid_size": 64, "optim.iters": steps, "optim.lr": 5e-3,
         "log.save_interval": 10000, "log.eval_size": 1, "log.full_eval_size": 2, "optim.fp16": precision == "bf16",
         "guide.text": "a lego man",
-        "optim.views_per_step": world, "optim.exchange_groups": groups})
+        "optim.views_per_step": world, "optim.exchange_groups": groups,
+        "optim.graph_collectives": os.environ.get("LNERF_TEST_GRAPH_COLLECTIVES", "1") != "0"})
     tr = Trainer(cfg, device=dev)
     table0 = tr.nerf.encoder.embeddings.detach().clone()
     if save:   # the table after the FIRST step too (Adam's first step is lr * sign(g): an exact comparison point)
@@ -49,6 +50,7 @@ def main():
            "bits_set": int(tr.nerf.density_bitfield.count_nonzero()),
            "noise_seed": int(cfg.render.noise_seed)}
     res["exchange"] = bool(tr.exchange)
+    res["capture_exchange"] = bool(tr.capture_exchange)
     res["graph_stats"] = dict(tr.graph_stats)
     if save:   # the tensors themselves, for comparisons to a tolerance (forced single-rank RCCL against the fused step)
         import numpy as np

@@ -21,7 +21,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(tmp_path, world, groups, steps=20, precision="bf16", backend="gloo", force=False, save=False, tag=""):
+def _run(tmp_path, world, groups, steps=20, precision="bf16", backend="gloo", force=False, save=False, tag="",
+         graph_collectives=True):
     out = tmp_path / ("w%d_g%d_%s%s" % (world, groups, precision, tag))
     out.mkdir()
     port = _free_port()
@@ -29,7 +30,8 @@ def _run(tmp_path, world, groups, steps=20, precision="bf16", backend="gloo", fo
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), LNERF_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0",
-                   LNERF_FORCE_DIST="1" if force else "0")
+                   LNERF_FORCE_DIST="1" if force else "0",
+                   LNERF_TEST_GRAPH_COLLECTIVES="1" if graph_collectives else "0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(out), str(groups),
                                        str(steps), precision] + (["save"] if save else []), env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
@@ -75,15 +77,21 @@ def test_f32_exchange_and_single_rank_paths(built_lib, tmp_path):
 def test_exchange_path_on_rccl_with_one_rank(built_lib, tmp_path):
     """The N > 1 step on RCCL itself: ONE rank joins a `backend="nccl"` process group (communicator of size 1,
     initialised before any GPU call) and LNERF_FORCE_DIST=1 takes the un-fused path -- bf16 gradient sink written by the
-    scatter, table exchanged in 4 pipelined level groups (async all-reduce per group on RCCL's stream, hand-offs against
-    the captured graph B), FusedAdam.step(row_groups=...), flat f32 bucket of small parameters -- through the real
-    Trainer (captured step: graph F / guidance / graph B = backward + binning, eager exchange + optimiser).  Against the
-    fused single-rank trainer on the same seeds the table must agree to the bf16-wire tolerance: the only difference is
-    the rounding of the summed table gradient to bf16 (2^-9 relative) before Adam."""
+    scatter, table exchanged in 4 pipelined level groups (async all-reduce per group on RCCL's stream), flat f32 bucket
+    of small parameters, FusedAdam.step(row_groups=...) -- through the real Trainer.  Twice: with the exchange and the
+    optimiser CAPTURED into the step graph (optim.graph_collectives, the default on RCCL: one graph launch per step) and
+    with graph / eager exchange / eager optimiser; the two run the same kernels in the same order and must agree bit
+    for bit.  Against the fused single-rank trainer on the same seeds the table must agree to the bf16-wire tolerance:
+    the only difference is the rounding of the summed table gradient to bf16 (2^-9 relative) before Adam."""
     import numpy as np
     (forced,) = _run(tmp_path, 1, 4, steps=20, backend="nccl", force=True, save=True, tag="_forced")
+    (eager_x,) = _run(tmp_path, 1, 4, steps=20, backend="nccl", force=True, save=True, tag="_eagerx",
+                      graph_collectives=False)
     (fused,) = _run(tmp_path, 1, 4, steps=20, backend="nccl", force=False, save=True, tag="_fused")
     assert forced["exchange"] and forced["pipelined"] and not fused["exchange"] and not fused["pipelined"]
+    assert forced["capture_exchange"] and not eager_x["capture_exchange"] and eager_x["pipelined"]
+    for key in ("table", "mlp", "density_grid", "bitfield"):
+        assert forced[key] == eager_x[key], key            # captured exchange == eager exchange, bit for bit
     assert forced["steps"] == fused["steps"] == 20 and forced["finite"] and forced["table_moved"] > 0
     assert forced["graph_stats"]["replayed_steps"] >= 15 and fused["graph_stats"]["replayed_steps"] >= 15
     ld = lambda r, name: np.load(os.path.join(r["dir"], name))

@@ -18,5 +18,5 @@ nl = 16
 for l in range(nl):
     b = sorted(dur(bins[i]) for i in range(l, len(bins), nl))
     r = sorted(dur(reds[i]) for i in range(l, len(reds), nl))
-    print("level %2d  bin %.1f us  reduce %.1f us  grid_red %s" % (l, b[len(b)//2], r[len(r)//2], reds[l]['Grid_Size']))
+    print("level %2d  bin %.1f us  reduce %.1f us  grid_red %s" % (l, b[len(b)//2], r[len(r)//2], reds[l].get('Grid_Size', reds[l].get('Grid_Size_X', '?'))))
 PY
