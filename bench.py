@@ -102,8 +102,8 @@ def parse():
     ap.add_argument("--fragment-shadow", type=int, default=1,
                     help="1: the optimiser mirrors the MLP weights into their bf16 fragments (no per-step fragment build)")
     ap.add_argument("--tail", type=int, default=1,
-                    help="1: the step ends with ONE launch (lnerf_step_tail: scatter finishing pass + MLP slab sum + Adam of "
-                         "the MLP's tensors + step-counter tick + clearing of the scatter's level maxima); 0: separate launches")
+                    help="1: the step's tail (MLP slab sum + Adam of the MLP's tensors + step-counter tick + clearing of the "
+                         "scatter's level maxima) runs inside the scatter's pass 2 -- no launch behind it; 0: separate launches")
     ap.add_argument("--tune", default="", help="lnerf_set_tuning overrides for an experiment: key=value,key=value "
                     "(recorded in the output line; the default run sets none)")
     ap.add_argument("--force-dist", action="store_true",
@@ -512,7 +512,8 @@ def main():
     opt.grad_scale = 1.0 / world
     tr = args.precision if args.grad_transport == "auto" else args.grad_transport
     groups = args.exchange_groups if (dist_on and tr == "bf16") else 0
-    scatter_call = ("lnerf_grid_encode_backward_adam" if fuse else
+    inline_tail = bool(opt.fused is not None and opt.fused.inline_tail)   # pass 2 of the scatter closes the step itself
+    scatter_call = ("lnerf_grid_encode_backward_adam_tail" if inline_tail else "lnerf_grid_encode_backward_adam" if fuse else
                     "lnerf_grid_scatter_bin" if groups else
                     "lnerf_grid_encode_backward_bf16" if (dist_on and tr == "bf16") else "lnerf_grid_encode_backward")
     prefetch = bool(args.prefetch_rays)
@@ -720,7 +721,7 @@ def main():
                              "(NeRFRenderer.prepare_rays, two buffer sets, two steps per captured graph)") if prefetch else None,
             "gridtype": args.gridtype,
             "mlp_fragment_shadow": bool(opt.mlp is not None),
-            "step_tail": bool(opt._tail is not None),
+            "step_tail": ("inside the scatter's pass 2" if inline_tail else "one launch") if opt._tail is not None else False,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -740,7 +741,8 @@ def main():
                          "bytes_per_sample": bytes_per_sample, "samples_per_launch": M, "kernel_ms": g_ms},
             "mfma": mfma,
             "scatter": {"kernel": scatter_call.replace("lnerf_", "") + " (H6: two-pass bucketed scatter"
-                                  + (" + fused Adam step of the table)" if fuse else
+                                  + (" + fused Adam step of the table + the step's tail in the same launch)" if inline_tail else
+                                     " + fused Adam step of the table)" if fuse else
                                      ", gradient written in the bf16 wire format)" if scatter_call.endswith("bf16") else
                                      " + grid_scatter_reduce_bf16 per level group: pipelined exchange)" if groups else ")"),
                         "algorithmic_GBps": scatter, "kernel_ms": s_ms},

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define LNERF_ABI_VERSION 4
+#define LNERF_ABI_VERSION 5
 
 #define LNERF_OK 0
 #define LNERF_ERR_INVALID_ARG (-1)
@@ -173,13 +173,16 @@ int lnerf_grid_encode_forward(const float *xyzs, float bound, const void *table,
  * variant 0/1: per-lane global float atomics (blockIdx.y level map / XCD-aware map); no workspace.
  * variant 2  : two-pass bucketed scatter -- records binned per 64 KiB table chunk with plain
  *              stores, then reduced in LDS in 64-bit fixed point and added with coalesced stores
- *              (heavily loaded coarse chunks are cut into slices whose exact integer partial sums a
- *              small finishing kernel adds up): the sums do not depend on execution order, the
+ *              (heavily loaded coarse chunks are cut into slices whose exact integer partial sums the
+ *              slice that finishes last adds up): the sums do not depend on execution order, the
  *              gradient is bitwise reproducible.  Needs `workspace` of
- *              lnerf_grid_encode_backward_workspace_bytes() bytes (16-byte aligned).
+ *              lnerf_grid_encode_backward_workspace_bytes() bytes (16-byte aligned) whose first
+ *              LNERF_SCATTER_ZERO_HEAD_BYTES were zero when it was FIRST used (arrival counters that
+ *              every call leaves zero again; the rest may hold anything).
  * variant 3  : variant 2 with packed 8-byte records (12-bit row inside the bucket + two values rounded
  *              to 26-bit floats, 17 mantissa bits): a third less record traffic, relative rounding
  *              2^-18 per addend; same workspace. */
+#define LNERF_SCATTER_ZERO_HEAD_BYTES (64 * 1024)
 size_t lnerf_grid_encode_backward_workspace_bytes(int num_levels, const int32_t *offsets_host, int64_t m_host);
 /* The first lnerf_grid_scatter_clear_bytes() bytes of that workspace (bucket cursors, level maxima) are cleared by every
  * bucketed scatter call with a fill dispatch of its own -- ~5 us in a replayed graph for a few KiB.  A caller that
@@ -192,8 +195,8 @@ size_t lnerf_grid_encode_backward_workspace_bytes(int num_levels, const int32_t 
  * One block = one 64-byte line of the bf16 table: a sample's 8 vertices touch 2.8 lines on average instead of 4.25.
  * Dense levels are unchanged.  Restated in oracle/nerf_oracle.py (grid_corner_indices(blocked=True)). */
 #define LNERF_GRID_BLOCKED 0x400
-/* variant | LNERF_SCATTER_DEFER_FINISH (lnerf_grid_encode_backward_adam): the finishing pass of the sliced buckets is not
- * launched -- lnerf_step_tail does it (with everything else that is left of the step) in one launch. */
+/* variant | LNERF_SCATTER_DEFER_FINISH: accepted and ignored (ABI 4 deferred a separate finishing pass of the sliced
+ * buckets to lnerf_step_tail; pass 2 finishes them itself now). */
 #define LNERF_SCATTER_DEFER_FINISH 0x200
 size_t lnerf_grid_scatter_clear_bytes(int num_levels, const int32_t *offsets_host, int64_t m_host);
 int lnerf_grid_encode_backward(const float *xyzs, float bound, const void *dfeat, int dfeat_dtype, int num_levels,
@@ -405,21 +408,24 @@ int lnerf_adam_step_multi_shadow(int count, float *const *p_host, float *const *
                                  float beta2, float eps, int step, const int32_t *step_dev, float grad_scale,
                                  int zero_grad, const int32_t *const *map_host, void *shadow_bf16,
                                  lnerf_stream_t stream);
-/* ---- the TAIL of a single-GPU optimisation step, one launch (a dependent dispatch in a replayed graph costs ~4.5 us
- * whatever it computes; three of them sat behind the scatter for a few microseconds of work):
- *   - finishing pass of the sliced buckets of the hash-grid scatter, with the fused Adam step of their rows
- *     (after lnerf_grid_encode_backward_adam(variant | LNERF_SCATTER_DEFER_FINISH); num_levels = 0: skipped);
+/* ---- the TAIL of a single-GPU optimisation step: what is left of it besides the scatter (a dependent dispatch in a
+ * replayed graph costs ~4.5 us whatever it computes; three of them sat behind the scatter for a few microseconds of work):
  *   - sum of the MLP's gradient slabs (after lnerf_mlp_backward(precision | LNERF_MLP_DEFER_REDUCE)) in the fixed order
  *     of the ordinary reduction, and the Adam step of w1, b1, w2, b2, w3, b3 straight from the sums
  *     (params / exp_avg / exp_avg_sq: host arrays of six device pointers; maps_host: optional, the three fragment maps of
  *     lnerf_mlp_fragment_maps -- the updated weights are mirrored into the fragment image at the head of mlp_workspace;
  *     mlp_workspace = NULL: skipped);
- *   - LNERF_TAIL_TICK: *step_dev += 1 once every workgroup has read it (needs the scatter part: the arrival counters
- *     live in the header of the scatter workspace, which lnerf_grid_encode_backward_workspace_bytes() includes and a
- *     fresh workspace must have zeroed once);
+ *   - LNERF_TAIL_TICK: *step_dev += 1 once every workgroup has read it (the arrival counters live in the header of the
+ *     scatter workspace: LNERF_SCATTER_ZERO_HEAD_BYTES);
  *   - LNERF_TAIL_CLEAR_SCATTER: the scatter's level maxima (first lnerf_grid_scatter_clear_bytes() bytes of its
  *     workspace) are zero on exit, i.e. the NEXT scatter call may pass LNERF_SCATTER_CLEARED.
- * Same arithmetic as the separate launches (csrc/adam_shared.h): parameters and moments are bit-identical. */
+ * Same arithmetic as the separate launches (csrc/adam_shared.h): parameters and moments are bit-identical.
+ * Two forms:
+ *   lnerf_grid_encode_backward_adam_tail  the scatter with the fused table update (lnerf_grid_encode_backward_adam) whose
+ *     pass 2 ALSO runs the tail, as extra workgroups of the same launch: the step has no launch behind the scatter.
+ *     For a step whose only parameters are the table and the MLP's six tensors; needs step_dev and m_host > 0.
+ *   lnerf_step_tail  the tail as a launch of its own, behind lnerf_grid_encode_backward_adam (when other small parameters
+ *     are stepped in between).  num_levels = 0: no scatter workspace (then no tick / clear). */
 #define LNERF_TAIL_TICK 1
 #define LNERF_TAIL_CLEAR_SCATTER 2
 int lnerf_step_tail(int num_levels, int level_dim, const int32_t *offsets_host, const float *scales_host,
@@ -429,6 +435,17 @@ int lnerf_step_tail(int num_levels, int level_dim, const int32_t *offsets_host, 
                     int mlp_precision, int out_dim, float *const *params_host, float *const *exp_avg_host,
                     float *const *exp_avg_sq_host, float mlp_lr, const int32_t *const *maps_host, float beta1, float beta2,
                     float eps, int step, int32_t *step_dev, float grad_scale, int flags, lnerf_stream_t stream);
+int lnerf_grid_encode_backward_adam_tail(const float *xyzs, float bound, const void *dfeat, int dfeat_dtype, int num_levels,
+                                         int level_dim, const int32_t *offsets_host, const float *scales_host,
+                                         const int32_t *res_host, int64_t m_host, const int32_t *m_dev,
+                                         int64_t level_stride, float *dtable_zero, int variant, void *workspace,
+                                         size_t workspace_bytes, float *table, float *exp_avg, float *exp_avg_sq,
+                                         void *shadow_bf16, float lr, const void *mlp_workspace,
+                                         size_t mlp_workspace_bytes, int mlp_precision, int out_dim,
+                                         float *const *params_host, float *const *exp_avg_host,
+                                         float *const *exp_avg_sq_host, float mlp_lr, const int32_t *const *maps_host,
+                                         float beta1, float beta2, float eps, int step, int32_t *step_dev, float grad_scale,
+                                         int flags, lnerf_stream_t stream);
 int lnerf_cast_f32_to_bf16(const float *src, void *dst, int64_t n, lnerf_stream_t stream);
 
 #ifdef __cplusplus

@@ -470,7 +470,11 @@ constexpr size_t HDR_GMAX_BYTES = (size_t)LNERF_MAX_LEVELS * CUR_STRIDE * sizeof
 constexpr size_t HDR_ITEMS_OFF = HDR_GMAX_BYTES;            // int32 [1] (+ padding to 128 bytes)
 constexpr size_t HDR_ARRIVE_OFF = HDR_GMAX_BYTES + 128;     // int32 [9 x CUR_STRIDE]: arrival counters of the step's tail
                                                             // launch (root + 8 shards, a line each; zero between launches)
-constexpr size_t HDR_BUCKETN_OFF = HDR_ARRIVE_OFF + 9 * CUR_STRIDE * sizeof(int32_t);    // int32 [buckets]
+// slice arrival counters of pass 2, one per bucket, at a FIXED place whatever the level table (a process re-uses one
+// workspace for every encoder: a region whose position depended on the bucket count would overlap another layout's
+// record counts); zero in a fresh workspace (LNERF_SCATTER_ZERO_HEAD_BYTES), left zero by every call
+constexpr size_t HDR_SLICE_ARRIVE_OFF = HDR_ARRIVE_OFF + 9 * CUR_STRIDE * sizeof(int32_t);
+constexpr size_t HDR_BUCKETN_OFF = HDR_SLICE_ARRIVE_OFF + (size_t)LNERF_MAX_LEVELS * 256 * sizeof(int32_t);    // int32 [buckets]
 
 struct BucketMeta {
     int nb[LNERF_MAX_LEVELS];            // buckets per level
@@ -918,7 +922,7 @@ __device__ __forceinline__ int active_slices(int n, int smax) {
 
 // A bucket summed by ONE workgroup: the workgroup adds its tile to dtable (or applies the Adam step, FUSE).
 // A bucket cut into slices (few, heavily loaded coarse buckets): every slice stores its EXACT 64-bit partial sums
-// as a tile of `partials`, and k_scatter_finish adds the tiles up -- integer addition, so the result does not depend
+// as a tile of `partials`, and the slice that arrives last adds the tiles up -- integer addition, so the result does not depend
 // on how many slices there were or in which order they ran: the whole gradient is bitwise reproducible.
 //
 // The records of bucket b are the segments (first slot, count) = segtab entry of (item, b), one per item of pass 1, inside
@@ -937,6 +941,129 @@ __device__ __forceinline__ int active_slices(int n, int smax) {
 #ifndef LNERF_REDUCE_WALK
 #define LNERF_REDUCE_WALK 1
 #endif
+// ---- the step's TAIL: what is left of a single-GPU step besides the scatter.  In a replayed graph a dependent dispatch
+// costs ~4.5 us whatever it computes, and three of them sat behind pass 2 for a few microseconds of work: the finishing
+// pass of the sliced buckets (pass 2 does it itself now), the sum of the MLP's gradient slabs and the Adam step of the
+// small parameters.  One SLAB BLOCK (256 threads) takes 16 parameters of the MLP: it sums their column of the gradient
+// slabs in a fixed order (k_mlp_reduce_slabs' arithmetic: deterministic) and applies the Adam step straight from the sum
+// -- the weight gradients never exist in memory; updated weights are mirrored into the bf16 weight fragments
+// (lnerf_mlp_fragment_maps).  The LAST block of a launch to arrive advances the device step counter and leaves the
+// scatter's level maxima zero for the next step (every other block has read both by then, and the arrival is a
+// device-scope atomic).  The slab blocks run
+//   * as EXTRA workgroups of pass 2 itself (lnerf_grid_encode_backward_adam_tail: four slab blocks per 1024-thread
+//     workgroup, in front of the buckets; the step then has no launch behind pass 2 at all), or
+//   * as their own launch (lnerf_step_tail: k_step_tail), where other small parameters must be stepped first.
+struct SlabAdam {
+    const float *slabs;
+    int n_slabs, out_dim;
+    float *p[6], *m[6], *v[6];        // w1, b1, w2, b2, w3, b3
+    const int32_t *map[3];            // optional: fragment positions of w1, w2, w3 (two per weight)
+    uint16_t *shadow;                 // the bf16 fragment image the maps point into
+    float lr;
+};
+constexpr int TAIL_P = 16, TAIL_G = 16;   // parameters per block, slab groups (as k_mlp_reduce_slabs)
+
+constexpr int TAIL_SLABS_PER_LANE = MLP_BWD_MAX_BLOCKS / TAIL_G;   // 32: every slab load of a lane in flight at once
+constexpr int TAIL_SHARDS = 8;                                     // arrival counters (one 128-byte line each)
+
+// One slab block: `blk` = index of the block of 16 parameters, `lt` = thread inside the block (0..255), `part` = its
+// [TAIL_G][TAIL_P] floats of LDS.  `a`: the table's Adam arguments; `step_now` the device step counter when
+// a.step_dev is set (requested by the caller with ONE device-scope atomic load per wave -- the last block of the launch
+// to arrive rewrites it).  Every load that depends on nothing is requested first and together: the launch is a handful
+// of dependent round trips per block.  Contains block-wide barriers at named-barrier-free places: call it with all 256
+// threads of the block (the 1024-thread form synchronises the whole workgroup, see the caller).
+// BATCH: slab values a lane keeps in flight (32 = all of them: the stand-alone launch; 8 inside pass 2, whose 64
+// registers per lane must not spill -- the sum takes the slabs in the same order either way).
+template <int BATCH, typename SYNC>
+__device__ __forceinline__ void slab_block(int blk, int lt, const SlabAdam &sa, AdamArgs a, int32_t step_now,
+                                           float (*part)[TAIL_P], SYNC sync) {
+    static_assert(TAIL_SLABS_PER_LANE % BATCH == 0, "whole batches");
+    const int pi = lt & (TAIL_P - 1), sg = lt / TAIL_P;
+    const int p = blk * TAIL_P + pi;
+    int k = -1, i = 0;   // slab column -> (tensor, element)
+    float Pw = 0.f, Mw = 0.f, Vw = 0.f;
+    int2 at = make_int2(-1, -1);
+    if (p < MLP_SLAB) {
+        if (p < MLP_SL_B1) { k = 0; i = p - MLP_SL_W1; }
+        else if (p < MLP_SL_W2) { k = 1; i = p - MLP_SL_B1; }
+        else if (p < MLP_SL_B2) { k = 2; i = p - MLP_SL_W2; }
+        else if (p < MLP_SL_W3) { k = 3; i = p - MLP_SL_B2; }
+        else if (p < MLP_SL_B3) { if ((p - MLP_SL_W3) / MLP_HID < sa.out_dim) { k = 4; i = p - MLP_SL_W3; } }
+        else { if (p - MLP_SL_B3 < sa.out_dim) { k = 5; i = p - MLP_SL_B3; } }
+    }
+    float vsl[BATCH];
+    auto fetch = [&](int j0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            const int bsl = sg + TAIL_G * (j0 + j);
+            vsl[j] = (p < MLP_SLAB && bsl < sa.n_slabs) ? sa.slabs[(int64_t)bsl * MLP_SLAB + p] : 0.f;
+        }
+    };
+    fetch(0);
+    if (sg == 0 && k >= 0) {
+        Pw = sa.p[k][i]; Mw = sa.m[k][i]; Vw = sa.v[k][i];
+        if (sa.shadow && !(k & 1)) at = reinterpret_cast<const int2 *>(sa.map[k >> 1])[i];
+    }
+    if (a.step_dev) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the counter has been READ: see the arrival)
+        adam_bias_at(a, step_now);
+    } else {
+        adam_bias(a);
+    }
+    a.zero_grad = 0;
+    float sum = 0.f;   // (k_mlp_reduce_slabs' order: slabs sg, sg + 16, ...)
+    for (int j0 = 0;; j0 += BATCH) {
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) sum += vsl[j];
+        if (j0 + BATCH >= TAIL_SLABS_PER_LANE) break;
+        fetch(j0 + BATCH);
+    }
+    part[sg][pi] = sum;
+    sync();
+    if (sg == 0 && k >= 0) {
+        sum = part[0][pi];
+#pragma unroll
+        for (int g = 1; g < TAIL_G; ++g) sum += part[g][pi];
+        AdamArgs am = a;
+        am.lr = sa.lr;
+        adam_one(Pw, sum, Mw, Vw, am);
+        sa.p[k][i] = Pw; sa.m[k][i] = Mw; sa.v[k][i] = Vw;
+        const uint16_t h = f32_to_bf16(Pw);   // weights (k = 0, 2, 4) are mirrored into their two fragment positions
+        if (at.x >= 0) sa.shadow[at.x] = h;
+        if (at.y >= 0) sa.shadow[at.y] = h;
+    }
+}
+
+// arrival of a block (call from ONE thread, after the block's reads of the step counter and the level maxima have
+// returned), two levels: 8 shard counters (a line each: ~600 arrivals on ONE word queue for 7 us at the memory side), the
+// block that completes a shard arrives at the root, the block that completes the root is the last of the launch
+__device__ __forceinline__ void tail_arrive(int32_t *arrive, int total, int block, int32_t *tick, int32_t step_now,
+                                            unsigned int *gmax, int do_tick, int clear_gmax) {
+    const int sh = block & (TAIL_SHARDS - 1);
+    const int mine = (total - sh + TAIL_SHARDS - 1) / TAIL_SHARDS;   // blocks of this shard
+    int32_t *cnt = arrive + (1 + sh) * CUR_STRIDE;
+    if (__hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine - 1) {
+        __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int shards = total < TAIL_SHARDS ? total : TAIL_SHARDS;
+        if (__hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1) {
+            __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (do_tick) __hip_atomic_store(&tick[0], step_now + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (clear_gmax)
+                for (int l = 0; l < LNERF_MAX_LEVELS; ++l)
+                    __hip_atomic_store(&gmax[l * CUR_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// what pass 2 does besides the buckets when it closes the step (all zero: nothing)
+struct TailJob {
+    SlabAdam sa;
+    int blocks;            // leading workgroups of the launch that run slab blocks (four each)
+    int32_t *tick;         // device step counter pair
+    int32_t *arrive;       // arrival counters (workspace header)
+    int do_tick, clear_gmax;
+};
+
 // LNERF_REDUCE_NT (bit mask): non-temporal policy on the once-per-step streams of the reduce pass -- 1: parameter /
 // moment loads, 2: their stores (the bf16 shadow the gather reads keeps the default policy), 4: the record loads
 // (measured: the gather gains 1.5 us more, the reduce pass loses 8 -- off)
@@ -973,9 +1100,11 @@ template <int RT, typename REC, bool FUSE>
 __device__ __forceinline__ void scatter_reduce_one(int wg, const GridMeta &meta, const BucketMeta &bm,
                                                    const int32_t *__restrict__ items_dev,
                                                    const uint32_t *__restrict__ segtab, int32_t *__restrict__ bucket_n,
+                                                   int32_t *__restrict__ slice_arrive,
                                                    const unsigned int *__restrict__ gmax, const REC *__restrict__ recs,
                                                    float *__restrict__ dtable, long long *__restrict__ partials,
-                                                   const FusedUpdate &fu) {
+                                                   const FusedUpdate &fu, const SlabAdam &sa, int32_t step_now,
+                                                   bool have_step) {
     // (declared HERE, not passed in: a pointer parameter loses the LDS address space and every ds_add_u64 becomes a
     // flat atomic -- measured 0.211 -> 0.275 ms for the scatter call)
     __shared__ long long acc[BK_ROWS * 2];  // [feature][row]: a wave's 64 random rows spread over 32 bank pairs
@@ -985,6 +1114,14 @@ __device__ __forceinline__ void scatter_reduce_one(int wg, const GridMeta &meta,
     __shared__ uint32_t s_soff[RT / 64][64];            // per wave: (chunk slot - flat start) of its non-empty segments
 #endif
     constexpr int NW = RT / 64;
+    if (wg < 0) {
+        // a SLAB workgroup of the closing launch (wg = -1 - index): RT / 256 slab blocks, their 1 KiB of LDS each carved
+        // out of the accumulator tile (used HERE, through the array itself: see above)
+        const int sub = (int)threadIdx.x >> 8, lt = (int)threadIdx.x & 255;
+        float (*part)[TAIL_P] = reinterpret_cast<float (*)[TAIL_P]>(acc) + sub * TAIL_G;
+        slab_block<8>((-1 - wg) * (RT / 256) + sub, lt, sa, fu.a, step_now, part, [] { __syncthreads(); });
+        return;
+    }
     // locate (level, bucket, slice) of this work unit
     int l = 0;
     while (l + 1 < meta.num_levels && wg >= bm.wgstart[l + 1]) ++l;
@@ -1022,8 +1159,10 @@ __device__ __forceinline__ void scatter_reduce_one(int wg, const GridMeta &meta,
         i1 = (int)(((long long)I * (s + 1)) / S);
     }
     const bool direct = S == 1;        // this workgroup sums the whole bucket: it finishes the rows itself
-    const bool fuse = FUSE && direct;
-    const bool have = i1 > i0;  // uniform
+    const bool fuse = FUSE;            // (whoever finishes a bucket -- its only workgroup, or the last slice to arrive)
+    // uniform.  (An active slice always has items: S > 1 means more than REDUCE_SLICE_RECS >= ITEM_RECS records, i.e.
+    // at least S items.)
+    const bool have = i1 > i0 || !direct;
     if (!have && !fuse) return;  // (a fused bucket without records still owes its rows the Adam step, g = 0)
     constexpr int FB = FixBits<REC>::kBits;
     const FixScale fs = fix_scale<FB>(gmax[l * CUR_STRIDE]);  // from the bound of |value| of the LEVEL (found by pass 1)
@@ -1041,7 +1180,7 @@ __device__ __forceinline__ void scatter_reduce_one(int wg, const GridMeta &meta,
 #ifdef LNERF_EXP_RED_NOADAM     // timing-only experiment build: the workgroup ends behind its record loop
     const bool fast = false;
 #else
-    const bool fast = fuse && !fu.grad_out && ((R0 | rows) & 1) == 0 && rows == BK_ROWS && (BK_ROWS / 2) % RT == 0;
+    const bool fast = fuse && direct && !fu.grad_out && ((R0 | rows) & 1) == 0 && rows == BK_ROWS && (BK_ROWS / 2) % RT == 0;
 #endif
     float4 P[NQ], Mv[NQ], V[NQ];
     float4 *p4 = reinterpret_cast<float4 *>(reinterpret_cast<float2 *>(fu.p) + R0);
@@ -1055,6 +1194,7 @@ __device__ __forceinline__ void scatter_reduce_one(int wg, const GridMeta &meta,
         if (lane < nmy) e_first = tab[(int64_t)(first + NW * lane) * nb];
         for (int i = tid; i < BK_ROWS * 2; i += RT) acc[i] = 0ll;
         __syncthreads();
+        step_now = __builtin_amdgcn_readfirstlane(step_now);   // (returned by now: into a scalar register for the loop)
         RED_STAMP(10);
         const REC *lrec = recs + (int64_t)l * bm.n_items * ITEM_RECS;
         unsigned long long *ua = reinterpret_cast<unsigned long long *>(acc);
@@ -1210,10 +1350,38 @@ __device__ __forceinline__ void scatter_reduce_one(int wg, const GridMeta &meta,
             P[j] = ld_f4(p4 + q); Mv[j] = ld_f4(m4 + q); V[j] = ld_f4(v4 + q);
         }
     }
-    if (!direct) {  // sliced bucket: hand the exact sums to k_scatter_finish
-        long long *pt = partials + ((int64_t)bm.pstart[l] + (int64_t)b * Smax + s) * (BK_ROWS * 2);
-        for (int i = tid; i < BK_ROWS * 2; i += RT) pt[i] = acc[i];
-        return;
+    if (!direct) {
+        // Sliced bucket: every slice publishes its EXACT 64-bit partial sums as a tile of `partials`; the slice that
+        // arrives LAST adds the other tiles to its own sums and finishes the rows like the only workgroup of an unsliced
+        // bucket (integer sums: neither the slicing nor the arrival order changes a bit of the result).  The heavily
+        // loaded coarse buckets come first in the grid, so this happens early in the launch, under the other buckets'
+        // work -- as its own pass behind the launch it was a chain of dependent round trips (~9 us) at the end of the
+        // step.  Tiles travel with device-scope (write-through / cache-bypassing) accesses: slices run on different
+        // XCDs, whose L2s are not coherent for plain stores, and the addresses are the same every step.
+        unsigned long long *tiles = reinterpret_cast<unsigned long long *>(partials) +
+                                    ((int64_t)bm.pstart[l] + (int64_t)b * Smax) * (BK_ROWS * 2);
+        unsigned long long *pt = tiles + (int64_t)s * (BK_ROWS * 2);
+        const unsigned long long *ul = reinterpret_cast<const unsigned long long *>(acc);
+        for (int i = tid; i < BK_ROWS * 2; i += RT)
+            __hip_atomic_store(&pt[i], ul[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the tile has been written
+        __syncthreads();
+        int32_t *arr = slice_arrive + bm.bstart[l] + b;
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(arr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == S - 1) __hip_atomic_store(arr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next call
+            s_red[0] = old;
+        }
+        __syncthreads();
+        if (s_red[0] != S - 1) return;     // uniform: an earlier arrival, somebody else finishes the bucket
+        for (int i = tid; i < BK_ROWS * 2; i += RT) {
+            unsigned long long q = ul[i];
+            for (int s2 = 0; s2 < S; ++s2)   // (S <= 64; four tiles in flight per lane)
+                if (s2 != s) q += __hip_atomic_load(&tiles[(int64_t)s2 * (BK_ROWS * 2) + i], __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+            acc[i] = (long long)q;
+        }
+        __syncthreads();
     }
     float *dst = dtable + R0 * 2;
 #ifdef LNERF_EXP_RED_NOADAM
@@ -1221,7 +1389,8 @@ __device__ __forceinline__ void scatter_reduce_one(int wg, const GridMeta &meta,
 #endif
     if (fuse) {
         AdamArgs a = fu.a;
-        adam_bias(a);
+        if (have_step) adam_bias_at(a, __builtin_amdgcn_readfirstlane(step_now));   // (the closing launch: see the kernel)
+        else adam_bias(a);
         a.zero_grad = 0;
         float2 *p2 = reinterpret_cast<float2 *>(fu.p) + R0, *m2 = reinterpret_cast<float2 *>(fu.m) + R0;
         float2 *v2 = reinterpret_cast<float2 *>(fu.v) + R0;
@@ -1292,216 +1461,37 @@ __device__ __forceinline__ void scatter_reduce_one(int wg, const GridMeta &meta,
 template <int RT, typename REC, bool FUSE>
 __global__ void __launch_bounds__(RT, RT / 128)
 k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ items_dev, const uint32_t *__restrict__ segtab,
-                 int32_t *__restrict__ bucket_n, const unsigned int *__restrict__ gmax, const REC *__restrict__ recs,
-                 float *__restrict__ dtable, long long *__restrict__ partials, int wg_lo, FusedUpdate fu) {
-    scatter_reduce_one<RT, REC, FUSE>((int)blockIdx.x + wg_lo, meta, bm, items_dev, segtab, bucket_n, gmax, recs, dtable,
-                                      partials, fu);
+                 int32_t *__restrict__ bucket_n, int32_t *__restrict__ slice_arrive, unsigned int *__restrict__ gmax,
+                 const REC *__restrict__ recs, float *__restrict__ dtable, long long *__restrict__ partials, int wg_lo,
+                 FusedUpdate fu, TailJob tj) {
+    // (closing the step: the counter is read ONCE per wave, with a device-scope atomic load, before anything else --
+    // the last workgroup of the launch to arrive rewrites it)
+    int32_t step_now = 0;
+    const bool closing = FUSE && (tj.do_tick || tj.clear_gmax || tj.blocks > 0);
+    // (requested here, consumed behind the workgroup's first barrier: no stall in front of the record stream)
+    if (closing && fu.a.step_dev) step_now = __hip_atomic_load(fu.a.step_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int unit = (int)blockIdx.x - (FUSE ? tj.blocks : 0);
+    scatter_reduce_one<RT, REC, FUSE>(unit < 0 ? unit : unit + wg_lo, meta, bm, items_dev, segtab, bucket_n, slice_arrive,
+                                      gmax, recs, dtable, partials, fu, tj.sa, step_now, closing && fu.a.step_dev != nullptr);
+    if (closing && (tj.do_tick || tj.clear_gmax) && threadIdx.x == 0)
+        // (this wave is done.  The workgroup's other waves requested the counter as their first instruction and the
+        // level maximum in front of the record loop; a workgroup's barriers wait for a wave's outstanding loads, and
+        // a workgroup that leaves before its first barrier has not used either value)
+        tail_arrive(tj.arrive, (int)gridDim.x, (int)blockIdx.x, tj.tick, step_now, gmax, tj.do_tick, tj.clear_gmax);
 }
 
-// Finishing pass of the sliced levels: one thread per table row adds the active slices' exact partial sums
-// (k_scatter_reduce), converts once and adds the result to dtable -- or applies the Adam step (FUSE).
-template <bool FUSE, int FB>
-__device__ __forceinline__ void scatter_finish_block(int block, const GridMeta &meta, const BucketMeta &bm,
-                                                     const int32_t *__restrict__ bucket_n,
-                                                     const unsigned int *__restrict__ gmax,
-                                                     const long long *__restrict__ partials, float *__restrict__ dtable,
-                                                     const FusedUpdate &fu, int lv_lo, int lv_hi) {
-    constexpr int WG_PER_BUCKET = BK_ROWS / 256;
-    const int fb = block / WG_PER_BUCKET;  // index among the buckets of sliced levels
-    int l = 0;
-    while (l + 1 < meta.num_levels && (bm.slices[l] <= 1 || fb >= bm.fstart[l] + bm.nb[l])) ++l;
-    if (bm.slices[l] <= 1) return;  // (cannot happen: the grid covers sliced buckets only)
-    if (l < lv_lo || l >= lv_hi) return;  // a launch over a level range (pipelined data-parallel exchange)
-    const int b = fb - bm.fstart[l];
-    const int Smax = bm.slices[l];
-    const int r = (block % WG_PER_BUCKET) * 256 + threadIdx.x;
-    const int hsize = meta.offsets[l + 1] - meta.offsets[l];
-    const int row0 = b << BK_SHIFT;
-    const bool in_range = row0 + r < hsize;
-    const int64_t R = (int64_t)meta.offsets[l] + row0 + (in_range ? r : 0);
-    // everything that does not depend on the slice count is requested together with it (the pass is a chain of dependent
-    // round trips: record count -> partial tiles -> parameters; the first and the last now travel together)
-    const int n = bucket_n[bm.bstart[l] + b];   // written by the bucket's slice 0 in pass 2
-    const unsigned int gbits = gmax[l * CUR_STRIDE];
-    float2 P = make_float2(0.f, 0.f), Mv = P, V = P;
-    const bool adam = FUSE && !fu.grad_out;
-    if (adam) {
-        P = reinterpret_cast<float2 *>(fu.p)[R]; Mv = reinterpret_cast<float2 *>(fu.m)[R];
-        V = reinterpret_cast<float2 *>(fu.v)[R];
-    }
-    const int S = active_slices(n, Smax);
-    if (S <= 1) return;  // the bucket was finished by its single pass-2 workgroup
-    if (!in_range) return;
-    const long long *pt = partials + ((int64_t)bm.pstart[l] + (int64_t)b * Smax) * (BK_ROWS * 2);
-    long long q0 = 0ll, q1 = 0ll;
-    int s = 0;
-    for (; s + 4 <= S; s += 4) {   // eight loads in flight per lane: the slice count is dynamic, an un-unrolled loop pays
-                                   // one memory round trip per slice (integer sums: the order is free)
-        long long a[4], b4[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            a[k] = pt[(int64_t)(s + k) * (BK_ROWS * 2) + r];
-            b4[k] = pt[(int64_t)(s + k) * (BK_ROWS * 2) + BK_ROWS + r];
-        }
-        q0 += (a[0] + a[1]) + (a[2] + a[3]);
-        q1 += (b4[0] + b4[1]) + (b4[2] + b4[3]);
-    }
-    for (; s < S; ++s) {
-        q0 += pt[(int64_t)s * (BK_ROWS * 2) + r];
-        q1 += pt[(int64_t)s * (BK_ROWS * 2) + BK_ROWS + r];
-    }
-    const FixScale fs = fix_scale<FB>(gbits);
-    const float g0 = ((float)q0 * fs.un_a) * fs.un_b, g1 = ((float)q1 * fs.un_a) * fs.un_b;
-    float2 *d2 = reinterpret_cast<float2 *>(dtable) + R;
-    if (FUSE) {
-        if (fu.grad_out) {
-            reinterpret_cast<uint32_t *>(fu.grad_out)[R] = (uint32_t)f32_to_bf16(g0) | ((uint32_t)f32_to_bf16(g1) << 16);
-            return;
-        }
-        AdamArgs a = fu.a;
-        adam_bias(a);
-        a.zero_grad = 0;
-        float ga = g0, gb = g1;
-        adam_one(P.x, ga, Mv.x, V.x, a);
-        adam_one(P.y, gb, Mv.y, V.y, a);
-        reinterpret_cast<float2 *>(fu.p)[R] = P;
-        reinterpret_cast<float2 *>(fu.m)[R] = Mv;
-        reinterpret_cast<float2 *>(fu.v)[R] = V;
-        if (fu.shadow) reinterpret_cast<uint32_t *>(fu.shadow)[R] = (uint32_t)f32_to_bf16(P.x) | ((uint32_t)f32_to_bf16(P.y) << 16);
-    } else {
-        float2 d = *d2;
-        d.x += g0;
-        d.y += g1;
-        *d2 = d;
-    }
-}
-
-template <bool FUSE, int FB>
+// the slab blocks + the closing arrival as a launch of their own (lnerf_step_tail)
 __global__ void __launch_bounds__(256)
-k_scatter_finish(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ bucket_n, const unsigned int *__restrict__ gmax,
-                 const long long *__restrict__ partials, float *__restrict__ dtable, FusedUpdate fu, int lv_lo, int lv_hi) {
-    scatter_finish_block<FUSE, FB>((int)blockIdx.x, meta, bm, bucket_n, gmax, partials, dtable, fu, lv_lo, lv_hi);
-}
-
-// ---- the step's TAIL: everything that is left behind pass 2 of a single-GPU step, in ONE launch.  In a replayed graph a
-// dependent dispatch costs ~4.5 us whatever it computes, and three of them sat here for a few microseconds of work:
-// the finishing pass of the sliced buckets, the sum of the MLP's gradient slabs, the Adam step of the small parameters.
-//   blocks [0, n_finish)      scatter_finish_block: sliced buckets of the table (fused Adam step of their rows)
-//   blocks [n_finish, ...)    16 parameters of the MLP each: sum their column of the gradient slabs in a fixed order
-//                             (k_mlp_reduce_slabs' arithmetic: deterministic) and apply the Adam step straight from the
-//                             sum -- the weight gradients never exist in memory; updated weights are mirrored into the
-//                             bf16 weight fragments (lnerf_mlp_fragment_maps)
-//   last block to arrive      advances the device step counter and leaves the scatter's level maxima zero for the next
-//                             step (every other block has read both by then: the reads are waited for before a block's
-//                             arrival, the arrival is a device-scope atomic)
-struct SlabAdam {
-    const float *slabs;
-    int n_slabs, out_dim;
-    float *p[6], *m[6], *v[6];        // w1, b1, w2, b2, w3, b3
-    const int32_t *map[3];            // optional: fragment positions of w1, w2, w3 (two per weight)
-    uint16_t *shadow;                 // the bf16 fragment image the maps point into
-    float lr;
-};
-constexpr int TAIL_P = 16, TAIL_G = 16;   // parameters per block, slab groups (as k_mlp_reduce_slabs)
-
-constexpr int TAIL_SLABS_PER_LANE = MLP_BWD_MAX_BLOCKS / TAIL_G;   // 32: every slab load of a lane in flight at once
-constexpr int TAIL_SHARDS = 8;                                     // arrival counters (one 128-byte line each)
-
-template <int FB>
-__global__ void __launch_bounds__(256)
-k_step_tail(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ bucket_n, unsigned int *__restrict__ gmax,
-            const long long *__restrict__ partials, float *__restrict__ dtable, FusedUpdate fu, int n_finish,
-            SlabAdam sa, int32_t *__restrict__ tick, int32_t *__restrict__ arrive, int do_tick, int clear_gmax) {
-    // The launch is a handful of dependent round trips per block, so every load that depends on nothing is requested
-    // FIRST and together: the step counter (ONE device-scope atomic load per wave: the last block to arrive rewrites it,
-    // see k_adam_multi in optim.hip), a slab block's 32 slab values + its parameter, moments and fragment positions.
-    AdamArgs a = fu.a;
+k_step_tail(unsigned int *__restrict__ gmax, AdamArgs a, SlabAdam sa, int32_t *__restrict__ tick,
+            int32_t *__restrict__ arrive, int do_tick, int clear_gmax) {
     int32_t step_now = 0;
     if (a.step_dev) step_now = __hip_atomic_load(a.step_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool is_finish = (int)blockIdx.x < n_finish;
     __shared__ float part[TAIL_G][TAIL_P];
-    const int pi = threadIdx.x & (TAIL_P - 1), sg = threadIdx.x / TAIL_P;
-    const int p = ((int)blockIdx.x - n_finish) * TAIL_P + pi;
-    int k = -1, i = 0;   // slab column -> (tensor, element)
-    float vsl[TAIL_SLABS_PER_LANE];
-    float Pw = 0.f, Mw = 0.f, Vw = 0.f;
-    int2 at = make_int2(-1, -1);
-    if (!is_finish && sa.slabs) {
-        if (p < MLP_SLAB) {
-            if (p < MLP_SL_B1) { k = 0; i = p - MLP_SL_W1; }
-            else if (p < MLP_SL_W2) { k = 1; i = p - MLP_SL_B1; }
-            else if (p < MLP_SL_B2) { k = 2; i = p - MLP_SL_W2; }
-            else if (p < MLP_SL_W3) { k = 3; i = p - MLP_SL_B2; }
-            else if (p < MLP_SL_B3) { if ((p - MLP_SL_W3) / MLP_HID < sa.out_dim) { k = 4; i = p - MLP_SL_W3; } }
-            else { if (p - MLP_SL_B3 < sa.out_dim) { k = 5; i = p - MLP_SL_B3; } }
-#pragma unroll
-            for (int j = 0; j < TAIL_SLABS_PER_LANE; ++j) {
-                const int bsl = sg + TAIL_G * j;
-                vsl[j] = bsl < sa.n_slabs ? sa.slabs[(int64_t)bsl * MLP_SLAB + p] : 0.f;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < TAIL_SLABS_PER_LANE; ++j) vsl[j] = 0.f;
-        }
-        if (sg == 0 && k >= 0) {
-            Pw = sa.p[k][i]; Mw = sa.m[k][i]; Vw = sa.v[k][i];
-            if (sa.shadow && !(k & 1)) at = reinterpret_cast<const int2 *>(sa.map[k >> 1])[i];
-        }
-    }
-    if (a.step_dev) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the counter has been READ: see the arrival below)
-        adam_bias_at(a, step_now);
-        a.step_dev = nullptr;   // (the bias corrections are final: nothing below re-reads the counter)
-    } else {
-        adam_bias(a);
-    }
-    a.zero_grad = 0;
-    if (is_finish) {
-        FusedUpdate f2 = fu;
-        f2.a = a;
-        scatter_finish_block<true, FB>((int)blockIdx.x, meta, bm, bucket_n, gmax, partials, dtable, f2, 0,
-                                       meta.num_levels);
-        // this block's read of the level maxima has returned before it arrives (the last arrival clears them)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else if (sa.slabs) {
-        float sum = 0.f;
-#pragma unroll
-        for (int j = 0; j < TAIL_SLABS_PER_LANE; ++j) sum += vsl[j];   // (k_mlp_reduce_slabs' order: slabs sg, sg + 16, ...)
-        part[sg][pi] = sum;
-        __syncthreads();
-        if (sg == 0 && k >= 0) {
-            sum = part[0][pi];
-#pragma unroll
-            for (int g = 1; g < TAIL_G; ++g) sum += part[g][pi];
-            AdamArgs am = a;
-            am.lr = sa.lr;
-            adam_one(Pw, sum, Mw, Vw, am);
-            sa.p[k][i] = Pw; sa.m[k][i] = Mw; sa.v[k][i] = Vw;
-            const uint16_t h = f32_to_bf16(Pw);   // weights (k = 0, 2, 4) are mirrored into their two fragment positions
-            if (at.x >= 0) sa.shadow[at.x] = h;
-            if (at.y >= 0) sa.shadow[at.y] = h;
-        }
-    }
+    if (sa.slabs) slab_block<TAIL_SLABS_PER_LANE>((int)blockIdx.x, (int)threadIdx.x, sa, a, step_now, part, [] { __syncthreads(); });
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (do_tick || clear_gmax) {
-        // arrival, two levels: 8 shard counters (a line each: ~600 arrivals on ONE word queue for 7 us at the memory
-        // side), the block that completes a shard arrives at the root, the block that completes the root is the last
         __syncthreads();
-        if (threadIdx.x == 0) {
-            const int total = (int)gridDim.x, sh = (int)blockIdx.x & (TAIL_SHARDS - 1);
-            const int mine = (total - sh + TAIL_SHARDS - 1) / TAIL_SHARDS;   // blocks of this shard
-            int32_t *cnt = arrive + (1 + sh) * CUR_STRIDE;
-            if (__hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine - 1) {
-                __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int shards = total < TAIL_SHARDS ? total : TAIL_SHARDS;
-                if (__hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1) {
-                    __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (do_tick) __hip_atomic_store(&tick[0], step_now + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (clear_gmax)
-                        for (int l = 0; l < LNERF_MAX_LEVELS; ++l)
-                            __hip_atomic_store(&gmax[l * CUR_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
+        if (threadIdx.x == 0) tail_arrive(arrive, (int)gridDim.x, (int)blockIdx.x, tick, step_now, gmax, do_tick, clear_gmax);
     }
 }
 
@@ -1527,6 +1517,8 @@ static int g_reduce_threads = 1024;
 static int g_scatter_groups = 1;
 
 // workspace: [header: level maxima | item count | record count per bucket] [segment table] [record chunks] [partial tiles]
+static_assert(BK_MAX_PER_LEVEL == 256 && HDR_BUCKETN_OFF <= LNERF_SCATTER_ZERO_HEAD_BYTES,
+              "the counters of the header must lie inside the head a caller zeroes");
 static size_t header_bytes(int n_buckets) {
     return (HDR_BUCKETN_OFF + (size_t)n_buckets * sizeof(int32_t) + 4095) / 4096 * 4096;
 }
@@ -1788,12 +1780,12 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
                             int level_dim, const int32_t *offsets_host, const float *scales_host,
                             const int32_t *res_host, int64_t m_host, const int32_t *m_dev, int64_t level_stride,
                             float *dtable, int variant, void *workspace, size_t workspace_bytes,
-                            lnerf_stream_t stream, FusedUpdate *fu, int phases = 3, int lv_lo = 0, int lv_hi = -1) {
+                            lnerf_stream_t stream, FusedUpdate *fu, int phases = 3, int lv_lo = 0, int lv_hi = -1,
+                            const TailJob *tail = nullptr) {
     // LNERF_SCATTER_CLEARED: the caller zeroed the head of the workspace (lnerf_grid_scatter_clear_bytes()) with
     // something it was launching anyway -- the fill dispatch of this call is skipped
     const bool cleared = (variant & LNERF_SCATTER_CLEARED) != 0;
-    // LNERF_SCATTER_DEFER_FINISH: the finishing pass of the sliced buckets is left to lnerf_step_tail
-    const bool defer_finish = (variant & LNERF_SCATTER_DEFER_FINISH) != 0;
+    // (LNERF_SCATTER_DEFER_FINISH: accepted, without effect -- pass 2 finishes the sliced buckets itself)
     const int blocked = variant & LNERF_GRID_BLOCKED;
     variant &= ~(LNERF_SCATTER_CLEARED | LNERF_SCATTER_DEFER_FINISH | LNERF_GRID_BLOCKED);
     GridMeta meta;
@@ -1832,6 +1824,7 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
     char *wsb = (char *)workspace;
     unsigned int *gmax = (unsigned int *)wsb;
     int32_t *items_dev = (int32_t *)(wsb + HDR_ITEMS_OFF);
+    int32_t *slice_arrive = (int32_t *)(wsb + HDR_SLICE_ARRIVE_OFF);
     int32_t *bucket_n = (int32_t *)(wsb + HDR_BUCKETN_OFF);
     uint32_t *segtab = (uint32_t *)(wsb + plan.header_bytes);
     void *rec = wsb + plan.header_bytes + plan.seg_bytes;
@@ -1860,12 +1853,23 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
     FusedUpdate fu0;
     memset(&fu0, 0, sizeof(fu0));
     if (fu) fu0 = *fu;
+    TailJob tj0;
+    memset(&tj0, 0, sizeof(tj0));
+    if (tail) {
+        LNERF_REQUIRE(fu && !fu->grad_out && phases == 3 && lv_lo == 0 && lv_hi == num_levels && g_scatter_groups <= 1,
+                      "grid_encode_backward: the closing form needs the fused whole-table call");
+        tj0 = *tail;
+        tj0.arrive = (int32_t *)(wsb + HDR_ARRIVE_OFF);
+        tj0.blocks = tj0.sa.slabs ? (int)div_up(div_up(MLP_SLAB, TAIL_P), 4) : 0;   // four slab blocks per workgroup
+    }
     auto launch_reduce = [&](hipStream_t st, int l0, int l1) {
         const int w0 = bm.wgstart[l0], w1 = bm.wgstart[l1];
-        if (w1 <= w0) return;
+        if (w1 <= w0 && tj0.blocks == 0) return;
 #define LAUNCH_RED(T, REC, FUSE)                                                                                  \
-    hipLaunchKernelGGL((k_scatter_reduce<T, REC, FUSE>), dim3((unsigned)(w1 - w0)), dim3(T), 0, st, meta, bm, items_dev, \
-                       segtab, bucket_n, gmax, (const REC *)rec, dtable, partials, w0, fu0)
+    hipLaunchKernelGGL((k_scatter_reduce<T, REC, FUSE>), dim3((unsigned)(w1 - w0 + (FUSE ? tj0.blocks : 0))), dim3(T), 0,  \
+                       st, meta, bm, items_dev, segtab, bucket_n, slice_arrive, gmax, (const REC *)rec, dtable, partials, \
+                       w0, fu0, tj0)
+        // (the fused pass with 512-thread workgroups: 118 us against 108, profiles/r03_exp_scatter.jsonl)
         if (fu && packed) LAUNCH_RED(1024, Rec8, true);
         else if (fu) LAUNCH_RED(1024, Rec12, true);
         else if (packed && g_reduce_threads == 512) LAUNCH_RED(512, Rec8, false);
@@ -1873,18 +1877,6 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
         else if (g_reduce_threads == 512) LAUNCH_RED(512, Rec12, false);
         else LAUNCH_RED(1024, Rec12, false);
 #undef LAUNCH_RED
-    };
-    auto launch_finish = [&]() {  // sliced levels: add up the slices' exact partial sums
-        if (plan.fbuckets == 0) return;
-        const dim3 g((unsigned)(plan.fbuckets * (BK_ROWS / 256)));
-#define LAUNCH_FIN(FUSE, FB)                                                                                        \
-    hipLaunchKernelGGL((k_scatter_finish<FUSE, FB>), g, dim3(256), 0, s, meta, bm, bucket_n, gmax, partials, dtable, fu0, \
-                       lv_lo, lv_hi)
-        if (fu && packed) LAUNCH_FIN(true, 30);
-        else if (fu) LAUNCH_FIN(true, 44);
-        else if (packed) LAUNCH_FIN(false, 30);
-        else LAUNCH_FIN(false, 44);
-#undef LAUNCH_FIN
     };
     if (phases == 3 && g_scatter_groups > 1 && lv_lo == 0 && lv_hi == num_levels) {
         // level GROUPS: bin(group) -> reduce(group) -> bin(next group) ...  A group's records (1/groups of the 216 MB a
@@ -1899,10 +1891,6 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
             launch_reduce(s, l0, l1);
             LNERF_CHECK_LAUNCH("grid_encode_backward(reduce)");
         }
-        bool any_sliced = false;
-        for (int l = 0; l < num_levels; ++l) any_sliced = any_sliced || bm.slices[l] > 1;
-        if (any_sliced && !defer_finish) launch_finish();
-        LNERF_CHECK_LAUNCH("grid_encode_backward(finish)");
         return LNERF_OK;
     }
     if (phases & 1) {
@@ -1912,10 +1900,6 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
     if (phases & 2) {
         launch_reduce(s, lv_lo, lv_hi);
         LNERF_CHECK_LAUNCH("grid_encode_backward(reduce)");
-        bool any_sliced = false;
-        for (int l = lv_lo; l < lv_hi; ++l) any_sliced = any_sliced || bm.slices[l] > 1;
-        if (any_sliced && !defer_finish) launch_finish();
-        LNERF_CHECK_LAUNCH("grid_encode_backward(finish)");
     }
     return LNERF_OK;
 }
@@ -1993,6 +1977,74 @@ int lnerf_grid_encode_backward_adam(const float *xyzs, float bound, const void *
                             m_host, m_dev, level_stride, dtable_zero, variant, workspace, workspace_bytes, stream, &fu);
 }
 
+// the MLP half of a step tail: argument checks + the kernel-side descriptor
+static int fill_slab_adam(const char *who, SlabAdam &sa, const void *mlp_workspace, size_t mlp_workspace_bytes,
+                          int mlp_precision, int out_dim, int64_t m_host, float *const *params_host,
+                          float *const *exp_avg_host, float *const *exp_avg_sq_host, float mlp_lr,
+                          const int32_t *const *maps_host) {
+    memset(&sa, 0, sizeof(sa));
+    LNERF_REQUIRE(out_dim >= 2 && out_dim <= 8, "%s: out_dim must be in [2,8]", who);
+    LNERF_REQUIRE(mlp_precision == LNERF_F32 || mlp_precision == LNERF_BF16, "%s: bad precision tag", who);
+    LNERF_REQUIRE(mlp_workspace && mlp_workspace_bytes >= lnerf_mlp_backward_workspace_bytes(out_dim),
+                  "%s: MLP workspace too small", who);
+    LNERF_REQUIRE(params_host && exp_avg_host && exp_avg_sq_host && m_host > 0, "%s: null MLP state", who);
+    for (int k = 0; k < 6; ++k) {
+        LNERF_REQUIRE(params_host[k] && exp_avg_host[k] && exp_avg_sq_host[k], "%s: null MLP tensor %d", who, k);
+        sa.p[k] = params_host[k]; sa.m[k] = exp_avg_host[k]; sa.v[k] = exp_avg_sq_host[k];
+    }
+    if (maps_host) {
+        for (int k = 0; k < 3; ++k) {
+            LNERF_REQUIRE(maps_host[k] && ((uintptr_t)maps_host[k] & 7) == 0, "%s: bad fragment map %d", who, k);
+            sa.map[k] = maps_host[k];
+        }
+        sa.shadow = (uint16_t *)const_cast<void *>(mlp_workspace);   // the fragment image heads the workspace
+    }
+    sa.slabs = reinterpret_cast<const float *>(static_cast<const char *>(mlp_workspace) + MLP_FRAG_BYTES);
+    sa.n_slabs = lnerf_mlp_backward_slabs(m_host, mlp_precision);
+    sa.out_dim = out_dim;
+    sa.lr = mlp_lr;
+    return LNERF_OK;
+}
+
+int lnerf_grid_encode_backward_adam_tail(const float *xyzs, float bound, const void *dfeat, int dfeat_dtype, int num_levels,
+                                         int level_dim, const int32_t *offsets_host, const float *scales_host,
+                                         const int32_t *res_host, int64_t m_host, const int32_t *m_dev,
+                                         int64_t level_stride, float *dtable_zero, int variant, void *workspace,
+                                         size_t workspace_bytes, float *table, float *exp_avg, float *exp_avg_sq,
+                                         void *shadow_bf16, float lr, const void *mlp_workspace,
+                                         size_t mlp_workspace_bytes, int mlp_precision, int out_dim,
+                                         float *const *params_host, float *const *exp_avg_host,
+                                         float *const *exp_avg_sq_host, float mlp_lr, const int32_t *const *maps_host,
+                                         float beta1, float beta2, float eps, int step, int32_t *step_dev, float grad_scale,
+                                         int flags, lnerf_stream_t stream) {
+    LNERF_REQUIRE(table && exp_avg && exp_avg_sq, "grid_encode_backward_adam_tail: null optimiser state");
+    LNERF_REQUIRE(step_dev, "grid_encode_backward_adam_tail: needs the device counter pair (int32[2])");
+    LNERF_REQUIRE(m_host > 0, "grid_encode_backward_adam_tail: needs m_host > 0 (use lnerf_step_tail for an empty frame)");
+    LNERF_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f,
+                  "grid_encode_backward_adam_tail: betas must be in [0,1)");
+    LNERF_REQUIRE((((uintptr_t)table | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)dtable_zero) & 15) == 0,
+                  "grid_encode_backward_adam_tail: buffers must be 16-byte aligned");
+    LNERF_REQUIRE(!shadow_bf16 || ((uintptr_t)shadow_bf16 & 7) == 0,
+                  "grid_encode_backward_adam_tail: shadow must be 8-byte aligned");
+    FusedUpdate fu;
+    fu.p = table; fu.m = exp_avg; fu.v = exp_avg_sq; fu.shadow = (uint16_t *)shadow_bf16;
+    fu.grad_out = nullptr;
+    adam_host_args(fu.a, lr, beta1, beta2, eps, step, step_dev, grad_scale, 0);
+    TailJob tj;
+    memset(&tj, 0, sizeof(tj));
+    if (mlp_workspace) {
+        int rc = fill_slab_adam("grid_encode_backward_adam_tail", tj.sa, mlp_workspace, mlp_workspace_bytes, mlp_precision,
+                                out_dim, m_host, params_host, exp_avg_host, exp_avg_sq_host, mlp_lr, maps_host);
+        if (rc) return rc;
+    }
+    tj.tick = step_dev;
+    tj.do_tick = (flags & LNERF_TAIL_TICK) ? 1 : 0;
+    tj.clear_gmax = (flags & LNERF_TAIL_CLEAR_SCATTER) ? 1 : 0;
+    return scatter_backward(xyzs, bound, dfeat, dfeat_dtype, num_levels, level_dim, offsets_host, scales_host, res_host,
+                            m_host, m_dev, level_stride, dtable_zero, variant, workspace, workspace_bytes, stream, &fu, 3, 0,
+                            -1, &tj);
+}
+
 int lnerf_step_tail(int num_levels, int level_dim, const int32_t *offsets_host, const float *scales_host,
                     const int32_t *res_host, int64_t m_host, int variant, void *scatter_workspace,
                     size_t scatter_workspace_bytes, float *dtable_zero, float *table, float *exp_avg, float *exp_avg_sq,
@@ -2018,7 +2070,6 @@ int lnerf_step_tail(int num_levels, int level_dim, const int32_t *offsets_host, 
     unsigned int *gmax = nullptr;
     int32_t *bucket_n = nullptr, *arrive = nullptr;
     long long *partials = nullptr;
-    int n_finish = 0;
     const bool packed = (variant & 0xFF) == 3;
     if (with_scatter) {
         int rc = fill_meta("step_tail", meta, num_levels, level_dim, offsets_host, scales_host, res_host);
@@ -2035,7 +2086,6 @@ int lnerf_step_tail(int num_levels, int level_dim, const int32_t *offsets_host, 
         arrive = (int32_t *)(wsb + HDR_ARRIVE_OFF);
         partials = (long long *)(wsb + plan.header_bytes + plan.seg_bytes + plan.rec_bytes);
         fu.p = table; fu.m = exp_avg; fu.v = exp_avg_sq; fu.shadow = (uint16_t *)shadow_bf16;
-        n_finish = plan.fbuckets * (BK_ROWS / 256);
     }
     LNERF_REQUIRE(!(flags & (LNERF_TAIL_CLEAR_SCATTER | LNERF_TAIL_TICK)) || with_scatter,
                   "step_tail: the tick / the clearing epilogue keep their arrival counters in the scatter workspace");
@@ -2043,37 +2093,16 @@ int lnerf_step_tail(int num_levels, int level_dim, const int32_t *offsets_host, 
     memset(&sa, 0, sizeof(sa));
     int n_slab_blocks = 0;
     if (with_mlp) {
-        LNERF_REQUIRE(out_dim >= 2 && out_dim <= 8, "step_tail: out_dim must be in [2,8]");
-        LNERF_REQUIRE(mlp_precision == LNERF_F32 || mlp_precision == LNERF_BF16, "step_tail: bad precision tag");
-        LNERF_REQUIRE(mlp_workspace_bytes >= lnerf_mlp_backward_workspace_bytes(out_dim), "step_tail: MLP workspace too small");
-        LNERF_REQUIRE(params_host && exp_avg_host && exp_avg_sq_host && m_host > 0, "step_tail: null MLP state");
-        for (int k = 0; k < 6; ++k) {
-            LNERF_REQUIRE(params_host[k] && exp_avg_host[k] && exp_avg_sq_host[k], "step_tail: null MLP tensor %d", k);
-            sa.p[k] = params_host[k]; sa.m[k] = exp_avg_host[k]; sa.v[k] = exp_avg_sq_host[k];
-        }
-        if (maps_host) {
-            for (int k = 0; k < 3; ++k) {
-                LNERF_REQUIRE(maps_host[k] && ((uintptr_t)maps_host[k] & 7) == 0, "step_tail: bad fragment map %d", k);
-                sa.map[k] = maps_host[k];
-            }
-            sa.shadow = (uint16_t *)const_cast<void *>(mlp_workspace);   // the fragment image heads the workspace
-        }
-        sa.slabs = reinterpret_cast<const float *>(static_cast<const char *>(mlp_workspace) + MLP_FRAG_BYTES);
-        sa.n_slabs = lnerf_mlp_backward_slabs(m_host, mlp_precision);
-        sa.out_dim = out_dim;
-        sa.lr = mlp_lr;
+        int rc = fill_slab_adam("step_tail", sa, mlp_workspace, mlp_workspace_bytes, mlp_precision, out_dim, m_host,
+                                params_host, exp_avg_host, exp_avg_sq_host, mlp_lr, maps_host);
+        if (rc) return rc;
         n_slab_blocks = (int)div_up(MLP_SLAB, TAIL_P);
     }
-    const dim3 g((unsigned)(n_finish + n_slab_blocks));
+    const dim3 g((unsigned)n_slab_blocks);
     if (g.x == 0) return LNERF_OK;
     hipStream_t s = as_stream(stream);
     const int do_tick = (flags & LNERF_TAIL_TICK) ? 1 : 0, clr = (flags & LNERF_TAIL_CLEAR_SCATTER) ? 1 : 0;
-    if (packed)
-        hipLaunchKernelGGL((k_step_tail<30>), g, dim3(256), 0, s, meta, bm, bucket_n, gmax, partials, dtable_zero, fu,
-                           n_finish, sa, step_dev, arrive, do_tick, clr);
-    else
-        hipLaunchKernelGGL((k_step_tail<44>), g, dim3(256), 0, s, meta, bm, bucket_n, gmax, partials, dtable_zero, fu,
-                           n_finish, sa, step_dev, arrive, do_tick, clr);
+    hipLaunchKernelGGL(k_step_tail, g, dim3(256), 0, s, gmax, fu.a, sa, step_dev, arrive, do_tick, clr);
     LNERF_CHECK_LAUNCH("step_tail");
     return LNERF_OK;
 }

@@ -84,7 +84,8 @@ def scatter_workspace(levels: GridLevels, m_host, device):
             return ws
     size = max(need, (3 * have[-1].numel()) // 2 if have else 0)
     ws = torch.empty(size, device=device, dtype=torch.uint8)
-    ws[:4096].zero_()      # header: the level maxima start out clean
+    # header: level maxima and arrival counters start out clean (LNERF_SCATTER_ZERO_HEAD_BYTES; the calls keep them so)
+    ws[:min(size, _b.SCATTER_ZERO_HEAD_BYTES)].zero_()
     have.append(ws)
     return ws
 
@@ -137,6 +138,10 @@ class FusedTableUpdate:
         self.tail = False
         self.pending_tail = None            # (levels, m_host, variant, scatter workspace, mlp workspace, precision, out_dim)
         self.clean_ws = None                # data_ptr of the scatter workspace whose level maxima are known to be zero
+        # the armed backward closed the step itself (grid_encode_backward_adam_tail): slab sums, the MLP's Adam step, the
+        # tick of the step counter all ran inside the scatter's pass 2
+        self.closed = False
+        self.inline_tail = False            # set by FusedAdam: the tail may run inside the scatter (no other small parameter)
 
     def take(self):
         """True once per arm(): the caller (a backward pass) then owes the fused update."""
@@ -163,6 +168,29 @@ def grid_encode_backward_adam(xyzs, bound, dfeat, encoder, m_host, m_dev, level_
             _p(wst), wst.numel(), _p(table), _p(fu.exp_avg), _p(fu.exp_avg_sq), _p(shadow), fu.lr, b1, b2, fu.eps,
             opt.step_no + 1, _p(opt.step_dev), float(opt.grad_scale), _stream())
     fu.applied += 1
+
+
+def grid_encode_backward_adam_tail(xyzs, bound, dfeat, encoder, m_host, m_dev, level_stride, variant, mlp_ws, precision,
+                                   out_dim):
+    """The armed scatter that also CLOSES the step (lnerf_grid_encode_backward_adam_tail): the workgroups of its pass 2
+    sum the MLP's gradient slabs, step the MLP's six tensors, advance the device step counter and leave the level maxima
+    zero for the next step -- no launch behind the scatter.  FusedAdam(tail=True) with no other small parameter."""
+    fu = encoder.fused_update
+    levels = encoder.levels
+    opt = fu.optimizer
+    t = opt.tail_args()
+    wst = scatter_workspace(levels, m_host, xyzs.device)
+    b1, b2 = fu.betas
+    _b.call("lnerf_grid_encode_backward_adam_tail", _chk(xyzs, "xyzs"), float(bound), _chk(dfeat, "dfeat"), _b.F32,
+            levels.num_levels, levels.level_dim, levels.c_offsets, levels.c_scales, levels.c_res, int(m_host),
+            _chk(m_dev, "m_dev", torch.int32, allow_none=True), int(level_stride), _p(fu.zero), int(variant) | levels.flag,
+            _p(wst), wst.numel(), _p(encoder.embeddings.data), _p(fu.exp_avg), _p(fu.exp_avg_sq), _p(encoder.shadow()),
+            fu.lr, _p(mlp_ws), mlp_ws.numel(), int(precision), int(out_dim), t["p"], t["m"], t["v"], float(t["lr"]),
+            t["maps"], b1, b2, fu.eps, opt.step_no + 1, _p(opt.step_dev), float(opt.grad_scale),
+            _b.TAIL_TICK | _b.TAIL_CLEAR_SCATTER, _stream())
+    fu.applied += 1
+    fu.closed = True                 # optimizer.step() has nothing left to launch
+    fu.clean_ws = wst.data_ptr()     # (level maxima zero again when the launch ends)
 
 
 class GradSink:

@@ -116,8 +116,9 @@ class _HashMLPField(torch.autograd.Function):
         fdt = _b.F32 if feat.dtype == torch.float32 else _b.BF16
         fu = encoder.fused_update
         sv = encoder.scatter_variant
-        # TAIL mode (FusedAdam(tail=True), armed, m_host > 0): the slab sum, the Adam step of the six MLP tensors and the
-        # scatter's finishing pass are left to ONE launch in optimizer.step() (lnerf_step_tail): no weight gradients here
+        # TAIL mode (FusedAdam(tail=True), armed, m_host > 0): the slab sum and the Adam step of the six MLP tensors are
+        # left to the scatter's own pass 2 (or, with other small parameters around, to ONE launch in optimizer.step():
+        # lnerf_step_tail): no weight gradients here
         tail = fu is not None and fu.armed and fu.tail and own_ws and sv >= 2 and m_host > 0
         if tail:
             wst = E.scatter_workspace(encoder.levels, m_host, dev)
@@ -126,10 +127,14 @@ class _HashMLPField(torch.autograd.Function):
                     _chk(dsigmas, "dsigmas"), _chk(drgbs, "drgbs"), _p(dfeat), None, None, None, None, None, None, 0,
                     _p(workspace), workspace.numel(), precision | _b.MLP_DEFER_REDUCE, None, 0, _stream())
             fu.take()
-            flags = _b.SCATTER_DEFER_FINISH | (_b.SCATTER_CLEARED if fu.clean_ws == wst.data_ptr() else 0)
+            flags = _b.SCATTER_CLEARED if fu.clean_ws == wst.data_ptr() else 0
             fu.clean_ws = None
-            E.grid_encode_backward_adam(xyzs, bound, dfeat, encoder, m_host, m_dev, level_stride, sv | flags)
-            fu.pending_tail = (encoder.levels, int(m_host), int(sv), wst, workspace, int(base_precision), int(out_dim))
+            if fu.inline_tail:   # the scatter's pass 2 closes the step: no launch behind it
+                E.grid_encode_backward_adam_tail(xyzs, bound, dfeat, encoder, m_host, m_dev, level_stride, sv | flags,
+                                                 workspace, base_precision, out_dim)
+            else:
+                E.grid_encode_backward_adam(xyzs, bound, dfeat, encoder, m_host, m_dev, level_stride, sv | flags)
+                fu.pending_tail = (encoder.levels, int(m_host), int(sv), wst, workspace, int(base_precision), int(out_dim))
             return (None,) * 19
         grads = [torch.empty_like(t) for t in (w1, b1, w2, b2, w3, b3)]  # overwritten (accumulate = 0)
         # the bucketed scatter that follows needs its level maxima cleared: the MLP's slab-reduction launch does it on the

@@ -15,6 +15,7 @@ HEADER_PATH = os.path.join(REPO_ROOT, "include", "lnerf_hip.h")
 LNERF_OK = 0
 F32, BF16 = 0, 1
 MLP_FRAGMENTS_READY = 0x100   # flag on lnerf_mlp_backward's precision tag (include/lnerf_hip.h)
+SCATTER_ZERO_HEAD_BYTES = 64 * 1024  # LNERF_SCATTER_ZERO_HEAD_BYTES: head of a fresh scatter workspace that must be zero
 MLP_FRAGMENT_BYTES = 36 * 1024  # LNERF_MLP_FRAGMENT_BYTES: the bf16 weight-fragment image at the head of the MLP workspace
 SCATTER_DEFER_FINISH = 0x200  # flag on the scatter's variant: lnerf_step_tail runs the finishing pass
 MLP_DEFER_REDUCE = 0x200      # flag on lnerf_mlp_backward's precision tag: lnerf_step_tail sums the slabs
@@ -39,7 +40,7 @@ _F = _c.c_float
 _Z = _c.c_size_t
 _U = _c.c_uint32
 
-ABI_VERSION = 4  # LNERF_ABI_VERSION of include/lnerf_hip.h this host side was written against
+ABI_VERSION = 5  # LNERF_ABI_VERSION of include/lnerf_hip.h this host side was written against
 
 # name -> argtypes (return type int unless listed in _RESTYPES)
 _SIGNATURES = {
@@ -102,6 +103,8 @@ _SIGNATURES = {
     "lnerf_mlp_fragment_maps": [_I, _P, _P, _P, _P],
     "lnerf_cast_f32_to_bf16": [_P, _P, _L, _P],
     "lnerf_mlp_backward_slabs": [_L, _I],
+    "lnerf_grid_encode_backward_adam_tail": [_P, _F, _P, _I, _I, _I, _P, _P, _P, _L, _P, _L, _P, _I, _P, _Z, _P, _P, _P, _P,
+                                             _F, _P, _Z, _I, _I, _P, _P, _P, _F, _P, _F, _F, _F, _I, _P, _F, _I, _P],
     "lnerf_step_tail": [_I, _I, _P, _P, _P, _L, _I, _P, _Z, _P, _P, _P, _P, _P, _F, _P, _Z, _I, _I, _P, _P, _P, _F, _P,
                         _F, _F, _F, _I, _P, _F, _I, _P],
 }

@@ -115,6 +115,10 @@ class FusedAdam:
                           "maps": None if self._map_tensors is None else
                           (ctypes.c_void_p * 3)(*[self._map_tensors[n].data_ptr() for n in ("w1", "w2", "w3")])}
             self.fused.tail = True
+            # no other small parameter and a device step counter: the armed scatter closes the step ITSELF (its pass 2 runs
+            # the slab sums, the MLP's Adam step and the tick: lnerf_grid_encode_backward_adam_tail); else the tail is the
+            # step's last launch (lnerf_step_tail, behind the ordinary Adam launch of the other small parameters)
+            self.fused.inline_tail = len(idx) == len(self.small) and self.step_dev is not None
 
     def arm(self):
         """Let the NEXT backward through the encoder apply the table's Adam step (no-op without fuse_table_update)."""
@@ -165,7 +169,9 @@ class FusedAdam:
                         None if shadow is None else _p(shadow[sl]), p.data[sl].numel(), lr, b1, b2, self.eps,
                         self.step_no, _p(self.step_dev), float(grad_scale), 0, _stream())
         pend = self.fused.pending_tail if self.fused is not None else None
-        if pend is not None:
+        if self.fused is not None and self.fused.closed:
+            self.fused.closed = False      # the armed backward closed the step: nothing left to launch
+        elif pend is not None:
             self._step_tail(pend, float(grad_scale))
         elif self.small:
             for k, (p, m, v, lr) in enumerate(self.small):
@@ -195,6 +201,13 @@ class FusedAdam:
         if set_to_none:
             for p, *_ in self.big + self.small:
                 p.grad = None
+
+    def tail_args(self):
+        """Host-side pointer arrays of the MLP's six tensors for the tail entry points (refreshed: `p.data` may move)."""
+        t = self._tail
+        for j, k in enumerate(t["idx"]):
+            t["p"][j] = self.small[k][0].data.data_ptr()
+        return t
 
     def _step_tail(self, pend, grad_scale):
         """The armed step's last launch (see __init__): lnerf_step_tail.  Small parameters outside the MLP (a background
