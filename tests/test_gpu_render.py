@@ -396,7 +396,8 @@ def _run_steps(dev, fuse, precision, log2_T, steps=3, tail=None, capturable=Fals
         frag = net.mlp_workspace(dev)[:30 * 1024].clone() if precision == "bf16" else None   # the 30 weight fragments (F_ALL)
         return {"table": emb.detach().clone(), "m": m.clone(), "v": v.clone(), "shadow": None if sh is None else sh.clone(),
                 "small": small, "frag": frag, "step_dev": None if opt.step_dev is None else opt.step_dev.clone(),
-                "frag_current": net.fragments_current(), "grad_w2": net.w2.grad}
+                "frag_current": net.fragments_current(), "grad_w2": net.w2.grad,
+                "inline_tail": bool(opt.fused is not None and opt.fused.inline_tail)}
     return (emb.detach().clone(), m.clone(), v.clone(), None if sh is None else sh.clone(), net.w2.detach().clone(),
             emb.grad)
 
@@ -407,8 +408,8 @@ def test_fused_table_update_is_bit_identical(dev, precision, log2_T):
     """lnerf_grid_encode_backward_adam (Adam step of the hash table applied by the kernel that finishes a row's sum)
     against backward + FusedAdam.step(): same table, moments and bf16 shadow, BIT FOR BIT, after three steps -- the
     scatter sums in fixed point (order-independent) and both paths share one Adam definition.  2^19 rows per level:
-    levels 5..15 are finished by the reduce pass, the sliced coarse levels by the finishing kernel; 2^14: every level
-    is sliced."""
+    levels 5..15 are finished by their only workgroup, the sliced coarse levels by the last slice to arrive; 2^14: every
+    level is sliced."""
     ref = _run_steps(dev, False, precision, log2_T)
     got = _run_steps(dev, True, precision, log2_T)
     assert got[5] is None            # the table never gets a .grad in fused mode
@@ -475,14 +476,17 @@ def test_full_size_bf16_step_with_fused_adam_matches_oracle(dev):
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision,log2_T,capturable", [("bf16", 19, True), ("bf16", 14, True), ("f32", 19, False)])
 def test_step_tail_is_bit_identical_to_the_separate_launches(dev, precision, log2_T, capturable):
-    """lnerf_step_tail -- ONE launch for the scatter's finishing pass, the sum of the MLP's gradient slabs + the Adam
-    step of its six tensors, the step-counter tick and the clearing of the scatter's level maxima -- against the
-    separate launches (slab sum inside the backward pass, finishing kernel, multi-tensor Adam): table, every MLP tensor,
-    every moment, the bf16 weight fragments and the device step counter agree BIT FOR BIT after four steps.  2^14 rows per
-    level: every level's buckets are sliced, so the tail's finishing blocks do the table's whole Adam step."""
+    """The step's tail -- the sum of the MLP's gradient slabs + the Adam step of its six tensors, the step-counter tick
+    and the clearing of the scatter's level maxima -- in both of its forms: inside the armed scatter's pass 2
+    (lnerf_grid_encode_backward_adam_tail, the capturable optimiser: no launch behind the scatter) and as one launch
+    of its own (lnerf_step_tail, the optimiser without a device step counter), against the separate launches (slab sum
+    inside the backward pass, multi-tensor Adam): table, every MLP tensor, every moment, the bf16 weight fragments and
+    the device step counter agree BIT FOR BIT after four steps.  2^14 rows per level: every level's buckets are sliced,
+    so the table's whole Adam step is done by the last slice of each bucket to arrive."""
     ref = _run_steps(dev, True, precision, log2_T, steps=4, tail=False, capturable=capturable, full=True)
     got = _run_steps(dev, True, precision, log2_T, steps=4, tail=True, capturable=capturable, full=True)
     assert got["grad_w2"] is None                      # tail mode: the weight gradients never exist
+    assert got["inline_tail"] == bool(capturable)      # with the device counter the scatter closes the step itself
     for k in ("table", "m", "v", "shadow", "frag", "step_dev"):
         a, b = got[k], ref[k]
         assert (a is None) == (b is None), k
