@@ -218,6 +218,11 @@ __device__ __forceinline__ void march_totals(const int32_t *__restrict__ cnt, in
     }
 }
 
+// chunks of 64 lattice points whose occupancy bytes one round of the uniform-step march requests together
+#ifndef LNERF_MARCH_CHUNKS
+#define LNERF_MARCH_CHUNKS 4
+#endif
+constexpr int MARCH_CHUNKS = LNERF_MARCH_CHUNKS;
 // One wavefront per ray.  Each iteration tests 64 consecutive lattice points of the ray;
 // ballot + popcount gives the count (pass 1) or, with mbcnt, each sample's slot (pass 2).
 template <bool WRITE, bool UNIFORM_DT>
@@ -335,17 +340,17 @@ k_march_train(const float *__restrict__ rays_o, const float *__restrict__ rays_d
             for (int i = 0; i < lane; ++i) t = t + clampf(t * P.dt_gamma, P.dt_min, P.dt_max);
         }
         if (UNIFORM_DT) {
-            // Closed-form lattice: FOUR chunks of 64 lattice points per round, their occupancy bytes requested together
-            // -- the pass is a chain of dependent L2 round trips (one per chunk, ~16 per ray), this makes it ~4.  Chunks
+            // Closed-form lattice: MARCH_CHUNKS chunks of 64 lattice points per round, their occupancy bytes requested together
+            // -- the pass is a chain of dependent L2 round trips (one per chunk, ~16 per ray), this makes it ~16 / MARCH_CHUNKS.  Chunks
             // past the ray's end read a clamped (valid) cell and are ignored; the decisions and their order are those
             // of the one-chunk loop below.
             const float dt = P.dt_min;
             bool done = false;
-            for (int base = 0; base < (1 << 22) && !done; base += 256) {  // bound: a non-finite `far` must not spin
-                float tj[4], xj[4], yj[4], zj[4];
-                bool vj[4], oj[4];
+            for (int base = 0; base < (1 << 22) && !done; base += 64 * MARCH_CHUNKS) {  // bound: a non-finite `far` must not spin
+                float tj[MARCH_CHUNKS], xj[MARCH_CHUNKS], yj[MARCH_CHUNKS], zj[MARCH_CHUNKS];
+                bool vj[MARCH_CHUNKS], oj[MARCH_CHUNKS];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < MARCH_CHUNKS; ++j) {
                     float tt = (float)(base + 64 * j + lane) * dt;
                     tt = tt + t0;
                     tj[j] = tt;
@@ -357,9 +362,9 @@ k_march_train(const float *__restrict__ rays_o, const float *__restrict__ rays_d
                     zj[j] = clampf(z, -P.bound, P.bound);
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) oj[j] = cell_occupied(xj[j], yj[j], zj[j], dt, P, bitfield);
+                for (int j = 0; j < MARCH_CHUNKS; ++j) oj[j] = cell_occupied(xj[j], yj[j], zj[j], dt, P, bitfield);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < MARCH_CHUNKS; ++j) {
                     if (done) break;
                     if (__ballot(vj[j]) == 0ull) { done = true; break; }  // lattice is monotone: nothing further is valid
                     const bool occ = vj[j] && oj[j];
