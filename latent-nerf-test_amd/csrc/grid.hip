@@ -394,7 +394,10 @@ k_grid_backward_atomic(const float *__restrict__ xyzs, float bound, const TG *__
 // Every record has a fixed place that depends on the input only, every sum is an exact integer sum: the
 // result is bitwise reproducible for ANY input (round 2's layout reserved spans with global atomics and fell back to
 // float atomics when a bucket's region overflowed).
-constexpr int BK_SHIFT = 12, BK_ROWS = 1 << BK_SHIFT;  // 4096 rows * 8 B = 32 KiB of accumulators
+#ifndef LNERF_BK_SHIFT
+#define LNERF_BK_SHIFT 12
+#endif
+constexpr int BK_SHIFT = LNERF_BK_SHIFT, BK_ROWS = 1 << BK_SHIFT;  // 4096 rows * 2 features * 8 B = 64 KiB of accumulators
 // threads (= samples) per binning tile: template parameter BIN_T of k_scatter_bin (256 or 512)
 constexpr int BK_MAX_PER_LEVEL = 256;                   // LDS counters per workgroup tile
 
@@ -449,7 +452,7 @@ struct alignas(8) Rec8 {
     __device__ __forceinline__ float a() const { return __uint_as_float((((lo >> 12) | (hi << 20)) & 0x3FFFFFFu) << 6); }
     __device__ __forceinline__ float b() const { return __uint_as_float((hi >> 6) << 6); }
 };
-static_assert(BK_SHIFT == 12, "Rec8 stores 12 row bits");
+static_assert(BK_SHIFT <= 12, "Rec8 stores 12 row bits");
 // "This record is needed HERE, by every lane": an empty asm that reads the registers.  A load whose result is only used
 // under a lane predicate is otherwise SUNK into the predicated block by the compiler -- one load, one s_waitcnt
 // vmcnt(0), one use at a time instead of a batch of loads in flight (measured on the reduce pass: 2-3x its time).
@@ -1458,8 +1461,11 @@ __device__ __forceinline__ void scatter_reduce_one(int wg, const GridMeta &meta,
 // One workgroup per (bucket, slice) unit.  (PERSISTENT workgroups striding over the units were built and measured: the
 // loop keeps the three kernel-argument structs live across iterations, 77 VGPRs spill at the 64 the two-workgroups-per-CU
 // occupancy allows, and the pass went from 0.211 to 0.27 ms per scatter call: profiles/r03_exp_scatter.jsonl.)
+#ifndef LNERF_FUSED_RT          // threads per workgroup of the fused pass (experiment knob: 512 with LNERF_BK_SHIFT = 11)
+#define LNERF_FUSED_RT 1024
+#endif
 template <int RT, typename REC, bool FUSE>
-__global__ void __launch_bounds__(RT, RT / 128)
+__global__ void __launch_bounds__(RT, (LNERF_BK_SHIFT < 12 && RT == 512) ? 8 : RT / 128)
 k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ items_dev, const uint32_t *__restrict__ segtab,
                  int32_t *__restrict__ bucket_n, int32_t *__restrict__ slice_arrive, unsigned int *__restrict__ gmax,
                  const REC *__restrict__ recs, float *__restrict__ dtable, long long *__restrict__ partials, int wg_lo,
@@ -1860,7 +1866,7 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
                       "grid_encode_backward: the closing form needs the fused whole-table call");
         tj0 = *tail;
         tj0.arrive = (int32_t *)(wsb + HDR_ARRIVE_OFF);
-        tj0.blocks = tj0.sa.slabs ? (int)div_up(div_up(MLP_SLAB, TAIL_P), 4) : 0;   // four slab blocks per workgroup
+        tj0.blocks = tj0.sa.slabs ? (int)div_up(div_up(MLP_SLAB, TAIL_P), LNERF_FUSED_RT / 256) : 0;   // four slab blocks per workgroup
     }
     auto launch_reduce = [&](hipStream_t st, int l0, int l1) {
         const int w0 = bm.wgstart[l0], w1 = bm.wgstart[l1];
@@ -1870,8 +1876,8 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
                        st, meta, bm, items_dev, segtab, bucket_n, slice_arrive, gmax, (const REC *)rec, dtable, partials, \
                        w0, fu0, tj0)
         // (the fused pass with 512-thread workgroups: 118 us against 108, profiles/r03_exp_scatter.jsonl)
-        if (fu && packed) LAUNCH_RED(1024, Rec8, true);
-        else if (fu) LAUNCH_RED(1024, Rec12, true);
+        if (fu && packed) LAUNCH_RED(LNERF_FUSED_RT, Rec8, true);
+        else if (fu) LAUNCH_RED(LNERF_FUSED_RT, Rec12, true);
         else if (packed && g_reduce_threads == 512) LAUNCH_RED(512, Rec8, false);
         else if (packed) LAUNCH_RED(1024, Rec8, false);
         else if (g_reduce_threads == 512) LAUNCH_RED(512, Rec12, false);
