@@ -519,6 +519,8 @@ __device__ unsigned long long g_bin_stamps[16];
         if (threadIdx.x == 0)                                                                     \
             for (int k__ = 0; k__ < 10; ++k__) atomicAdd(&g_bin_stamps[k__], stamp_acc__[k__]);   \
     } while (0)
+// per-workgroup log of pass 2: (entry, exit) on the constant 100 MHz clock + where it ran: 4 words per workgroup
+__device__ unsigned long long g_wg_log[4 * 4096];
 #define RED_STAMP(k) BIN_STAMP(k)
 #define RED_STAMP_INIT()                                                                          \
     unsigned long long stamp_acc__[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};        \
@@ -1065,6 +1067,7 @@ struct TailJob {
     int32_t *tick;         // device step counter pair
     int32_t *arrive;       // arrival counters (workspace header)
     int do_tick, clear_gmax;
+    int rev_lo, rev_hi;    // work units [rev_lo, rev_hi) are taken in DESCENDING order (0, 0: none)
 };
 
 // LNERF_REDUCE_NT (bit mask): non-temporal policy on the once-per-step streams of the reduce pass -- 1: parameter /
@@ -1377,12 +1380,25 @@ __device__ __forceinline__ void scatter_reduce_one(int wg, const GridMeta &meta,
         }
         __syncthreads();
         if (s_red[0] != S - 1) return;     // uniform: an earlier arrival, somebody else finishes the bucket
-        for (int i = tid; i < BK_ROWS * 2; i += RT) {
-            unsigned long long q = ul[i];
-            for (int s2 = 0; s2 < S; ++s2)   // (S <= 64; four tiles in flight per lane)
-                if (s2 != s) q += __hip_atomic_load(&tiles[(int64_t)s2 * (BK_ROWS * 2) + i], __ATOMIC_RELAXED,
-                                                    __HIP_MEMORY_SCOPE_AGENT);
-            acc[i] = (long long)q;
+        // (one tile at a time, ALL of the lane's elements of it in flight: element by element the sum was a chain of
+        // 8 (S - 1) dependent round trips -- 94 us for a six-slice bucket, the longest workgroup of the launch)
+        constexpr int NI = BK_ROWS * 2 / RT, NB = NI < 4 ? NI : 4;   // (four 64-bit loads in flight: no spill at 64 registers)
+        for (int k0 = 0; k0 < NI; k0 += NB) {
+            unsigned long long q[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) q[k] = ul[tid + (k0 + k) * RT];
+            for (int s2 = 0; s2 < S; ++s2) {
+                if (s2 == s) continue;     // uniform
+                const unsigned long long *ot = tiles + (int64_t)s2 * (BK_ROWS * 2) + tid + k0 * RT;
+                unsigned long long t[NB];
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+                    t[k] = __hip_atomic_load(&ot[k * RT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int k = 0; k < NB; ++k) q[k] += t[k];
+            }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) acc[tid + (k0 + k) * RT] = (long long)q[k];
         }
         __syncthreads();
     }
@@ -1472,13 +1488,33 @@ k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ items
                  FusedUpdate fu, TailJob tj) {
     // (closing the step: the counter is read ONCE per wave, with a device-scope atomic load, before anything else --
     // the last workgroup of the launch to arrive rewrites it)
+#ifdef LNERF_STAMPS
+    const unsigned long long wg_t0 = wall_clock64();
+#endif
     int32_t step_now = 0;
     const bool closing = FUSE && (tj.do_tick || tj.clear_gmax || tj.blocks > 0);
     // (requested here, consumed behind the workgroup's first barrier: no stall in front of the record stream)
     if (closing && fu.a.step_dev) step_now = __hip_atomic_load(fu.a.step_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int unit = (int)blockIdx.x - (FUSE ? tj.blocks : 0);
+    int unit = (int)blockIdx.x - (FUSE ? tj.blocks : 0);
+    // heaviest first: the un-merged fine levels carry the most records per bucket; taken in level order they ran LAST
+    // and the launch's tail was its heaviest workgroups (the sliced coarse levels keep their place at the front)
+    if (unit + wg_lo >= tj.rev_lo && unit + wg_lo < tj.rev_hi) unit = tj.rev_lo + (tj.rev_hi - 1 - (unit + wg_lo)) - wg_lo;
     scatter_reduce_one<RT, REC, FUSE>(unit < 0 ? unit : unit + wg_lo, meta, bm, items_dev, segtab, bucket_n, slice_arrive,
                                       gmax, recs, dtable, partials, fu, tj.sa, step_now, closing && fu.a.step_dev != nullptr);
+#ifdef LNERF_STAMPS
+    if (blockIdx.x < 4096) {   // (exit = the LAST wave's, with its stores acknowledged: the slot is free after that)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if ((threadIdx.x & 63) == 0) atomicMax(&g_wg_log[4 * blockIdx.x + 1], (unsigned long long)wall_clock64());
+        if (threadIdx.x == 0) {
+            unsigned int hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            g_wg_log[4 * blockIdx.x] = wg_t0;
+            g_wg_log[4 * blockIdx.x + 2] = ((unsigned long long)xcc << 32) | hw;
+            g_wg_log[4 * blockIdx.x + 3] = (unsigned long long)(unsigned int)unit;
+        }
+    }
+#endif
     if (closing && (tj.do_tick || tj.clear_gmax) && threadIdx.x == 0)
         // (this wave is done.  The workgroup's other waves requested the counter as their first instruction and the
         // level maximum in front of the record loop; a workgroup's barriers wait for a wave's outstanding loads, and
@@ -1745,6 +1781,13 @@ int lnerf_set_tuning(const char *key, int value) {
 
 #ifdef LNERF_STAMPS
 // diagnostic builds only: read (and clear) the per-phase shader-clock totals of the binning pass
+int lnerf_debug_wg_log(unsigned long long *out, int words) {   // reads AND clears the log
+    static unsigned long long zero[4 * 4096];
+    if (words > 4 * 4096) words = 4 * 4096;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_log), (size_t)words * 8) != hipSuccess) return LNERF_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_wg_log), zero, sizeof(zero)) != hipSuccess) return LNERF_ERR_HIP;
+    return LNERF_OK;
+}
 int lnerf_debug_bin_stamps(unsigned long long *out16) {
     unsigned long long z[16] = {0};
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_bin_stamps), sizeof(z)) != hipSuccess) return LNERF_ERR_HIP;
@@ -1868,8 +1911,18 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
         tj0.arrive = (int32_t *)(wsb + HDR_ARRIVE_OFF);
         tj0.blocks = tj0.sa.slabs ? (int)div_up(div_up(MLP_SLAB, TAIL_P), LNERF_FUSED_RT / 256) : 0;   // four slab blocks per workgroup
     }
+#ifndef LNERF_REDUCE_ORDER
+#define LNERF_REDUCE_ORDER 1
+#endif
+    if (LNERF_REDUCE_ORDER) {   // whole-table launches only (a level-range launch keeps the plain order)
+        int lf = 0;
+        for (int l = 0; l < num_levels; ++l) if (bm.slices[l] > 1) lf = l + 1;
+        tj0.rev_lo = bm.wgstart[lf];
+        tj0.rev_hi = bm.wgstart[num_levels];
+    }
     auto launch_reduce = [&](hipStream_t st, int l0, int l1) {
         const int w0 = bm.wgstart[l0], w1 = bm.wgstart[l1];
+        if (l0 != 0 || l1 != num_levels) { tj0.rev_lo = tj0.rev_hi = 0; }
         if (w1 <= w0 && tj0.blocks == 0) return;
 #define LAUNCH_RED(T, REC, FUSE)                                                                                  \
     hipLaunchKernelGGL((k_scatter_reduce<T, REC, FUSE>), dim3((unsigned)(w1 - w0 + (FUSE ? tj0.blocks : 0))), dim3(T), 0,  \
