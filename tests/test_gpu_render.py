@@ -502,6 +502,34 @@ def test_step_tail_is_bit_identical_to_the_separate_launches(dev, precision, log
 
 
 @pytest.mark.gpu
+def test_closing_scatter_refuses_what_it_cannot_do(dev):
+    """lnerf_grid_encode_backward_adam_tail: without the device step counter (the closing arrival ticks it) and for an
+    empty frame bound (m_host = 0) the call is refused with a message, nothing is launched; the optimiser picks the
+    stand-alone tail for those cases by itself (inline_tail False without a device counter)."""
+    from src.latent_nerf.models import encoding as E
+    from src.latent_nerf.raymarching import backend as B
+    from src.latent_nerf.training.optimizer import FusedAdam
+    net, cfg, lv, table, params, grid = _make(dev, 64, 32, 14, 16, seed=3, mlp_precision="bf16", table_dtype="bf16")
+    net.train()
+    opt = FusedAdam(net.get_params(1e-3), encoder=net.encoder, fuse_table_update=True, mlp=net, tail=True, capturable=False)
+    assert opt.fused.tail and not opt.fused.inline_tail            # no device counter: lnerf_step_tail closes the step
+    M, stride = 1000, 1024
+    xyzs = (torch.rand(stride, 3, device=dev) * 2 - 1)
+    dfeat = torch.randn(16, stride, 2, device=dev)
+    m_dev = torch.tensor([M], dtype=torch.int32, device=dev)
+    ws = net.mlp_workspace(dev)
+    before = net.encoder.embeddings.detach().clone()
+    with pytest.raises(B.LnerfError, match="device counter"):
+        E.grid_encode_backward_adam_tail(xyzs, 1.0, dfeat, net.encoder, M, m_dev, stride, 3, ws, B.BF16, 5)
+    opt2 = FusedAdam(net.get_params(1e-3), encoder=net.encoder, fuse_table_update=True, mlp=net, tail=True, capturable=True)
+    assert opt2.fused.inline_tail
+    with pytest.raises(B.LnerfError, match="m_host > 0"):
+        E.grid_encode_backward_adam_tail(xyzs, 1.0, dfeat, net.encoder, 0, m_dev, stride, 3, ws, B.BF16, 5)
+    torch.cuda.synchronize()
+    assert torch.equal(net.encoder.embeddings.detach(), before) and int(opt2.step_dev[0]) == 1
+
+
+@pytest.mark.gpu
 def test_fused_table_update_arming(dev):
     """Only an armed backward applies the fused update; an unarmed one yields the ordinary table gradient, and a step
     that mixes both is refused."""
