@@ -534,7 +534,9 @@ def main():
     if args.graph:
         from src.latent_nerf.training.graph_step import GraphedTrainStep
         # (a capture failure raises: the line must not silently describe eager launches; use --graph 0 for those)
-        in_graph = bool(dist_on and args.graph_collectives and dist.get_backend() == "nccl")
+        # (LNERF_GRAPH_COLLECTIVES=0: an operator's switch that needs no flag -- the driver's command line is fixed)
+        in_graph = bool(dist_on and args.graph_collectives and dist.get_backend() == "nccl"
+                        and os.environ.get("LNERF_GRAPH_COLLECTIVES", "1") != "0")
         kw = dict(sync=sync, world=2 if dist_on else 1, warmup=3, stream=main_stream, opt_in_graph=not groups,
                   steps_per_graph=2 if prefetch else 1)
         launch = "hipgraph"

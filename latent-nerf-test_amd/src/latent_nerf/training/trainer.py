@@ -83,7 +83,8 @@ class Trainer:
         self.pipelined = self.exchange and bf16 and n_views == 1
         # the exchange goes into the captured step where the collectives can be captured (RCCL; not gloo's host staging)
         self.capture_exchange = (self.exchange and bool(getattr(cfg.optim, "graph_collectives", True))
-                                 and D.backend_name() == "nccl")
+                                 and D.backend_name() == "nccl"
+                                 and os.environ.get("LNERF_GRAPH_COLLECTIVES", "1") != "0")
         if self.pipelined:
             self.grad_sync.attach_sink(self.nerf.encoder, pipeline_groups=max(1, cfg.optim.exchange_groups))
         self.dataloaders = self.init_dataloaders()
