@@ -110,21 +110,33 @@ def parse():
                     help="run the N > 1 step at N = 1: process group (RCCL, communicator of one rank) initialised before any "
                          "GPU call, bf16 gradient sink, pipelined per-group all-reduce, row-group Adam, graph A + eager "
                          "exchange -- the un-fused path the driver's 8-GPU run takes, measured on one card")
-    ap.add_argument("--graph-collectives", type=int, default=1,
+    ap.add_argument("--graph-collectives", default="auto", choices=["auto", "0", "1"],
                     help="N > 1 (or --force-dist) on RCCL: 1 = the exchange and the optimiser are captured into the step "
-                         "graph (one graph launch per step and rank); 0 = graph A + eager exchange + eager optimiser")
+                         "graph (one graph launch per step and rank); 0 = graph A + eager exchange + eager optimiser; "
+                         "auto (default) = captured IF a pre-flight passes on this very job: every rank runs a few steps "
+                         "both ways in a supervised child process (time limit: a hang is a verdict, not a stall) and the "
+                         "ranks agree on the outcome -- captured == eager bit for bit and replicas identical, on all of "
+                         "them -- before the timed run picks its form (`preflight` on the output line)")
+    ap.add_argument("--preflight", action="store_true", help=argparse.SUPPRESS)   # (the pre-flight child itself)
+    ap.add_argument("--preflight-timeout", type=float, default=300.0)
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="--gpus N > 1 started without a launcher: seconds until the parent kills every rank")
     ap.add_argument("--refresh", type=int, default=1,
                     help="1: the occupancy refresh runs inside the timed region every update_extra_interval steps (shadow "
                          "state: the analytic scene stays pinned); 0: the refresh-free step only")
     ap.add_argument("--repeats", type=int, default=0, help="timed regions of --steps steps each (0 = auto: 5 below 100 steps, else 1); the median region is reported")
     ap.add_argument("--trainer-steps", type=int, default=200, help="steps of the `trainer` companion (0 = skip)")
+    ap.add_argument("--views-per-rank", type=int, default=1,
+                    help="views every rank renders per optimisation step, as ONE batch through the fused captured step "
+                         "(render.batch_size of the reference's fork: src/latent_paint_mesh/configs/train_config.py:32); "
+                         "`value` counts every view")
     ap.add_argument("--exchange-groups", type=int, default=4,
                     help="N > 1, bf16 on the wire: level groups the table gradient is exchanged in, each group's all-reduce "
                          "launched behind its own sums (0 = one collective after the whole scatter)")
     return ap.parse_args()
 
 
-def build(dev, precision, variant, rank, table="f32", jitter_rng="kernel", gridtype="hash"):
+def build(dev, precision, variant, rank, table="f32", jitter_rng="kernel", gridtype="hash", views=1):
     from src.latent_nerf.configs.render_config import RenderConfig
     from src.latent_nerf.models.network_grid import NeRFNetwork
     from src.latent_nerf.models.nerf_utils import intrinsics_from_fov, pose_from_angles
@@ -132,16 +144,19 @@ def build(dev, precision, variant, rank, table="f32", jitter_rng="kernel", gridt
     torch.manual_seed(0)
     cfg = RenderConfig(grid_size=GRID, train_h=H, train_w=W, mlp_precision=precision, table_dtype=table,
                        gather_variant=variant, noise_seed=(0x5EED + rank) if jitter_rng == "kernel" else None,
-                       max_samples=BENCH_CAPACITY, gridtype=gridtype)
+                       max_samples=BENCH_CAPACITY * views, gridtype=gridtype)
     net = NeRFNetwork(cfg)
     net.encoder.embeddings.data.normal_(0, 0.1)
     net = net.to(dev).train()
     sphere_scene(net)
-    pose = pose_from_angles(math.radians(60.0), math.radians(45.0 * rank), 1.25)[None].to(dev)
+    # `views` views per rank and step, rendered as ONE batch (one march / gather / MLP / composite / scatter over all of
+    # their rays and samples, one optimiser step): view v of rank r looks from phi = 45 deg * (r * views + v)
+    pose = torch.stack([pose_from_angles(math.radians(60.0), math.radians(45.0 * (rank * views + v)), 1.25)
+                        for v in range(views)]).to(dev)
     intr = intrinsics_from_fov(FOVY, H, W)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    bg = torch.rand(H * W, 4, generator=g).to(dev)
-    grad = (torch.randn(1, H * W, 4, generator=g) * math.sqrt(0.5) * 0.5).to(dev)
+    bg = torch.rand(views * H * W, 4, generator=g).to(dev)
+    grad = (torch.randn(views, H * W, 4, generator=g) * math.sqrt(0.5) * 0.5).to(dev)
     return net, pose, intr, bg, grad
 
 
@@ -382,6 +397,31 @@ def companion_blocked(dev, rank, precision, steps=60, warmup=10):
                     "table); a different table layout, NOT the headline's Instant-NGP hash"}
 
 
+def companion_views(args, dev, rank, k=8, steps=30, warmup=6):
+    """k views per rank and step as ONE batch through the same fused, captured step (`--views-per-rank k`): one march /
+    gather / MLP / composite / scatter over the k views' rays and samples, the 318 MB table update, the step's tail and
+    the tick paid once per STEP (BASELINE configs[3]'s 8 views per step on one GPU; render.batch_size of the reference's
+    fork, src/latent_paint_mesh/configs/train_config.py:32)."""
+    a = argparse.Namespace(**vars(args))
+    a.views_per_rank, a.prefetch_rays, a.fuse_table_update = k, 0, "auto"
+    S = build_step(a, dev, rank, 1, False)
+    gstep = make_gstep(S, False, False, torch.cuda.current_stream())
+    for _ in range(warmup):
+        gstep()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = gstep()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if int(out["counter"][2].item()) != 0:
+        raise SystemExit("bench (views companion): rays did not fit the sample capacity")
+    return {"value": k * steps / dt, "unit": "latent-frames/sec", "views_per_step": k, "ms_per_step": 1e3 * dt / steps,
+            "ms_per_view": 1e3 * dt / steps / k, "steps": steps, "samples_per_step": int(out["counter"][0].item()),
+            "what": "--views-per-rank %d: the views of a step rendered and back-propagated as one batch inside the fused, "
+                    "captured step; one optimiser step per batch" % k}
+
+
 def companion_f32(dev, rank, steps=40, warmup=6):
     """The exact-f32 parity configuration (f32 table, f32 features, exact-f32 MFMA MLP, 12-byte scatter records) through
     the same captured step: frames/s beside the headline (bf16) number."""
@@ -457,37 +497,200 @@ def trainer_companion(dev, steps, precision, fixed_pose=False):
         shutil.rmtree(root, ignore_errors=True)
 
 
-def main():
-    args = parse()
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): this process -- which has not
+    touched the GPU and never will -- starts the N ranks as children (one per GPU, a free rendezvous port), relays rank 0's
+    JSON line, kills every rank when one fails or the time limit passes, and exits with the worst exit code.  Under
+    `python -m torch.distributed.run ... bench.py --gpus N` the ranks arrive with WORLD_SIZE set and none of this runs."""
+    from src.latent_nerf.training.launch import spawn_ranks
+    n = args.gpus
+    backend = os.environ.get("LNERF_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()          # (counting devices does not initialise the GPU)
+    if ndev == 0:
+        raise SystemExit("bench: no GPU visible")
+    if backend == "nccl" and ndev < n:
+        raise SystemExit("bench: --gpus %d but %d GPU(s) visible (RCCL needs one GPU per rank; LNERF_DIST_BACKEND=gloo lets "
+                         "ranks share a card for a functional rehearsal)" % (n, ndev))
+    log("starting %d ranks (backend %s)" % (n, backend))
+    rc, out = spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], n, timeout_s=args.launch_timeout,
+                          log=log)
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    if rc == 0 and not lines:
+        log("rank 0 printed no result line")
+        rc = 1
+    if lines:
+        print(lines[-1], flush=True)
+    return rc
+
+
+def dist_setup(args):
+    """Rank / device / process group of this process, before anything touches the GPU."""
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d ...`"
-                             % (args.gpus, args.gpus))
-    import torch.distributed as dist
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # one process per GPU; LNERF_DIST_BACKEND=gloo lets several ranks share one card for a functional rehearsal
     backend = os.environ.get("LNERF_DIST_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
     local_dev = local if backend == "nccl" else local % max(ndev, 1)
-    torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     if args.force_dist:
         os.environ["LNERF_FORCE_DIST"] = "1"   # (GradSync / Trainer read it: exchange at any world size)
     dist_on = world > 1 or args.force_dist     # gradients are exchanged (collectives run; the table update is not fused)
+    store = None
     if dist_on:
+        from src.latent_nerf.training.launch import free_port, open_store
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
+        if "MASTER_PORT" not in os.environ:    # (only a one-rank --force-dist run gets here without a launcher)
+            if world > 1:
+                raise SystemExit("bench: WORLD_SIZE > 1 needs MASTER_PORT (a launcher sets it)")
+            os.environ["MASTER_PORT"] = str(free_port())
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
-        with stdout_to_stderr():   # (the communicator is created by the first collective: do one here)
-            if backend == "nccl":
-                dist.init_process_group("nccl", device_id=dev)
-            else:
-                dist.init_process_group(backend)
-            dist.barrier()
-            torch.cuda.synchronize()
+        store = open_store(rank, world)
+    return rank, world, local_dev, dev, backend, dist_on, store
+
+
+def join_group(store, rank, world, dev, backend):
+    import torch.distributed as dist
+    torch.cuda.set_device(dev)
+    with stdout_to_stderr():   # (the communicator is created by the first collective: do one here)
+        if backend == "nccl":
+            dist.init_process_group("nccl", store=store, rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, store=store, rank=rank, world_size=world)
+        dist.barrier()
+        torch.cuda.synchronize()
+
+
+def decide_graph_collectives(args, store, rank, world, backend):
+    """-> (capture the exchange?, verdict dict for the output line).  Runs BEFORE this process touches the GPU."""
+    from src.latent_nerf.training.launch import agree, free_port, run_child
+    env_sw = os.environ.get("LNERF_GRAPH_COLLECTIVES", "")
+    if backend != "nccl" or not args.graph:
+        return False, {"ran": False, "why": "collectives of backend %r are not captured" % backend}
+    if args.graph_collectives != "auto" or env_sw in ("0", "1"):
+        on = (args.graph_collectives == "1") if env_sw not in ("0", "1") else env_sw == "1"
+        return on, {"ran": False, "why": "forced %s by %s" % ("on" if on else "off", "LNERF_GRAPH_COLLECTIVES"
+                                                              if env_sw in ("0", "1") else "--graph-collectives")}
+    # every rank starts ONE child that joins a process group of its own (a fresh port rank 0 publishes), runs the step
+    # with the eager and with the captured exchange from the same seeded state and compares; a child that hangs is
+    # killed at the time limit.  The ranks then read each other's exit codes: all take the same turn.
+    if rank == 0:
+        store.set("lnerf_preflight_port", str(free_port()))
+    port = store.get("lnerf_preflight_port").decode()
+    env = dict(os.environ, MASTER_PORT=port, LNERF_BENCH_PREFLIGHT="1")
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+    argv = [sys.executable, os.path.abspath(__file__), "--preflight", "--gpus", str(world), "--precision", args.precision,
+            "--table", args.table, "--grad-transport", args.grad_transport, "--exchange-groups", str(args.exchange_groups),
+            "--gridtype", args.gridtype, "--views-per-rank", str(args.views_per_rank), "--perturb", str(args.perturb)]
+    if args.force_dist:
+        argv.append("--force-dist")
+    t0 = time.perf_counter()
+    gave_up = lambda: store.check(["lnerf_preflight_abort"])
+    rc = run_child(argv, env, args.preflight_timeout, poll=gave_up)
+    if rc != 0:
+        store.set("lnerf_preflight_abort", "1")      # the other ranks stop waiting for their children
+    codes = agree(store, "lnerf_preflight_rc", rank, world, rc, timeout_s=args.preflight_timeout + 60)
+    ok = all(c == "0" for c in codes)
+    return ok, {"ran": True, "passed": ok, "exit_codes": [int(c) for c in codes], "seconds": time.perf_counter() - t0,
+                "what": "per rank: one supervised child, 3 + 4 steps with the eager exchange and 3 eager + 4 REPLAYED steps "
+                        "with exchange and optimiser captured, from the same seeded state: tables / MLP bit-identical "
+                        "between the two forms and across ranks; 124 = killed at the time limit"}
+
+
+def build_step(args, dev, rank, world, dist_on):
+    """Model, optimiser and the step closures of this rank."""
+    from src.latent_nerf.training.optimizer import FusedAdam
+    table = args.precision if args.table == "auto" else args.table
+    net, pose, intr, bg, grad = build(dev, args.precision, args.gather_variant, rank, table, args.jitter_rng, args.gridtype,
+                                      views=args.views_per_rank)
+    fuse = (not dist_on) if args.fuse_table_update == "auto" else (args.fuse_table_update == "1")
+    if fuse and dist_on:
+        raise SystemExit("--fuse-table-update 1 needs one rank without --force-dist (the gradient all-reduce sits between "
+                         "backward and Adam)")
+    opt = FusedAdam(net.get_params(LR if args.lr is None else args.lr), betas=(0.9, 0.99), eps=1e-15, encoder=net.encoder, capturable=True,
+                    fuse_table_update=fuse, mlp=net if args.fragment_shadow else None,
+                    tail=bool(args.tail) and fuse and bool(args.fragment_shadow))
+    opt.grad_scale = 1.0 / (world * args.views_per_rank)
+    tr = args.precision if args.grad_transport == "auto" else args.grad_transport
+    groups = args.exchange_groups if (dist_on and tr == "bf16") else 0
+    prefetch = bool(args.prefetch_rays)
+    if prefetch and (dist_on or args.views_per_rank != 1):
+        raise SystemExit("--prefetch-rays 1 needs one rank without --force-dist and one view per rank")
+    step, fwd_bwd, opt_step, sync = make_step(net, pose, intr, bg, grad, opt, world * args.views_per_rank,
+                                              torch.bfloat16 if tr == "bf16" else torch.float32, bool(args.perturb), groups,
+                                              prefetch)
+    return dict(net=net, opt=opt, step=step, fwd_bwd=fwd_bwd, opt_step=opt_step, sync=sync, table=table, fuse=fuse, tr=tr,
+                groups=groups, prefetch=prefetch)
+
+
+def make_gstep(S, dist_on, in_graph, stream):
+    from src.latent_nerf.training.graph_step import GraphedTrainStep
+    kw = dict(sync=S["sync"], world=2 if dist_on else 1, warmup=3, stream=stream, opt_in_graph=not S["groups"],
+              steps_per_graph=2 if S["prefetch"] else 1)
+    return GraphedTrainStep(S["fwd_bwd"], S["opt_step"], list(S["net"].parameters()), sync_in_graph=bool(in_graph), **kw)
+
+
+def preflight_main(args):
+    """The pre-flight child of one rank (decide_graph_collectives): exit code 0 = the captured exchange reproduces the
+    eager one bit for bit on this rank and the replicas agree; 3 = it does not; anything else = it failed to run."""
+    import hashlib
+    import torch.distributed as dist
+    rank, world, _local, dev, backend, dist_on, store = dist_setup(args)
+    join_group(store, rank, world, dev, backend)
+    from src.latent_nerf.raymarching import backend as B
+    B.get_lib()
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+
+    def digest(S):
+        torch.cuda.synchronize()
+        h = hashlib.sha256()
+        for p in S["net"].parameters():
+            h.update(p.detach().contiguous().cpu().numpy().tobytes())
+        return h.hexdigest()
+
+    K = 4
+    A = build_step(args, dev, rank, world, True)
+    for _ in range(3 + K):            # (GraphedTrainStep below runs 3 eager steps before it captures)
+        A["step"]()
+    da = digest(A)
+    del A
+    Bs = build_step(args, dev, rank, world, True)
+    g = make_gstep(Bs, True, True, stream)
+    for _ in range(K):
+        g()
+    db = digest(Bs)
+    same = torch.tensor([1 if da == db else 0], device=dev, dtype=torch.int32)
+    dist.all_reduce(same, op=dist.ReduceOp.MIN)
+    chk = torch.frombuffer(bytearray(bytes.fromhex(db)), dtype=torch.uint8).to(dev)
+    allc = [torch.empty_like(chk) for _ in range(world)]
+    dist.all_gather(allc, chk)
+    replicas = all(torch.equal(allc[0], c) for c in allc)
+    ok = bool(int(same.item())) and replicas
+    log("pre-flight rank %d: captured %s eager, replicas %s" % (rank, "==" if da == db else "!=",
+                                                                  "identical" if replicas else "DIFFER"))
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 3
+
+
+def main():
+    args = parse()
+    if args.preflight:
+        raise SystemExit(preflight_main(args))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
+    import torch.distributed as dist
+    rank, world, _local, dev, backend, dist_on, store = dist_setup(args)
+    in_graph, preflight = False, None
+    if dist_on:
+        in_graph, preflight = decide_graph_collectives(args, store, rank, world, backend)   # (no GPU call before this)
+        join_group(store, rank, world, dev, backend)
+    torch.cuda.set_device(dev)
 
     from src.latent_nerf.raymarching import backend as B
     B.get_lib()  # no fallback: raise here if the HIP library is missing
@@ -499,29 +702,13 @@ def main():
     # everything (eager steps, graph capture, replays, collectives) runs on one non-default stream
     main_stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(main_stream)
-    table = args.precision if args.table == "auto" else args.table
-    net, pose, intr, bg, grad = build(dev, args.precision, args.gather_variant, rank, table, args.jitter_rng, args.gridtype)
-    from src.latent_nerf.training.optimizer import FusedAdam
-    fuse = (not dist_on) if args.fuse_table_update == "auto" else (args.fuse_table_update == "1")
-    if fuse and dist_on:
-        raise SystemExit("--fuse-table-update 1 needs one rank without --force-dist (the gradient all-reduce sits between "
-                         "backward and Adam)")
-    opt = FusedAdam(net.get_params(LR if args.lr is None else args.lr), betas=(0.9, 0.99), eps=1e-15, encoder=net.encoder, capturable=True,
-                    fuse_table_update=fuse, mlp=net if args.fragment_shadow else None,
-                    tail=bool(args.tail) and fuse and bool(args.fragment_shadow))
-    opt.grad_scale = 1.0 / world
-    tr = args.precision if args.grad_transport == "auto" else args.grad_transport
-    groups = args.exchange_groups if (dist_on and tr == "bf16") else 0
+    S = build_step(args, dev, rank, world, dist_on)
+    net, opt, step, sync = S["net"], S["opt"], S["step"], S["sync"]
+    table, fuse, tr, groups, prefetch = S["table"], S["fuse"], S["tr"], S["groups"], S["prefetch"]
     inline_tail = bool(opt.fused is not None and opt.fused.inline_tail)   # pass 2 of the scatter closes the step itself
     scatter_call = ("lnerf_grid_encode_backward_adam_tail" if inline_tail else "lnerf_grid_encode_backward_adam" if fuse else
                     "lnerf_grid_scatter_bin" if groups else
                     "lnerf_grid_encode_backward_bf16" if (dist_on and tr == "bf16") else "lnerf_grid_encode_backward")
-    prefetch = bool(args.prefetch_rays)
-    if prefetch and dist_on:
-        raise SystemExit("--prefetch-rays 1 needs one rank without --force-dist")
-    step, fwd_bwd, opt_step, sync = make_step(net, pose, intr, bg, grad, opt, world,
-                                              torch.bfloat16 if tr == "bf16" else torch.float32, bool(args.perturb), groups,
-                                              prefetch)
 
     def barrier():
         if dist_on:
@@ -532,24 +719,17 @@ def main():
     launch = "eager"
     gstep = None
     if args.graph:
-        from src.latent_nerf.training.graph_step import GraphedTrainStep
         # (a capture failure raises: the line must not silently describe eager launches; use --graph 0 for those)
-        # (LNERF_GRAPH_COLLECTIVES=0: an operator's switch that needs no flag -- the driver's command line is fixed)
-        in_graph = bool(dist_on and args.graph_collectives and dist.get_backend() == "nccl"
-                        and os.environ.get("LNERF_GRAPH_COLLECTIVES", "1") != "0")
-        kw = dict(sync=sync, world=2 if dist_on else 1, warmup=3, stream=main_stream, opt_in_graph=not groups,
-                  steps_per_graph=2 if prefetch else 1)
         launch = "hipgraph"
         if in_graph:
-            try:
-                gstep = GraphedTrainStep(fwd_bwd, opt_step, list(net.parameters()), sync_in_graph=True, **kw)
-                launch = "hipgraph (exchange + optimiser captured)"
-            except RuntimeError as e:   # a collective the backend cannot capture: every rank takes the same turn
-                log("capture with collectives failed (%s): graph A + eager exchange" % str(e).splitlines()[0])
-                torch.cuda.synchronize()
-                launch = "hipgraph (exchange eager: capture with collectives failed)"
-        if gstep is None:
-            gstep = GraphedTrainStep(fwd_bwd, opt_step, list(net.parameters()), **kw)
+            # the pre-flight passed on every rank (or the operator forced the form): a failure here is fatal on every
+            # rank alike -- no per-rank fallback that could leave ranks on different paths
+            gstep = make_gstep(S, dist_on, True, main_stream)
+            launch = "hipgraph (exchange + optimiser captured)"
+        else:
+            gstep = make_gstep(S, dist_on, False, main_stream)
+            if dist_on:
+                launch = "hipgraph (render + backward; exchange and optimiser eager)"
     emb0 = net.encoder.embeddings.detach().clone()
     spg = gstep.steps_per_call if gstep is not None else 1
     # occupancy refresh (H10) at the trainer's cadence, inside the timed region: update_extra_state() in its
@@ -632,7 +812,7 @@ def main():
     n_probe = state["n_probe"]
     M = int(out["counter"][0].item())
     if int(out["counter"][2].item()) != 0:
-        raise SystemExit("bench: %d rays did not fit the sample capacity %d" % (int(out["counter"][2].item()), BENCH_CAPACITY))
+        raise SystemExit("bench: %d rays did not fit the sample capacity %d" % (int(out["counter"][2].item()), net.cfg.max_samples))
     if rank == 0:
         log("timed region: %.4f s for %d steps (median of %d: %s)" % (elapsed, args.steps, repeats,
                                                                    ", ".join("%.4f" % r[0] for r in regions)))
@@ -666,6 +846,7 @@ def main():
         B.set_profile_hook(None)
         breakdown = {n.replace("lnerf_", ""): round(bt.mean_ms(n) * (len(bt.pairs[n]) / 20.0), 4) for n in names}
 
+    kv = int(args.views_per_rank)
     if rank == 0:
         # algorithmic bytes per sample of the gather: 16 levels x 8 vertices x 2 features x
         # sizeof(table entry) gathered + 12 B position + 16 x 2 x sizeof(feature) written
@@ -701,7 +882,7 @@ def main():
         ref_med = ref_ms[len(ref_ms) // 2] if ref_ms else None
         res = {
             "metric": "latent-frames/sec (64x64x4, 128^3 grid), render forward+backward",
-            "value": world * args.steps / elapsed,
+            "value": world * kv * args.steps / elapsed,
             "unit": "latent-frames/sec",
             "n_gpus": world,
             "steps": args.steps,
@@ -713,7 +894,7 @@ def main():
             "launch": launch, "eager_probe_steps": n_probe,
             "refresh": ({"in_timed_region": True, "every_steps": iv, "refreshes_in_region": n_ref,
                          "ms_per_refresh": ref_med, "ms_per_step_amortised": (ref_med / iv) if ref_med else None,
-                         "value_without_refresh": (world * args.steps / (elapsed - 1e-3 * ref_med * n_ref))
+                         "value_without_refresh": (world * kv * args.steps / (elapsed - 1e-3 * ref_med * n_ref))
                          if ref_med else None,
                          "what": "NeRFRenderer.update_extra_state() (H10), steady-state form, every %d steps between "
                                  "replays, INCLUDED in `value`; it writes a shadow copy of the occupancy state, so the "
@@ -730,12 +911,13 @@ def main():
             "dtype": args.precision,
             "data": "synthetic",
             "config": {"workload": "configs[1]: unconstrained latent-NeRF 64x64x4, 128^3 occupancy grid, hash grid "
-                                   "L=16 F=2 T=2^19, 1 view/GPU/step, fwd+bwd+grad all-reduce+Adam, occupancy refresh every "
-                                   "%d steps" % iv,
-                       "rays_per_view": H * W, "samples_per_view": M, "sample_capacity": BENCH_CAPACITY,
-                       "views_per_step": world,
-                       "parallelism": "dp%d (1 view per GPU, RCCL all-reduce of gradients, %s on the wire%s)%s"
-                                      % (world, tr, ", table in %d pipelined level groups" % groups if groups else "",
+                                   "L=16 F=2 T=2^19, %d view%s/GPU/step, fwd+bwd+grad all-reduce+Adam, occupancy refresh every "
+                                   "%d steps" % (kv, "" if kv == 1 else "s (one batch)", iv),
+                       "rays_per_view": H * W, "samples_per_view": M // kv, "sample_capacity": int(net.cfg.max_samples),
+                       "views_per_step": world * kv, "views_per_rank": kv,
+                       "parallelism": "dp%d (%d view%s per GPU, RCCL all-reduce of gradients, %s on the wire%s)%s"
+                                      % (world, kv, "" if kv == 1 else "s", tr,
+                                         ", table in %d pipelined level groups" % groups if groups else "",
                                          "; --force-dist: the exchange path on ONE rank (communicator of size 1)"
                                          if args.force_dist else "")},
             "roofline": {"kernel": "k_grid_forward (hash-grid gather, H5)", "bound": "hbm", "achieved": achieved,
@@ -752,15 +934,18 @@ def main():
         if breakdown:
             res["kernel_ms_per_step"] = breakdown
         res["build"] = build_tag
+        if preflight is not None:
+            res["preflight"] = preflight
         if tuned:
             res["tuning_overrides"] = tuned
-        if not args.no_extras and not dist_on and args.gridtype == "hash":
+        if not args.no_extras and not dist_on and args.gridtype == "hash" and kv == 1:
             if args.trainer_steps > 0:
                 # the product loop twice: on the bench's own view (same GPU work per step as the headline: what the loop
                 # itself costs) and on the training pose distribution (random radius / angles / field of view per step)
                 res["trainer"] = trainer_companion(dev, args.trainer_steps, args.precision, fixed_pose=True)
                 res["trainer"]["frac_of_value"] = res["trainer"]["value"] / res["value"]
                 res["trainer_random_views"] = trainer_companion(dev, args.trainer_steps, args.precision)
+            res["views8"] = companion_views(args, dev, rank, 8)
             res["blocked"] = companion_blocked(dev, rank, args.precision)
             res["f32"] = companion_f32(dev, rank)
         if not args.no_cpu_baseline and not dist_on:

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define LNERF_ABI_VERSION 5
+#define LNERF_ABI_VERSION 6
 
 #define LNERF_OK 0
 #define LNERF_ERR_INVALID_ARG (-1)
@@ -101,7 +101,10 @@ int lnerf_packbits(const float *grid, int64_t n_cells, float thresh, const float
  *   rays    int32 [N,3]  (ray id, offset, count)
  *   counter int32 [lnerf_march_counter_len(N)]
  *                        [0]=M total samples written, [1]=number of rays with count>0,
- *                        [2]=rays dropped because offset+count exceeded `capacity`, [3]=reserved,
+ *                        [2]=rays dropped because offset+count exceeded `capacity`,
+ *                        [3]=running maximum of  M | (rays dropped ? 2^30 : 0)  over the calls since the CALLER last
+ *                        zeroed it (zero it when the buffer is allocated): the peak a training loop sizes its sample
+ *                        buffers from, kept without a launch of its own,
  *                        [4 ...) scratch of the call (two-launch form: per-ray counts, per-workgroup sums)
  *   jitter of the march start t0 = near + dt(near) * u_n, one of
  *     noises [N] in [0,1)          the upstream form (`noises = torch.rand(N)`);
@@ -414,7 +417,7 @@ int lnerf_adam_step_multi_shadow(int count, float *const *p_host, float *const *
  *     of the ordinary reduction, and the Adam step of w1, b1, w2, b2, w3, b3 straight from the sums
  *     (params / exp_avg / exp_avg_sq: host arrays of six device pointers; maps_host: optional, the three fragment maps of
  *     lnerf_mlp_fragment_maps -- the updated weights are mirrored into the fragment image at the head of mlp_workspace;
- *     mlp_workspace = NULL: skipped);
+ *     mlp_workspace = NULL: skipped -- the tick / the clearing below still run, as one workgroup);
  *   - LNERF_TAIL_TICK: *step_dev += 1 once every workgroup has read it (the arrival counters live in the header of the
  *     scatter workspace: LNERF_SCATTER_ZERO_HEAD_BYTES);
  *   - LNERF_TAIL_CLEAR_SCATTER: the scatter's level maxima (first lnerf_grid_scatter_clear_bytes() bytes of its

@@ -488,6 +488,8 @@ struct BucketMeta {
     int pstart[LNERF_MAX_LEVELS];        // sliced levels: first partial-sum tile of the level (pass 2 -> finish)
     int fstart[LNERF_MAX_LEVELS];        // sliced levels: first bucket index in the finishing pass's grid
     int n_items;                         // item capacity: ceil(m_host / ITEM_SAMPLES)
+    int fix_bits;                        // exact 12-byte records: bits of the fixed-point addends (<= 44), chosen so that
+                                         // m_host addends of the level's bound cannot overflow an int64 (see fix_scale)
     // chunk of (level l, item t): record slot ((int64)l * n_items + t) * ITEM_RECS;
     // segment table entry of (l, t, bucket b): ((int64)bstart[l] * n_items + (int64)t * nb[l] + b)
 };
@@ -903,11 +905,10 @@ struct FusedUpdate {
 struct FixScale {
     float sc_a, sc_b, un_a, un_b;
 };
-template <int BITS>
-__device__ __forceinline__ FixScale fix_scale(unsigned int gmax_bits) {
+__device__ __forceinline__ FixScale fix_scale(unsigned int gmax_bits, int bits) {
     int e = (int)(gmax_bits >> 23);
     e = e < 1 ? 1 : (e > 254 ? 254 : e);
-    int k = BITS + 126 - e;
+    int k = bits + 126 - e;
     k = k > 200 ? 200 : k;
     FixScale f;
     f.sc_a = ldexpf(1.0f, k / 2); f.sc_b = ldexpf(1.0f, k - k / 2);
@@ -1107,7 +1108,7 @@ __device__ __forceinline__ void scatter_reduce_one(int wg, const GridMeta &meta,
                                                    const int32_t *__restrict__ items_dev,
                                                    const uint32_t *__restrict__ segtab, int32_t *__restrict__ bucket_n,
                                                    int32_t *__restrict__ slice_arrive,
-                                                   const unsigned int *__restrict__ gmax, const REC *__restrict__ recs,
+                                                   unsigned int *gmax, const REC *__restrict__ recs,
                                                    float *__restrict__ dtable, long long *__restrict__ partials,
                                                    const FusedUpdate &fu, const SlabAdam &sa, int32_t step_now,
                                                    bool have_step) {
@@ -1171,7 +1172,11 @@ __device__ __forceinline__ void scatter_reduce_one(int wg, const GridMeta &meta,
     const bool have = i1 > i0 || !direct;
     if (!have && !fuse) return;  // (a fused bucket without records still owes its rows the Adam step, g = 0)
     constexpr int FB = FixBits<REC>::kBits;
-    const FixScale fs = fix_scale<FB>(gmax[l * CUR_STRIDE]);  // from the bound of |value| of the LEVEL (found by pass 1)
+    // from the bound of |value| of the LEVEL (found by pass 1).  One device-scope atomic load: the last workgroup of a
+    // closing launch to arrive ZEROES the maxima (tail_arrive) -- ordered behind this read by the arrival, but a plain
+    // load the compiler might re-issue later would be a data race on paper
+    const FixScale fs = fix_scale(__hip_atomic_load(&gmax[l * CUR_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                  REC::kPacked ? FB : bm.fix_bits);
     RED_STAMP_INIT();
     const int hsize = meta.offsets[l + 1] - meta.offsets[l];
     const int row0 = b << BK_SHIFT;
@@ -1483,7 +1488,7 @@ __device__ __forceinline__ void scatter_reduce_one(int wg, const GridMeta &meta,
 template <int RT, typename REC, bool FUSE>
 __global__ void __launch_bounds__(RT, (LNERF_BK_SHIFT < 12 && RT == 512) ? 8 : RT / 128)
 k_scatter_reduce(GridMeta meta, BucketMeta bm, const int32_t *__restrict__ items_dev, const uint32_t *__restrict__ segtab,
-                 int32_t *__restrict__ bucket_n, int32_t *__restrict__ slice_arrive, unsigned int *__restrict__ gmax,
+                 int32_t *__restrict__ bucket_n, int32_t *__restrict__ slice_arrive, unsigned int *gmax,
                  const REC *__restrict__ recs, float *__restrict__ dtable, long long *__restrict__ partials, int wg_lo,
                  FusedUpdate fu, TailJob tj) {
     // (closing the step: the counter is read ONCE per wave, with a device-scope atomic load, before anything else --
@@ -1602,6 +1607,13 @@ static int fill_bucket_meta(const GridMeta &meta, int64_t m_host, BucketMeta &bm
     bm.bstart[meta.num_levels] = total_buckets;
     bm.wgstart[meta.num_levels] = total_wgs;
     bm.n_items = (int)n_items;
+    // 12-byte records, exact sums: the addends of a bucket sum to at most m_host x the level's bound (the weights of a
+    // sample's 8 vertices sum to 1; a merged run's bound is 64 x the largest |g| and it stands for up to 64 samples), so
+    // bits + ceil(log2(m_host)) <= 62 keeps every int64 sum exact whatever the input: 44 bits up to 2^18 samples, 42 at
+    // the bench's 640 Ki, 39 with eight views in a batch (the 8-byte records use 30 bits: exact below 2^32 samples)
+    int lg = 1;
+    while (((int64_t)1 << lg) < m_host) ++lg;
+    bm.fix_bits = 62 - lg < 44 ? 62 - lg : 44;
     plan.buckets = total_buckets;
     plan.wgs = total_wgs;
     plan.ptiles = total_ptiles;
@@ -2127,8 +2139,7 @@ int lnerf_step_tail(int num_levels, int level_dim, const int32_t *offsets_host, 
     memset(&fu, 0, sizeof(fu));
     adam_host_args(fu.a, table_lr, beta1, beta2, eps, step, step_dev, grad_scale, 0);
     unsigned int *gmax = nullptr;
-    int32_t *bucket_n = nullptr, *arrive = nullptr;
-    long long *partials = nullptr;
+    int32_t *arrive = nullptr;
     const bool packed = (variant & 0xFF) == 3;
     if (with_scatter) {
         int rc = fill_meta("step_tail", meta, num_levels, level_dim, offsets_host, scales_host, res_host);
@@ -2141,9 +2152,7 @@ int lnerf_step_tail(int num_levels, int level_dim, const int32_t *offsets_host, 
                       "step_tail: buffers must be 16-byte aligned");
         char *wsb = (char *)scatter_workspace;
         gmax = (unsigned int *)wsb;
-        bucket_n = (int32_t *)(wsb + HDR_BUCKETN_OFF);
         arrive = (int32_t *)(wsb + HDR_ARRIVE_OFF);
-        partials = (long long *)(wsb + plan.header_bytes + plan.seg_bytes + plan.rec_bytes);
         fu.p = table; fu.m = exp_avg; fu.v = exp_avg_sq; fu.shadow = (uint16_t *)shadow_bf16;
     }
     LNERF_REQUIRE(!(flags & (LNERF_TAIL_CLEAR_SCATTER | LNERF_TAIL_TICK)) || with_scatter,
@@ -2157,10 +2166,13 @@ int lnerf_step_tail(int num_levels, int level_dim, const int32_t *offsets_host, 
         if (rc) return rc;
         n_slab_blocks = (int)div_up(MLP_SLAB, TAIL_P);
     }
+    const int do_tick = (flags & LNERF_TAIL_TICK) ? 1 : 0, clr = (flags & LNERF_TAIL_CLEAR_SCATTER) ? 1 : 0;
+    // no MLP: the tick / the clearing epilogue still run -- ONE block that arrives on its own (k_step_tail's
+    // `sa.slabs == nullptr` branch); a call with nothing at all to do returns without a launch
+    if (n_slab_blocks == 0 && (do_tick || clr)) n_slab_blocks = 1;
     const dim3 g((unsigned)n_slab_blocks);
     if (g.x == 0) return LNERF_OK;
     hipStream_t s = as_stream(stream);
-    const int do_tick = (flags & LNERF_TAIL_TICK) ? 1 : 0, clr = (flags & LNERF_TAIL_CLEAR_SCATTER) ? 1 : 0;
     hipLaunchKernelGGL(k_step_tail, g, dim3(256), 0, s, gmax, fu.a, sa, step_dev, arrive, do_tick, clr);
     LNERF_CHECK_LAUNCH("step_tail");
     return LNERF_OK;

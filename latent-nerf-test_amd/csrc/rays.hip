@@ -181,6 +181,14 @@ __device__ __forceinline__ float march_noise(const MarchNoise &nz, int64_t n) {
 #define LNERF_MARCH_FUSED_MAX_RAYS 8192   // above: the per-wavefront prefix (N^2 / 2 loads) loses to the scan kernel
 #endif
 constexpr int64_t MARCH_FUSED_MAX_RAYS = LNERF_MARCH_FUSED_MAX_RAYS;
+// counter[3]: running maximum, over the marches since the caller last zeroed it, of  M | (rays dropped ? 2^30 : 0)  --
+// what a training loop that sizes its sample buffers from observed marches reads back once in a while
+// (NeRFRenderer.update_sample_budget), kept by the ONE thread that writes the totals: no launch, no atomics
+__device__ __forceinline__ void march_note_peak(int32_t *__restrict__ counter, int32_t m, int dropped) {
+    const int32_t word = m | (dropped > 0 ? (1 << 30) : 0);
+    const int32_t old = counter[3];
+    counter[3] = word > old ? word : old;
+}
 __device__ __forceinline__ void march_totals(const int32_t *__restrict__ cnt, int64_t N, int64_t capacity,
                                              int32_t *__restrict__ counter, int32_t *__restrict__ noise_counter) {
     const int lane = lane_id();
@@ -213,7 +221,7 @@ __device__ __forceinline__ void march_totals(const int32_t *__restrict__ cnt, in
         counter[0] = drop > 0 ? (int32_t)best : (int32_t)(carry > capacity ? capacity : carry);
         counter[1] = live;
         counter[2] = drop;
-        counter[3] = 0;
+        march_note_peak(counter, counter[0], drop);
         if (noise_counter) *noise_counter += 1;   // (this pass took its jitter from rays[][1], not from the counter)
     }
 }
@@ -317,7 +325,7 @@ k_march_train(const float *__restrict__ rays_o, const float *__restrict__ rays_d
                     counter[0] = (int32_t)total;
                     counter[1] = nonempty + (c > 0 ? 1 : 0);
                     counter[2] = 0;
-                    counter[3] = 0;
+                    march_note_peak(counter, (int32_t)total, 0);
                     if (noise_counter) *noise_counter += 1;   // (this pass took its jitter from rays[][1])
                 }
             } else {
@@ -493,7 +501,7 @@ __global__ void __launch_bounds__(1024) k_march_scan(int32_t *__restrict__ rays,
         counter[0] = dr > 0 ? (int32_t)bmax : (int32_t)(total > capacity ? capacity : total);
         counter[1] = lv;
         counter[2] = dr;
-        counter[3] = 0;
+        march_note_peak(counter, counter[0], dr);
     }
 }
 

@@ -56,16 +56,20 @@ class OptimConfig:
     # its own sums while the next group is still being summed); 1 = one collective for the whole table
     exchange_groups: int = 4
     # replay the step from captured hipGraphs (graph F: render / eager guidance / graph B: backward + optimiser); the
-    # first steps, and the step after every change of the sample budget, run eagerly.  One view per rank and step.
+    # first steps, and the step after every change of the sample budget, run eagerly.  Any number of views per rank (a
+    # step's views are rendered as one batch).
     graph_step: bool = True
     # a guidance object that is itself capturable (guidance.capturable: device ops only, device-side RNG -- the synthetic
     # one) is captured INSIDE the step graph: one graph launch per step.  False: graph F / eager guidance / graph B always
     graph_guidance: bool = True
     # data parallel on RCCL: the gradient exchange (per-group sums + all-reduces, flat bucket) and the optimiser are
     # captured INTO the step graph (RCCL's collectives are capturable; one graph launch per step on every rank, no eager
-    # launches between the ranks' graphs).  False, or a backend that stages through the host (gloo): graph / eager
-    # exchange + optimiser
-    graph_collectives: bool = True
+    # launches between the ranks' graphs).  "false", or a backend that stages through the host (gloo): graph / eager
+    # exchange + optimiser.  "auto" (default): captured on a communicator of ONE rank (LNERF_FORCE_DIST, where tests pin
+    # captured == eager bit for bit), NOT with more than one rank -- no recorded multi-rank run has shown the two forms
+    # equal yet (parity unpinned at N > 1); "true" / LNERF_GRAPH_COLLECTIVES=1 opt in (bench.py does so after a
+    # supervised pre-flight of exactly that comparison on the job's own ranks)
+    graph_collectives: str = "auto"
 
 
 @dataclass

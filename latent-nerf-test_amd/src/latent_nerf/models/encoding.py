@@ -90,6 +90,40 @@ def scatter_workspace(levels: GridLevels, m_host, device):
     return ws
 
 
+# Whether the level maxima at the head of a device's (shared) scatter workspace are known to be ZERO, and a counter of the
+# scatter calls issued through it from Python.  The workspace is one buffer per DEVICE, so this is tracked per device, not
+# per encoder: a second model -- or a backward through the same net outside the training step -- leaves its maxima in the
+# header, and a step that passes LNERF_SCATTER_CLEARED on the strength of its OWN previous call would scale with stale,
+# larger maxima (no overflow, but fixed-point precision drops and graph == eager is lost).  A captured hipGraph bakes the
+# flag in: whoever replays one compares scatter_workspace_epoch() with the value it noted at capture time and captures
+# again when a foreign call went through in between (Trainer.train()).
+_ws_state = {}   # str(device) -> [data_ptr of the workspace whose maxima are zero | None, epoch]
+
+
+def _ws(device):
+    return _ws_state.setdefault(str(device), [None, 0])
+
+
+def ws_mark_dirty(device):
+    st = _ws(device)
+    st[0], st[1] = None, st[1] + 1
+
+
+def ws_mark_clean(wst):
+    st = _ws(wst.device)
+    st[0], st[1] = wst.data_ptr(), st[1] + 1
+
+
+def ws_is_clean(wst):
+    return _ws(wst.device)[0] == wst.data_ptr()
+
+
+def scatter_workspace_epoch(device):
+    """(clean workspace pointer, number of scatter calls issued from Python on this device): changes whenever anybody
+    scatters through the device's workspace outside a graph replay."""
+    return tuple(_ws(device))
+
+
 _clear_bytes = {}
 
 
@@ -109,9 +143,10 @@ def grid_encode_backward(xyzs, bound, dfeat, levels: GridLevels, m_host, m_dev, 
     variant 0/1: global float atomics; 2: two-pass bucketed scatter (LDS reduction); 3: the same with packed
     8-byte records (values rounded to 17 mantissa bits)."""
     ws, ws_bytes = None, 0
-    if variant >= 2:
+    if (variant & 0xFF) >= 2:
         wst = scatter_workspace(levels, m_host, xyzs.device)
         ws, ws_bytes = _p(wst), wst.numel()
+        ws_mark_dirty(xyzs.device)      # (this call leaves its level maxima in the shared workspace)
     _b.call("lnerf_grid_encode_backward", _chk(xyzs, "xyzs"), float(bound), _chk(dfeat, "dfeat"), _b.F32,
             levels.num_levels, levels.level_dim, levels.c_offsets, levels.c_scales, levels.c_res, int(m_host),
             _chk(m_dev, "m_dev", torch.int32, allow_none=True), int(level_stride), _chk(dtable, "dtable"),
@@ -137,7 +172,6 @@ class FusedTableUpdate:
         # parameters, ticks the step counter and leaves the scatter's level maxima zero for the next step
         self.tail = False
         self.pending_tail = None            # (levels, m_host, variant, scatter workspace, mlp workspace, precision, out_dim)
-        self.clean_ws = None                # data_ptr of the scatter workspace whose level maxima are known to be zero
         # the armed backward closed the step itself (grid_encode_backward_adam_tail): slab sums, the MLP's Adam step, the
         # tick of the step counter all ran inside the scatter's pass 2
         self.closed = False
@@ -168,6 +202,7 @@ def grid_encode_backward_adam(xyzs, bound, dfeat, encoder, m_host, m_dev, level_
             _p(wst), wst.numel(), _p(table), _p(fu.exp_avg), _p(fu.exp_avg_sq), _p(shadow), fu.lr, b1, b2, fu.eps,
             opt.step_no + 1, _p(opt.step_dev), float(opt.grad_scale), _stream())
     fu.applied += 1
+    ws_mark_dirty(xyzs.device)
 
 
 def grid_encode_backward_adam_tail(xyzs, bound, dfeat, encoder, m_host, m_dev, level_stride, variant, mlp_ws, precision,
@@ -190,7 +225,7 @@ def grid_encode_backward_adam_tail(xyzs, bound, dfeat, encoder, m_host, m_dev, l
             _b.TAIL_TICK | _b.TAIL_CLEAR_SCATTER, _stream())
     fu.applied += 1
     fu.closed = True                 # optimizer.step() has nothing left to launch
-    fu.clean_ws = wst.data_ptr()     # (level maxima zero again when the launch ends)
+    ws_mark_clean(wst)               # (level maxima zero again when the launch ends)
 
 
 class GradSink:
@@ -232,6 +267,7 @@ def grid_encode_backward_bf16(xyzs, bound, dfeat, encoder, m_host, m_dev, level_
     if variant < 2:
         raise _b.LnerfError("the bf16 gradient output needs the bucketed scatter (variant 2 or 3)")
     wst = scatter_workspace(levels, m_host, xyzs.device)
+    ws_mark_dirty(xyzs.device)
     if sink.groups:   # pipelined: pass 1 now, pass 2 per level group inside GradSync.allreduce_pipelined()
         _b.call("lnerf_grid_scatter_bin", _chk(xyzs, "xyzs"), float(bound), _chk(dfeat, "dfeat"), _b.F32,
                 levels.num_levels, levels.level_dim, levels.c_offsets, levels.c_scales, levels.c_res, int(m_host),
@@ -290,8 +326,6 @@ class _GridEncode(torch.autograd.Function):
                                       variant)
             return (None,) * 12
         dtable = torch.zeros(shape, device=dev, dtype=torch.float32)
-        if enc is not None and enc.fused_update is not None:
-            enc.fused_update.clean_ws = None     # (this call leaves its level maxima in the shared workspace)
         grid_encode_backward(xyzs, bound, dfeat, levels, m_host, m_dev if ctx.has_mdev else None, level_stride,
                              dtable, variant)
         return None, dtable, None, None, None, None, None, None, None, None, None, None

@@ -18,10 +18,10 @@ class NeRFType(Enum):
     latent_tune = "latent_tune"
 
 
-def pose_from_angles(theta, phi, radius, target=(0.0, 0.0, 0.0)):
-    """Camera-to-world [4,4] float32 (CPU tensor).  Columns: right, down, forward, eye.
-    Plain double arithmetic on Python floats (this runs once per training step on the host: the numpy form of the same
-    formulas -- cross, norm, eye -- cost 0.2 ms per call in array overheads)."""
+def pose_values(theta, phi, radius, target=(0.0, 0.0, 0.0)):
+    """The 16 values (row-major) of the camera-to-world matrix.  Columns: right, down, forward, eye.
+    Plain double arithmetic on Python floats (this runs once per view and training step on the host: the numpy form
+    of the same formulas -- cross, norm, eye -- cost 0.2 ms per call in array overheads)."""
     st, ct = math.sin(theta), math.cos(theta)
     ex, ey, ez = radius * st * math.sin(phi), radius * ct, radius * st * math.cos(phi)
     fx, fy, fz = target[0] - ex, target[1] - ey, target[2] - ez
@@ -35,8 +35,12 @@ def pose_from_angles(theta, phi, radius, target=(0.0, 0.0, 0.0)):
     rx, ry, rz = rx / n, ry / n, rz / n
     # down = fwd x right
     dx, dy, dz = fy * rz - fz * ry, fz * rx - fx * rz, fx * ry - fy * rx
-    return torch.tensor([[rx, dx, fx, ex], [ry, dy, fy, ey], [rz, dz, fz, ez], [0.0, 0.0, 0.0, 1.0]],
-                        dtype=torch.float32)
+    return (rx, dx, fx, ex, ry, dy, fy, ey, rz, dz, fz, ez, 0.0, 0.0, 0.0, 1.0)
+
+
+def pose_from_angles(theta, phi, radius, target=(0.0, 0.0, 0.0)):
+    """Camera-to-world [4,4] float32 (CPU tensor) of pose_values()."""
+    return torch.tensor(pose_values(theta, phi, radius, target), dtype=torch.float32).view(4, 4)
 
 
 def intrinsics_from_fov(fovy_deg, H, W):

@@ -127,8 +127,7 @@ class _HashMLPField(torch.autograd.Function):
                     _chk(dsigmas, "dsigmas"), _chk(drgbs, "drgbs"), _p(dfeat), None, None, None, None, None, None, 0,
                     _p(workspace), workspace.numel(), precision | _b.MLP_DEFER_REDUCE, None, 0, _stream())
             fu.take()
-            flags = _b.SCATTER_CLEARED if fu.clean_ws == wst.data_ptr() else 0
-            fu.clean_ws = None
+            flags = _b.SCATTER_CLEARED if E.ws_is_clean(wst) else 0
             if fu.inline_tail:   # the scatter's pass 2 closes the step: no launch behind it
                 E.grid_encode_backward_adam_tail(xyzs, bound, dfeat, encoder, m_host, m_dev, level_stride, sv | flags,
                                                  workspace, base_precision, out_dim)
@@ -144,8 +143,6 @@ class _HashMLPField(torch.autograd.Function):
             wst = E.scatter_workspace(encoder.levels, m_host, dev)
             clear_bytes = E.scatter_clear_bytes(encoder.levels, m_host)
             clear_ptr, sv = _p(wst), sv | _b.SCATTER_CLEARED
-            if fu is not None:
-                fu.clean_ws = None
         _b.call("lnerf_mlp_backward", _p(feat), fdt, int(level_stride), _p(xyzs), _p(w1), _p(b1), _p(w2), _p(b2),
                 _p(w3), _p(b3), out_dim, float(blob_scale), float(blob_std), int(m_host), _p(m_dev), _p(sigmas),
                 _chk(dsigmas, "dsigmas"), _chk(drgbs, "drgbs"), _p(dfeat), *[_p(g) for g in grads], 0, _p(workspace),

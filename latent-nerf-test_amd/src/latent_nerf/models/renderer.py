@@ -94,7 +94,6 @@ class NeRFRenderer(nn.Module):
         self._ray_slots = [None, None]    # ray buffers of the camera form of prepare_rays
         self._march_key = None
         self._budget = None       # ((N, max_steps), capacity) derived from observed marches
-        self._m_peak = None       # device int32 [3]: largest (M, live rays, dropped rays) of any march since the last budget update
         self.mean_count = 0
         self._noise_counter = None
         self._occ_scratch = None
@@ -168,10 +167,13 @@ class NeRFRenderer(nn.Module):
         The upstream renderer sizes its buffers from a running `mean_count` the same way, but reads the counter
         back every step."""
         m = self._march
-        if m is None or self._m_peak is None or self.cfg.max_samples > 0:
+        if m is None or self.cfg.max_samples > 0:
             return None
-        peak, _live, dropped = (int(v) for v in self._m_peak.tolist())   # (ONE read-back; window maxima, not the last march)
-        self._m_peak.zero_()
+        # window maxima, not the last march: the march itself keeps them in word 3 of its counter (no launch per step)
+        peak, dropped = 0, 0
+        for slot in {id(s): s for s in self._march_slots + [m] if s is not None}.values():
+            pk, dr = slot.take_peak()
+            peak, dropped = max(peak, pk), dropped + int(dr)
         key, cap = self._march_key, m.capacity
         self.mean_count = peak if self.mean_count == 0 else int(0.9 * self.mean_count + 0.1 * peak)
         want = -(-max(int(1.5 * peak), 1) // 65536) * 65536
@@ -247,11 +249,7 @@ class NeRFRenderer(nn.Module):
             bg = self._bg_tensor(bg_color, rays_d, N, self.img_dims)   # the background net reads the generated directions
         self._march_slots[slot] = march
         self._march = march
-        if self._march_key != (N, int(max_steps)) or self._m_peak is None:
-            self._march_key = (N, int(max_steps))
-            self._m_peak = torch.zeros(3, device=rays_o.device, dtype=torch.int32)
-        if self.cfg.max_samples <= 0:   # running maxima of (M, live, dropped), on the device (one tiny launch, no host sync)
-            torch.maximum(self._m_peak, march.counter[0:3], out=self._m_peak)
+        self._march_key = (N, int(max_steps))
         return PreparedRays(march, bg, prefix, N, cap)
 
     def run_cuda(self, rays_o, rays_d, dt_gamma=0.0, bg_color=None, perturb=False, force_all_rays=False,

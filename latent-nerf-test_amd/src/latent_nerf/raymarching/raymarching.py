@@ -109,13 +109,21 @@ def packbits(grid, thresh, bitfield=None, mean_dev=None):
 
 # ------------------------------------------------------------------------------ H4
 class MarchResult:
-    """Capacity-sized sample buffers of one training march.  `counter` (int32 [4], device) holds
-    [M, live rays, rays dropped for capacity, 0]; nothing here forces a host sync."""
+    """Capacity-sized sample buffers of one training march.  `counter` (int32 [4 + scratch], device) holds
+    [M, live rays, rays dropped for capacity, running peak of M | (dropped ? 2^30 : 0) over the marches into these
+    buffers]; nothing here forces a host sync."""
     __slots__ = ("xyzs", "dirs", "deltas", "rays", "counter", "capacity")
 
     def __init__(self, xyzs, dirs, deltas, rays, counter, capacity):
         self.xyzs, self.dirs, self.deltas, self.rays, self.counter, self.capacity = (xyzs, dirs, deltas, rays, counter,
                                                                                    capacity)
+
+    def take_peak(self):
+        """(largest M, any ray dropped) of the marches into these buffers since the last call: ONE read-back
+        (synchronises), then the word is cleared."""
+        w = int(self.counter[3].item())
+        self.counter[3:4].zero_()
+        return w & ((1 << 30) - 1), bool(w >> 30)
 
     def num_samples(self) -> int:
         """Host read-back of M (synchronises)."""
@@ -168,8 +176,9 @@ def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars,
         dirs = torch.empty(capacity, 3, device=dev, dtype=torch.float32)
         deltas = torch.empty(capacity, 2, device=dev, dtype=torch.float32)
         rays = torch.empty(N, 3, device=dev, dtype=torch.int32)
-        # (four totals + the scratch the two-launch form of the march keeps its per-ray counts in)
-        counter = torch.empty(int(_b.get_lib().lnerf_march_counter_len(N)), device=dev, dtype=torch.int32)
+        # (four totals + the scratch the two-launch form of the march keeps its per-ray counts in; ZEROED: word 3 is a
+        # running peak the library only ever raises -- MarchResult.take_peak() reads and clears it)
+        counter = torch.zeros(int(_b.get_lib().lnerf_march_counter_len(N)), device=dev, dtype=torch.int32)
     if camera is not None:
         if aabb is None or nears is not None:
             raise ValueError("march_rays_train(camera=...) needs aabb= and no nears/fars")

@@ -59,7 +59,13 @@ def init_distributed():
     dev = torch.device("cuda", local_dev)
     if (world > 1 or force_exchange()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
+        if "MASTER_PORT" not in os.environ:
+            # a launcher (torch.distributed.run, training/launch.spawn_ranks) picks the port for a job of several ranks;
+            # only a forced one-rank exchange gets here without one: any free port serves
+            if world > 1:
+                raise RuntimeError("WORLD_SIZE > 1 without MASTER_PORT: start the ranks with a launcher")
+            from .launch import free_port
+            os.environ["MASTER_PORT"] = str(free_port())
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
         if backend == "nccl":
@@ -94,6 +100,27 @@ def pose_generator(seed: int, step: int, view_index: int) -> torch.Generator:
     g = torch.Generator(device="cpu")
     g.manual_seed((seed * 1_000_003 + step) * 4099 + view_index)
     return g
+
+
+_M64 = (1 << 64) - 1
+
+
+def pose_uniforms(seed: int, step: int, view_index: int, n: int = 4):
+    """n uniforms in [0, 1) (24 bits each: exact in float32) of (seed, step, view): the counter-based form of
+    pose_generator -- a 64-bit mix (splitmix64's finaliser) of the three counters in plain integer arithmetic, ~2 us
+    where seeding a torch.Generator and drawing from it costs ~40 us of the trainer's per-step host time.  Every rank
+    can reproduce any view's pose without communication; W ranks render the same set of views as one."""
+    out = []
+    base = (int(seed) * 0x9E3779B97F4A7C15 + int(step) * 0xD1B54A32D192ED03 + int(view_index) * 0x8CB92BA72F3D8DD7) & _M64
+    for j in range(n):
+        x = (base + (j + 1) * 0x9E3779B97F4A7C15) & _M64
+        x ^= x >> 30
+        x = (x * 0xBF58476D1CE4E5B9) & _M64
+        x ^= x >> 27
+        x = (x * 0x94D049BB133111EB) & _M64
+        x ^= x >> 31
+        out.append((x >> 40) / 16777216.0)
+    return out
 
 
 class GradSync:

@@ -19,14 +19,16 @@ class NeRFDataset:
         self.training = type in ("train", "all")
         self.gen = torch.Generator().manual_seed(seed)
 
-    def sample_pose(self, index=0, generator=None):
+    def sample_pose(self, index=0, generator=None, uniforms=None):
+        """uniforms: four numbers in [0, 1) to use instead of a draw from `generator` (the trainer's counter-based
+        per-(step, view) stream, distributed.pose_uniforms)."""
         cfg = self.cfg
         g = self.gen if generator is None else generator
         if self.training and getattr(cfg, "train_pose", None) is not None:
             th, ph, radius, fov = [float(v) for v in cfg.train_pose]
             theta, phi = math.radians(th), math.radians(ph)
         elif self.training:
-            u = torch.rand(4, generator=g)
+            u = uniforms if uniforms is not None else torch.rand(4, generator=g).tolist()
             radius = float(cfg.radius_range[0] + u[0] * (cfg.radius_range[1] - cfg.radius_range[0]))
             theta = float(math.radians(0.0) + u[1] * (math.radians(150.0) - math.radians(0.0)))
             phi = float(u[2] * math.radians(360.0))
@@ -39,9 +41,9 @@ class NeRFDataset:
         theta = max(theta, 1e-3)
         # (the reference's callers pass already-converted radians for the two cone angles, src/utils.py:8-27 as called
         # from src/latent_paint/training/views_dataset.py:12-22; scalar form of get_view_direction for the one view)
-        dirs = torch.tensor([view_direction_index(theta, phi, np.deg2rad(cfg.angle_overhead),
-                                                  np.deg2rad(cfg.angle_front))], dtype=torch.long)
-        return {"theta": theta, "phi": phi, "radius": radius, "fov": fov, "dir": dirs}
+        di = view_direction_index(theta, phi, np.deg2rad(cfg.angle_overhead), np.deg2rad(cfg.angle_front))
+        return {"theta": theta, "phi": phi, "radius": radius, "fov": fov, "dir": torch.tensor([di], dtype=torch.long),
+                "dir_index": int(di)}
 
     def collate(self, index=0, generator=None, device_pose=True):
         """device_pose=False: the pose stays on the host (the trainer's captured step uploads pose + intrinsics itself,

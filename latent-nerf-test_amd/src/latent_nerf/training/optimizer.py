@@ -23,11 +23,12 @@ class FusedAdam:
         mlp: the NeRFNetwork whose w1 / w2 / w3 are in the groups (bf16 MLP): the multi-tensor launch then also writes
         the updated weights into the network's bf16 weight fragments (lnerf_adam_step_multi_shadow), and the network's
         forward stops rebuilding them every step (one dispatch less).
-        tail (default: on whenever fuse_table_update and mlp are given): an ARMED step ends with ONE launch
-        (lnerf_step_tail) that runs the scatter's finishing pass, sums the MLP's gradient slabs and steps its six
-        tensors straight from the sums, advances the device step counter and leaves the scatter's level maxima clean for
-        the next step -- instead of the slab-sum launch inside the backward pass, the scatter's finishing launch and the
-        multi-tensor Adam launch.  The six tensors then never get a `.grad` on armed steps."""
+        tail (default: on whenever fuse_table_update and mlp are given): an ARMED step is closed by the scatter's own pass
+        2 (lnerf_grid_encode_backward_adam_tail: extra workgroups of that launch sum the MLP's gradient slabs, step its
+        six tensors straight from the sums, advance the device step counter and leave the scatter's level maxima clean
+        for the next step) -- or, when other small parameters must be stepped first, by ONE launch behind their Adam
+        launch (lnerf_step_tail: the same slab blocks + tick + clearing; pass 2 finishes its sliced buckets itself
+        either way).  The six tensors then never get a `.grad` on armed steps."""
         self.betas, self.eps = betas, eps
         self.encoder = encoder
         self.step_no = 0
@@ -242,7 +243,9 @@ class FusedAdam:
                 t["p"], t["m"], t["v"], float(t["lr"]), t["maps"], b1, b2, self.eps, self.step_no, _p(self.step_dev),
                 grad_scale, flags, _stream())
         fu.pending_tail = None
-        fu.clean_ws = wst.data_ptr() if flags & _b.TAIL_CLEAR_SCATTER else None
+        from ..models import encoding as E
+        if flags & _b.TAIL_CLEAR_SCATTER:
+            E.ws_mark_clean(wst)
 
     def note_replayed_step(self):
         """A captured graph that contains step() was replayed: the device counter advanced, the host mirror follows

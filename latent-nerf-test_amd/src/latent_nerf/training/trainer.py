@@ -60,13 +60,18 @@ class Trainer:
             torch.cuda.manual_seed(cfg.optim.seed + 7919 * (self.rank + 1))
         self.diffusion = guidance if guidance is not None else self.init_diffusion()
         self.text_z = self.calc_text_embeddings()
-        n_views = len(D.views_for_rank(max(cfg.optim.views_per_step, self.world), self.rank, self.world))
+        # the views of a step that this rank renders -- as ONE batch (render.batch_size of the reference's fork,
+        # src/latent_paint_mesh/configs/train_config.py:32, src/latent_paint_mesh/training/views_dataset.py:98): one
+        # march / gather / MLP / composite / backward over all of their rays, one optimiser step
+        self.views = D.views_for_rank(max(cfg.optim.views_per_step, self.world), self.rank, self.world)
+        n_views = len(self.views)
         self.exchange = D.exchange_active()     # more than one rank, or LNERF_FORCE_DIST on one
-        fuse = bool(cfg.optim.fuse_table_update) and not self.exchange and n_views == 1
+        fuse = bool(cfg.optim.fuse_table_update) and not self.exchange
         # capturable: the step counter lives on the device, so that the captured step (optim.graph_step) and the eager
         # step run the very same kernels with the very same bias corrections
         self.optimizer = FusedAdam(self.nerf.get_params(cfg.optim.lr), betas=(0.9, 0.99), eps=1e-15,
                                    encoder=self.nerf.encoder, fuse_table_update=fuse, mlp=self.nerf, capturable=True)
+        self.optimizer.grad_scale = 1.0 / (n_views * self.world)   # the step's gradient is the MEAN over its views
         # the whole loop (eager steps, captures, replays, collectives) runs on ONE non-default stream: autograd pins a
         # parameter's gradient accumulation to the stream it first ran on, and the legacy default stream cannot capture.
         # Code that back-propagates through `self.nerf` outside train() must do so under
@@ -80,11 +85,18 @@ class Trainer:
         bf16 = cfg.render.precision("mlp_precision") == "bf16"
         self.grad_sync = D.GradSync([self.nerf.encoder.embeddings], small,
                                     transport=torch.bfloat16 if bf16 else torch.float32)
-        self.pipelined = self.exchange and bf16 and n_views == 1
-        # the exchange goes into the captured step where the collectives can be captured (RCCL; not gloo's host staging)
-        self.capture_exchange = (self.exchange and bool(getattr(cfg.optim, "graph_collectives", True))
-                                 and D.backend_name() == "nccl"
-                                 and os.environ.get("LNERF_GRAPH_COLLECTIVES", "1") != "0")
+        self.pipelined = self.exchange and bf16
+        # The exchange goes into the captured step where the collectives can be captured (RCCL; not gloo's host staging)
+        # AND the form has been seen to reproduce the eager exchange: optim.graph_collectives = "auto" (default) takes it
+        # for a communicator of ONE rank (LNERF_FORCE_DIST; tests/test_gpu_distributed.py pins captured == eager bit for
+        # bit there) and leaves it OFF for world > 1, where no recorded multi-rank run has shown that yet -- PARITY
+        # UNPINNED AT N > 1; "true" / LNERF_GRAPH_COLLECTIVES=1 opt in (bench.py does, after a supervised pre-flight of
+        # exactly that comparison on the job's own ranks), "false" / LNERF_GRAPH_COLLECTIVES=0 opt out.
+        gc = getattr(cfg.optim, "graph_collectives", "auto")
+        gc = {True: "true", False: "false"}.get(gc, str(gc).lower())
+        env = os.environ.get("LNERF_GRAPH_COLLECTIVES", "")
+        want = env == "1" or (env != "0" and (gc == "true" or (gc == "auto" and self.world == 1)))
+        self.capture_exchange = bool(self.exchange and want and D.backend_name() == "nccl")
         if self.pipelined:
             self.grad_sync.attach_sink(self.nerf.encoder, pipeline_groups=max(1, cfg.optim.exchange_groups))
         self.dataloaders = self.init_dataloaders()
@@ -144,16 +156,21 @@ class Trainer:
 
     # ------------------------------------------------------------------ one optimisation step
     def _render_train(self, camera):
+        """camera = (poses [B,4,4], intrinsics, H, W): B views as one batch -> (render dict, latents [B,C,H,W])."""
         out = self.nerf.render(None, None, staged=False, perturb=True, bg_color=None, force_all_rays=True, camera=camera)
         H, W = int(camera[2]), int(camera[3])
-        pred = out["image"].reshape(1, H, W, -1).permute(0, 3, 1, 2).contiguous()
+        pred = out["image"].reshape(-1, H, W, out["image"].shape[-1]).permute(0, 3, 1, 2).contiguous()
         return out, pred
 
     def _guidance_grad(self, pred, dirs):
-        text_z = self.text_z[int(dirs[0])] if isinstance(self.text_z, list) else self.text_z
+        """dirs: the views' direction buckets (host ints).  Direction-specific prompts: one guidance call per view."""
         if isinstance(self.diffusion, SyntheticGuidance):
-            return self.diffusion.train_step(text_z, pred, dirs=dirs)
-        return self.diffusion.train_step(text_z, pred)
+            return self.diffusion.train_step(self.text_z, pred, dirs=torch.as_tensor(dirs, dtype=torch.long))
+        if not isinstance(self.text_z, list):
+            return self.diffusion.train_step(self.text_z, pred)
+        if pred.shape[0] == 1:
+            return self.diffusion.train_step(self.text_z[int(dirs[0])], pred)
+        return torch.cat([self.diffusion.train_step(self.text_z[int(d)], pred[i:i + 1]) for i, d in enumerate(dirs)])
 
     def _backward(self, out, pred, grad):
         """SDS: d(loss)/d(pred) = grad (src/latent_paint_mesh/training/trainer.py:657-658).  The sparsity term's gradient
@@ -185,7 +202,7 @@ class Trainer:
             out = self.nerf.render(data["rays_o"], data["rays_d"], staged=False, perturb=True, bg_color=None,
                                    force_all_rays=True)
             pred = out["image"].reshape(1, H, W, -1).permute(0, 3, 1, 2).contiguous()
-        grad = self._guidance_grad(pred, data["dir"])
+        grad = self._guidance_grad(pred, [int(d) for d in data["dir"]])
         self._backward(out, pred, grad)
         return pred, out
 
@@ -200,99 +217,153 @@ class Trainer:
             self.grad_sync.allreduce()
             self.optimizer.step(grad_scale=scale)
 
-    # ---- the captured step (optim.graph_step): graph F (render) / eager guidance / graph B (backward [+ optimiser])
-    def _graph_ready(self, n_views):
+    # ---- one step on this rank's views: camera upload -> batched render -> guidance -> backward -> exchange -> optimiser
+    def _graph_ready(self):
         r = self.cfg.render
-        return (bool(getattr(self.cfg.optim, "graph_step", True)) and n_views == 1 and self.nerf.cuda_ray
-                and r.noise_seed is not None and self.nerf.bg_radius <= 0)
+        return (bool(getattr(self.cfg.optim, "graph_step", True)) and self.nerf.cuda_ray and r.noise_seed is not None
+                and self.nerf.bg_radius <= 0)
+
+    RING = 64
+
+    def _static_buffers(self):
+        """Static device buffers the step reads its views from (eager and captured steps alike), and the ring of pinned
+        upload slots: the host runs steps ahead of the GPU, a slot is rewritten only after the copy that read it has
+        executed (event per slot).  Layout of a slot / of `cam`, k views: [k x 16 pose | k x 4 intrinsics | k view
+        buckets (int32 bit patterns)]."""
+        if self._static is None:
+            k = len(self.views)
+            r = self.cfg.render
+            host = torch.zeros(self.RING, 21 * k, dtype=torch.float32).pin_memory()
+            cam = torch.zeros(21 * k, device=self.device)
+            self._static = {"k": k, "host": host, "host_np": host.numpy(), "host_i32": host.view(torch.int32).numpy(),
+                            "events": [None] * self.RING, "cam": cam,
+                            "poses": cam[:16 * k].view(k, 4, 4), "intr": cam[16 * k:20 * k].view(k, 4),
+                            "dirs": cam[20 * k:21 * k].view(torch.int32),
+                            "grad": torch.zeros(k, self.nerf.img_dims, r.train_h, r.train_w, device=self.device)}
+        return self._static
+
+    def _upload_views(self):
+        """This step's views -- poses from the counter-based per-(step, view) stream every rank can reproduce,
+        distribution of src/latent_paint/training/views_dataset.py:9-22 -- written into the next pinned slot with plain
+        Python arithmetic (no torch op per view) and sent to the static buffers with ONE asynchronous copy.  Returns the
+        views' direction buckets (host ints)."""
+        from ..models.nerf_utils import intrinsics_from_fov, pose_values
+        st = self._static_buffers()
+        k, ds = st["k"], self.dataloaders["train"]
+        slot = self.train_step % self.RING
+        if st["events"][slot] is not None:
+            st["events"][slot].synchronize()
+        row, row_i = st["host_np"][slot], st["host_i32"][slot]
+        dirs = []
+        for j, v in enumerate(self.views):
+            p = ds.sample_pose(0, uniforms=D.pose_uniforms(self.cfg.optim.seed, self.train_step, v))
+            row[16 * j:16 * j + 16] = pose_values(p["theta"], p["phi"], p["radius"])
+            row[16 * k + 4 * j:16 * k + 4 * j + 4] = intrinsics_from_fov(p["fov"], ds.H, ds.W)
+            row_i[20 * k + j] = p["dir_index"]
+            dirs.append(p["dir_index"])
+        st["cam"].copy_(st["host"][slot], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st["events"][slot] = ev
+        return dirs
+
+    def _camera(self):
+        st, r = self._static, self.cfg.render
+        return (st["poses"], st["intr"], r.train_h, r.train_w)
+
+    def _eager_step(self):
+        dirs = self._upload_views()
+        out, pred = self._render_train(self._camera())
+        grad = self._guidance_grad(pred, dirs)
+        self.optimizer.arm()          # no exchange: the scatter applies the table's Adam step (no-op otherwise)
+        self._backward(out, pred, grad)
+        self._exchange_and_step(len(self.views))
+        return pred, out
+
+    def _all_ranks(self, failed):
+        """True on every rank when `failed` is true on ANY rank (a collective decision: ranks must not end up on
+        different step forms).  Eager, outside any capture."""
+        if not (self.exchange and self.world > 1):
+            return bool(failed)
+        import torch.distributed as dist
+        flag = torch.tensor([1 if failed else 0], device=self.device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return bool(int(flag.item()))
 
     def _capture(self):
-        """Capture the step for the current sample capacity.  Runs no kernel: the training state does not advance."""
+        """Capture the step for the current sample capacity: graph F (render) / eager guidance / graph B (backward,
+        exchange where it can be captured, optimiser) -- or ONE graph when the guidance is capturable too.  Runs no
+        kernel: the training state does not advance."""
         from .graph_step import GraphedRenderStep
-        r = self.cfg.render
-        C, H, W = self.nerf.img_dims, r.train_h, r.train_w
-        if self._static is None:
-            self._static = {"pose": torch.zeros(1, 4, 4, device=self.device), "intr": torch.zeros(1, 4, device=self.device),
-                            "grad": torch.zeros(1, C, H, W, device=self.device),
-                            # ring of pinned upload slots: the host runs steps ahead of the GPU, a slot is rewritten
-                            # only after the copy that read it has executed (event per slot)
-                            # (16 pose + 4 intrinsics + the view bucket as an int32 bit pattern)
-                            "host": torch.zeros(64, 21, dtype=torch.float32).pin_memory(), "events": [None] * 64,
-                            "cam": torch.zeros(21, device=self.device)}
-        st = self._static
+        st = self._static_buffers()
         solo = not self.exchange
         inline = self.capture_exchange
         opt = self.optimizer
         keep = (opt.step_no, self.nerf.local_step)
+        n_views = len(self.views)
 
         def forward():
-            # (one 80-byte upload per step lands in `cam`; the two views below alias it)
-            return self._render_train((st["cam"][:16].view(1, 4, 4), st["cam"][16:20].view(1, 4), H, W))
+            return self._render_train(self._camera())
 
         def backward(out, pred):
             if solo:
-                opt.arm()                 # one view, one process: the scatter applies the table's Adam step
+                opt.arm()                 # one process: the scatter applies the table's Adam step
             self._backward(out, pred, st["grad"])
-            if solo:
-                opt.step(grad_scale=1.0)
-            elif inline:
-                self._exchange_and_step(1)   # collectives and the optimiser's waits on them are captured
+            if solo or inline:
+                self._exchange_and_step(n_views)   # (inline: collectives and the optimiser's waits on them are captured)
 
         # a guidance that is itself capturable (the synthetic one) goes INSIDE the graph: one launch per step
         self._whole = bool(getattr(self.diffusion, "capturable", False)) and hasattr(self.diffusion, "train_step_device") \
             and bool(getattr(self.cfg.optim, "graph_guidance", True))
         if self._whole:
             from .graph_step import GraphedWholeStep
-            dir_dev = st["cam"][20:21].view(torch.int32)
 
             def whole():
                 out, pred = forward()
-                grad = self.diffusion.train_step_device(pred, dir_dev)
+                grad = self.diffusion.train_step_device(pred, st["dirs"])
                 if solo:
                     opt.arm()
                 self._backward(out, pred, grad)
-                if solo:
-                    opt.step(grad_scale=1.0)
-                elif inline:
-                    self._exchange_and_step(1)
+                if solo or inline:
+                    self._exchange_and_step(n_views)
                 return out, pred
 
             build = lambda: GraphedWholeStep(whole, list(self.nerf.parameters()), self.stream)
         else:
             build = lambda: GraphedRenderStep(forward, backward, list(self.nerf.parameters()), self.stream)
+        err = None
         try:
-            self._gstep = build()
+            gstep = build()
         except RuntimeError as e:
-            opt.step_no, self.nerf.local_step = keep
-            if not inline:
-                raise
-            # a collective the backend cannot capture (every rank takes the same turn): exchange + optimiser stay eager
-            self.log("capture with collectives failed (%s): the exchange stays outside the graphs" % str(e).splitlines()[0])
+            err, gstep = e, None
             torch.cuda.synchronize()
+        opt.step_no, self.nerf.local_step = keep   # host-side counters the captured Python advanced
+        # a collective the backend cannot capture: the ranks decide TOGETHER (a capture runs nothing, so a failure is
+        # local and synchronous; the all-reduce below is an ordinary eager collective every rank reaches)
+        if inline and self._all_ranks(err is not None):
+            self.log("capture with collectives failed on some rank (%s): the exchange stays outside the graphs on all"
+                     % (str(err).splitlines()[0] if err is not None else "another rank"))
             self.capture_exchange = False
             return self._capture()
-        opt.step_no, self.nerf.local_step = keep   # host-side counters the captured Python advanced
+        if err is not None:
+            raise err
+        self._gstep = gstep
         self._gstep_capacity = self.nerf._march.capacity
+        self._gstep_ws = self._scatter_ws_state()
         self.graph_stats["captures"] += 1
 
-    def _graphed_step(self, data):
+    def _scatter_ws_state(self):
+        from ..models import encoding as E
+        return E.scatter_workspace_epoch(self.device)
+
+    def _graphed_step(self):
         st, g = self._static, self._gstep
-        slot = self.train_step % 64
-        if st["events"][slot] is not None:
-            st["events"][slot].synchronize()
-        host = st["host"][slot]
-        host[:16] = data["pose"].reshape(-1)
-        host[16:20] = torch.tensor(data["camera"][1], dtype=torch.float32)
-        host[20:21].view(torch.int32)[0] = int(data["dir"][0])
-        st["cam"].copy_(host, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        st["events"][slot] = ev
+        dirs = self._upload_views()
         if self._whole:
             grads = g.replay()
         else:
             out, pred = g.forward()
-            st["grad"].copy_(self._guidance_grad(pred, data["dir"]))
+            st["grad"].copy_(self._guidance_grad(pred, dirs))
             grads = g.backward()
         self.nerf.local_step += 1
         if not self.exchange or self.capture_exchange:
@@ -300,7 +371,7 @@ class Trainer:
         else:   # exchange outside the graphs: the captured backward left this rank's gradients; the rest is eager
             for p, gr in zip(g.params, grads):
                 p.grad = gr
-            self._exchange_and_step(1)
+            self._exchange_and_step(len(self.views))
             for p in g.params:
                 p.grad = None
         self.graph_stats["replayed_steps"] += 1
@@ -308,9 +379,7 @@ class Trainer:
     def train(self, iters=None):
         iters = self.cfg.optim.iters if iters is None else iters
         self.nerf.train()
-        views = D.views_for_rank(max(self.cfg.optim.views_per_step, self.world), self.rank, self.world)
-        ds = self.dataloaders["train"]
-        use_graph = self._graph_ready(len(views))
+        use_graph = self._graph_ready()
         eager_left = 2          # eager steps before the first capture (lazy allocations, workspace sizes, autograd streams)
         self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
@@ -320,22 +389,20 @@ class Trainer:
                     self.nerf.update_extra_state()
                     if self._gstep is not None and self.nerf._capacity(*self.nerf._march_key) != self._gstep_capacity:
                         self._gstep, eager_left = None, 1   # the sample budget moved: new buffers, capture again
+                if self._gstep is not None and self._scatter_ws_state() != self._gstep_ws:
+                    # somebody else scattered through this device's shared workspace since the last replay (a second
+                    # model, a backward through this net outside train()): the captured step assumes the level maxima
+                    # it left clean -- capture again (the new capture starts from a cleared header)
+                    self._gstep, eager_left = None, 1
                 if use_graph and self._gstep is None and eager_left <= 0:
                     self._capture()
                 if use_graph and self._gstep is not None:
-                    data = ds.collate(0, generator=D.pose_generator(self.cfg.optim.seed, self.train_step, views[0]),
-                                      device_pose=False)
-                    self._graphed_step(data)
+                    self._graphed_step()
                 else:
                     eager_left -= 1
                     self.graph_stats["eager_steps"] += 1
                     self.optimizer.zero_grad()
-                    for v in views:
-                        data = ds.collate(0, generator=D.pose_generator(self.cfg.optim.seed, self.train_step, v))
-                        if len(views) == 1:
-                            self.optimizer.arm()   # one view, one process: the scatter applies the table's Adam step
-                        self.train_render(data)
-                    self._exchange_and_step(len(views))
+                    self._eager_step()
                 if self.train_step % self.cfg.log.save_interval == 0:
                     self.save_checkpoint(full=True)
                     self.evaluate(self.dataloaders["val"], self.eval_renders_path)
@@ -395,7 +462,7 @@ class Trainer:
             return None
         name = "step_%06d" % self.train_step
         state = {"train_step": self.train_step, "checkpoints": self.past_checkpoints,
-                 "model": self.nerf.state_dict()}
+                 "model": self.nerf.state_dict(), "table_layout": self._table_layout()}
         if full:
             state["optimizer"] = self.optimizer.state_dict()
         file_path = "%s.pth" % name
@@ -405,6 +472,11 @@ class Trainer:
             old.unlink(missing_ok=True)
         torch.save(state, self.ckpt_path / file_path)
         return self.ckpt_path / file_path
+
+    def _table_layout(self):
+        lv = self.nerf.encoder.levels
+        return {"gridtype": str(lv.gridtype), "offsets": [int(o) for o in lv.offsets],
+                "resolutions": [int(r) for r in lv.resolutions]}
 
     def load_checkpoint(self, checkpoint=None, model_only=False):
         if checkpoint is None:
@@ -417,6 +489,15 @@ class Trainer:
         if "model" not in state:
             self.nerf.load_state_dict(state)
             return
+        # the row layout of the hashed levels is part of what the table MEANS: a `blocked` table loaded into a `hash`
+        # model has the right shape and renders scrambled features (the Adam moments likewise)
+        have, want = state.get("table_layout"), self._table_layout()
+        if have is not None and have != want:
+            raise ValueError("checkpoint %s holds a hash table laid out as %s; this model reads %s (render.gridtype / "
+                             "level table differ): tables are not interchangeable" % (checkpoint, have, want))
+        if have is None and want["gridtype"] != "hash":
+            self.log("WARNING: checkpoint %s does not record its table layout (written before round 4: Instant-NGP "
+                     "hash); loading it into a %r model scrambles the hashed levels" % (checkpoint, want["gridtype"]))
         missing, unexpected = self.nerf.load_state_dict(state["model"], strict=False)
         if missing or unexpected:
             self.log("checkpoint: missing %s unexpected %s" % (missing, unexpected))

@@ -118,6 +118,8 @@ def test_march_rays_train_bit_exact(dev, dt_gamma, perturb):
     cnt = res.counter.cpu()
     assert int(cnt[0]) == M and M > 1000
     assert int(cnt[1]) == int((rays[:, 2] > 0).sum()) and int(cnt[2]) == 0
+    assert int(cnt[3]) == M                      # running peak of M (fresh buffers: this march's own)
+    assert res.take_peak() == (M, False) and int(res.counter[3]) == 0
     assert torch.equal(res.rays.cpu(), rays)
     assert torch.equal(res.xyzs[:M].cpu(), xyzs)
     assert torch.equal(res.deltas[:M].cpu(), deltas)
@@ -170,6 +172,7 @@ def test_march_cascades_cap_and_capacity(dev):
     r = res.rays.cpu()
     c = res.counter.cpu()
     assert int(c[2]) > 0 and int(c[0]) <= cap
+    assert int(c[3]) == (int(c[0]) | (1 << 30))  # peak word: dropped rays raise bit 30
     kept = r[:, 2] > 0
     assert int((r[kept, 1] + r[kept, 2]).max()) == int(c[0])
     # no occupied cells / all rays missing: zero samples

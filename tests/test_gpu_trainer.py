@@ -50,7 +50,8 @@ def test_training_reduces_guidance_error_and_checkpoints_roundtrip(dev, tmp_path
     ck = sorted(tr.ckpt_path.glob("*.pth"))
     assert [c.name for c in ck] == ["step_000030.pth", "step_000060.pth"]
     state = torch.load(ck[-1], map_location="cpu", weights_only=True)
-    assert set(state) == {"train_step", "checkpoints", "model", "optimizer"} and state["train_step"] == 60
+    assert set(state) == {"train_step", "checkpoints", "model", "optimizer", "table_layout"} and state["train_step"] == 60
+    assert state["table_layout"]["gridtype"] == "hash" and len(state["table_layout"]["offsets"]) == 17
     # resume: same weights, step counter continues at train_step + 1 (reference semantics)
     cfg2 = _cfg(tmp_path, **{"optim.resume": True})
     tr2 = Trainer(cfg2, device=dev)
@@ -81,18 +82,104 @@ def test_bf16_training_step_runs(dev, tmp_path):
     assert bool(torch.isfinite(tr.nerf.w1).all())
 
 
-def test_multi_view_steps_accumulate_and_match_unfused_single_view(dev, tmp_path):
-    """Two views per step: the table update cannot be fused into one backward pass, gradients accumulate over the
-    views and the ordinary Adam kernel applies them.  And with one view per step the fused table update (default) and
-    the ordinary path give the same table, bit for bit (same seeds, same poses)."""
+def test_checkpoint_records_the_table_layout_and_refuses_another(dev, tmp_path):
+    """A `blocked` table has the shape of a `hash` table and different contents per row: the checkpoint says which it
+    holds, and loading it into a model of the other layout is refused (it would render scrambled features)."""
     from src.latent_nerf.training.trainer import Trainer
-    cfg = _cfg(tmp_path, **{"optim.views_per_step": 2, "optim.iters": 6, "log.save_interval": 1000, "log.exp_name": "v2"})
-    tr = Trainer(cfg, device=dev)
-    assert tr.optimizer.fused is None
-    before = tr.nerf.encoder.embeddings.detach().clone()
+    tr = Trainer(_cfg(tmp_path, **{"optim.iters": 2, "log.exp_name": "lay_b", "render.gridtype": "blocked",
+                                   "optim.fp16": True, "log.full_eval_size": 1}), device=dev)
     tr.train()
-    assert tr.train_step == 6 and bool(torch.isfinite(tr.nerf.encoder.embeddings).all())
-    assert float((tr.nerf.encoder.embeddings.detach() - before).abs().max()) > 0
+    path = tr.save_checkpoint(full=True)
+    other = Trainer(_cfg(tmp_path, **{"optim.iters": 2, "log.exp_name": "lay_h", "optim.fp16": True}), device=dev)
+    with pytest.raises(ValueError, match="not interchangeable"):
+        other.load_checkpoint(path, model_only=True)
+    same = Trainer(_cfg(tmp_path, **{"optim.iters": 2, "log.exp_name": "lay_b2", "render.gridtype": "blocked",
+                                     "optim.fp16": True}), device=dev)
+    same.load_checkpoint(path, model_only=True)
+    assert torch.equal(same.nerf.encoder.embeddings.detach(), tr.nerf.encoder.embeddings.detach())
+
+
+def test_batched_views_render_like_separate_views(dev):
+    """k views handed to the renderer as ONE batch (camera form, B = k): every view's image is bit-identical to that
+    view rendered alone (rays, samples, features and MLP outputs are per-ray / per-sample work), and one backward over
+    the batch gives the SUM of the separate backward passes: per-sample gradients are the same numbers, the table and
+    weight gradients are the same sums in another order (the table's fixed-point sums are exact; what differs is one
+    f32 rounding of the total against the sum of k rounded totals)."""
+    from src.latent_nerf.configs.render_config import RenderConfig
+    from src.latent_nerf.models.network_grid import NeRFNetwork
+    from src.latent_nerf.models.nerf_utils import intrinsics_from_fov, pose_from_angles
+    torch.manual_seed(3)
+    HW, G, k = 32, 64, 3
+    cfg = RenderConfig(grid_size=G, train_h=HW, train_w=HW, mlp_precision="f32", table_dtype="f32", noise_seed=None)
+    net = NeRFNetwork(cfg, log2_hashmap_size=14)
+    net.encoder.embeddings.data.normal_(0, 0.1)
+    net = net.to(dev).train()
+    net.seed_density_grid(lambda x: (x.norm(dim=-1) < 0.5).float() * 10.0, thresh=0.01)
+    poses = torch.stack([pose_from_angles(math.radians(50.0 + 20 * v), math.radians(70.0 * v), 1.2 + 0.1 * v)
+                         for v in range(k)]).to(dev)
+    intr = intrinsics_from_fov(55.0, HW, HW)
+    bg = torch.rand(k * HW * HW, 4, device=dev)
+    g = torch.randn(k, HW * HW, 4, device=dev)
+    params = [net.encoder.embeddings, net.w1, net.b1, net.w2, net.b2, net.w3, net.b3]
+
+    def grads():
+        out = [p.grad.detach().clone() for p in params]
+        for p in params:
+            p.grad = None
+        return out
+
+    out = net.render(None, None, camera=(poses, intr, HW, HW), bg_color=bg, perturb=False)
+    img = out["image"].detach().clone()
+    M = int(out["counter"][0])
+    assert img.shape == (k, HW * HW, 4) and M > 5000
+    out["image"].backward(g)
+    gb = grads()
+    gs, Ms = None, 0
+    for v in range(k):
+        o = net.render(None, None, camera=(poses[v:v + 1], intr, HW, HW), bg_color=bg[v * HW * HW:(v + 1) * HW * HW],
+                       perturb=False)
+        assert torch.equal(o["image"][0], img[v]), v
+        Ms += int(o["counter"][0])
+        o["image"].backward(g[v:v + 1])
+        gv = grads()
+        gs = gv if gs is None else [a + b for a, b in zip(gs, gv)]
+    assert Ms == M
+    for a, b in zip(gb, gs):
+        scale = float(b.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) <= 2e-5 * scale, (float((a - b).abs().max()), scale)
+
+
+def test_multi_view_steps_run_fused_and_captured(dev, tmp_path):
+    """Two views per step (render.batch_size of the reference's fork,
+    /root/reference/src/latent_paint_mesh/configs/train_config.py:32): the step's views are one batch, so the fused table
+    update, the closing scatter and the captured step all apply -- no eager accumulate loop.  Graphed == eager, bit for
+    bit, as with one view.  And with one view per step the fused table update (default) and the ordinary path give the
+    same table, bit for bit (same seeds, same poses)."""
+    from src.latent_nerf.training.trainer import Trainer
+    tabs = []
+    for graph in (True, False):
+        cfg = _cfg(tmp_path, **{"optim.views_per_step": 2, "optim.iters": 20, "log.save_interval": 1000, "optim.fp16": True,
+                                "log.exp_name": "v2g%d" % graph, "optim.graph_step": graph, "log.full_eval_size": 1})
+        torch.manual_seed(7)
+        torch.cuda.manual_seed(7)
+        tr = Trainer(cfg, device=dev)
+        assert tr.optimizer.fused is not None and tr.optimizer.fused.inline_tail and len(tr.views) == 2
+        assert abs(tr.optimizer.grad_scale - 0.5) < 1e-12
+        before = tr.nerf.encoder.embeddings.detach().clone()
+        torch.manual_seed(11)
+        torch.cuda.manual_seed(11)
+        tr.train()
+        assert tr.train_step == 20 and bool(torch.isfinite(tr.nerf.encoder.embeddings).all())
+        assert float((tr.nerf.encoder.embeddings.detach() - before).abs().max()) > 0
+        if graph:
+            assert tr.graph_stats["captures"] >= 1 and tr.graph_stats["replayed_steps"] >= 15, tr.graph_stats
+            assert tr._static["poses"].shape == (2, 4, 4)
+            assert not torch.equal(tr._static["poses"][0], tr._static["poses"][1])      # two different views
+        else:
+            assert tr.graph_stats["replayed_steps"] == 0
+        tabs.append((tr.nerf.encoder.embeddings.detach().clone(), tr.nerf.w2.detach().clone(), tr.optimizer.step_no))
+    assert tabs[0][2] == tabs[1][2] == 20
+    assert torch.equal(tabs[0][0], tabs[1][0]) and torch.equal(tabs[0][1], tabs[1][1])
     tabs = []
     for fuse in (True, False):
         c = _cfg(tmp_path, **{"optim.iters": 5, "log.save_interval": 1000, "log.exp_name": "f%d" % fuse,
@@ -102,6 +189,32 @@ def test_multi_view_steps_accumulate_and_match_unfused_single_view(dev, tmp_path
         t.train()
         tabs.append(t.nerf.encoder.embeddings.detach().clone())
     assert torch.equal(tabs[0], tabs[1])
+
+
+def test_trainer_recaptures_after_a_foreign_scatter_through_the_shared_workspace(dev, tmp_path):
+    """The scatter workspace is one buffer per device; the captured step bakes in "the level maxima are clean".  A
+    backward through the net OUTSIDE train() (here: an ordinary, non-closing scatter under the trainer's stream) leaves
+    its maxima in the header: the trainer must notice and capture again instead of replaying with stale maxima."""
+    from src.latent_nerf.models import encoding as E
+    from src.latent_nerf.training.trainer import Trainer
+    cfg = _cfg(tmp_path, **{"optim.iters": 8, "log.save_interval": 1000, "optim.fp16": True, "log.exp_name": "fs",
+                            "log.full_eval_size": 1})
+    tr = Trainer(cfg, device=dev)
+    tr.train()
+    assert tr.graph_stats["captures"] == 1
+    e0 = E.scatter_workspace_epoch(dev)
+    assert e0 == tr._gstep_ws and e0[0] is not None          # clean after the closing scatter
+    with torch.cuda.stream(tr.stream):
+        x = (torch.rand(4096, 3, device=dev) - 0.5)
+        s, _ = tr.nerf.field(x.contiguous(), 4096)
+        s.sum().backward()                                    # un-armed: ordinary scatter, maxima left behind
+        for p in tr.nerf.parameters():
+            p.grad = None
+    tr.stream.synchronize()
+    assert E.scatter_workspace_epoch(dev) != e0 and E.scatter_workspace_epoch(dev)[0] is None
+    tr.train(iters=16)
+    assert tr.train_step == 16 and tr.graph_stats["captures"] == 2, tr.graph_stats
+    assert bool(torch.isfinite(tr.nerf.encoder.embeddings).all())
 
 
 def test_mesh_winding_distance_and_shape_guidance(dev, tmp_path):
@@ -224,7 +337,7 @@ def test_graphed_trainer_recaptures_when_the_sample_budget_moves(dev, tmp_path):
     cap0 = tr._gstep_capacity
     with torch.cuda.stream(tr.stream):
         tr.nerf.seed_density_grid(lambda x: (x.norm(dim=-1) < 0.2).float() * 100.0)
-        tr.nerf._m_peak.zero_()
+        tr.nerf._march.take_peak()      # (forget the peaks of the big marches)
     tr.stream.synchronize()
     tr.train(iters=40)
     assert tr.train_step == 40 and tr.graph_stats["captures"] >= 2, tr.graph_stats
