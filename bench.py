@@ -126,6 +126,9 @@ def parse():
                          "state: the analytic scene stays pinned); 0: the refresh-free step only")
     ap.add_argument("--repeats", type=int, default=0, help="timed regions of --steps steps each (0 = auto: 5 below 100 steps, else 1); the median region is reported")
     ap.add_argument("--trainer-steps", type=int, default=200, help="steps of the `trainer` companion (0 = skip)")
+    ap.add_argument("--shard-optimizer", type=int, default=0,
+                    help="N > 1, bf16 on the wire, pipelined groups: row-sharded table optimiser -- reduce-scatter of the "
+                         "gradient, the owning rank steps its 1/N of the rows, all-gather of the bf16 shadow")
     ap.add_argument("--views-per-rank", type=int, default=1,
                     help="views every rank renders per optimisation step, as ONE batch through the fused captured step "
                          "(render.batch_size of the reference's fork: src/latent_paint_mesh/configs/train_config.py:32); "
@@ -167,7 +170,7 @@ def sphere_scene(net):
 
 
 def make_step(net, pose, intr, bg, grad, opt, world, transport=torch.float32, perturb=True, exchange_groups=0,
-              prefetch=False):
+              prefetch=False, shard=False):
     """Returns (eager_step, fwd_bwd, opt_step, sync).
     prefetch: the rays + occupancy march of step k+1 (NeRFRenderer.prepare_rays: they read neither the hash table
     nor the MLP) run on a side stream while step k is shaded and back-propagated; the two sample-buffer sets of the
@@ -175,7 +178,7 @@ def make_step(net, pose, intr, bg, grad, opt, world, transport=torch.float32, pe
     from src.latent_nerf.raymarching import raymarching as rm
     from src.latent_nerf.training.distributed import GradSync
     small = [p for p in net.parameters() if p is not net.encoder.embeddings]
-    sync = GradSync([net.encoder.embeddings], small, transport=transport)
+    sync = GradSync([net.encoder.embeddings], small, transport=transport, shard_optimizer=shard)
     # N > 1 with bf16 on the wire: backward writes the wire buffer directly; with exchange_groups >= 1 it only bins the
     # scatter records and the exchange sums + sends one level group at a time (GradSync.allreduce_pipelined)
     sink = sync.attach_sink(net.encoder, pipeline_groups=exchange_groups)
@@ -222,8 +225,9 @@ def make_step(net, pose, intr, bg, grad, opt, world, transport=torch.float32, pe
 
     def opt_step():
         if pipelined:   # the optimiser waits for a level group's all-reduce right before it steps those rows
-            opt.step(grad_scale=1.0 / world, grads=sync.reduced(),
-                     row_groups={net.encoder.embeddings: state.pop("ex").table_groups})
+            ex = state.pop("ex")
+            opt.step(grad_scale=1.0 / world, grads=sync.reduced(), row_groups={net.encoder.embeddings: ex.table_groups})
+            ex.finish_gathers()   # (--shard-optimizer: the owners' new shadow rows; no-op otherwise)
         else:
             opt.step(grad_scale=1.0 / world, grads=sync.reduced() if sync.active else None)
 
@@ -484,6 +488,10 @@ def trainer_companion(dev, steps, precision, fixed_pose=False):
         iv = cfg.render.update_extra_interval
         return {"value": steps / dt, "unit": "steps/sec (= latent-frames/sec at 1 view per step)", "steps": steps,
                 "ms_per_step": 1e3 * dt / steps, "host_ms_per_step": 1e3 * host / steps,
+                # (host_ms_per_step includes the wait at every refresh, where the sample budget is read back; this one is
+                # the host time of the replayed steps alone: pose, upload, one graph launch)
+                "host_ms_per_replayed_step": 1e3 * (tr.graph_stats["host_s"] - c0["host_s"])
+                / max(tr.graph_stats["replayed_steps"] - c0["replayed_steps"], 1),
                 "refreshes_in_region": len([k for k in range(warm + 1, warm + steps + 1) if (k - 1) % iv == 0]),
                 "replayed_steps": tr.graph_stats["replayed_steps"] - c0["replayed_steps"],
                 "eager_steps": tr.graph_stats["eager_steps"] - c0["eager_steps"],
@@ -585,7 +593,8 @@ def decide_graph_collectives(args, store, rank, world, backend):
     env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
     argv = [sys.executable, os.path.abspath(__file__), "--preflight", "--gpus", str(world), "--precision", args.precision,
             "--table", args.table, "--grad-transport", args.grad_transport, "--exchange-groups", str(args.exchange_groups),
-            "--gridtype", args.gridtype, "--views-per-rank", str(args.views_per_rank), "--perturb", str(args.perturb)]
+            "--gridtype", args.gridtype, "--views-per-rank", str(args.views_per_rank), "--perturb", str(args.perturb),
+            "--shard-optimizer", str(args.shard_optimizer)]
     if args.force_dist:
         argv.append("--force-dist")
     t0 = time.perf_counter()
@@ -622,7 +631,7 @@ def build_step(args, dev, rank, world, dist_on):
         raise SystemExit("--prefetch-rays 1 needs one rank without --force-dist and one view per rank")
     step, fwd_bwd, opt_step, sync = make_step(net, pose, intr, bg, grad, opt, world * args.views_per_rank,
                                               torch.bfloat16 if tr == "bf16" else torch.float32, bool(args.perturb), groups,
-                                              prefetch)
+                                              prefetch, shard=bool(args.shard_optimizer) and bool(groups))
     return dict(net=net, opt=opt, step=step, fwd_bwd=fwd_bwd, opt_step=opt_step, sync=sync, table=table, fuse=fuse, tr=tr,
                 groups=groups, prefetch=prefetch)
 
@@ -820,8 +829,12 @@ def main():
     emb = net.encoder.embeddings.detach()
     if not bool(torch.isfinite(emb).all()) or not all(bool(torch.isfinite(p.detach()).all()) for p in net.parameters()):
         raise SystemExit("bench: non-finite parameters after the timed steps")
+    if dist_on and args.shard_optimizer and groups:   # the owners' rows of the f32 master, whole again for the checks
+        sync.gather_rows([net.encoder.embeddings.data])
     if world > 1:  # data parallel: every rank applied the same update, the replicas must still be bit-identical
-        chk = torch.stack([emb.double().sum(), emb.double().abs().sum(), net.w2.detach().double().sum()])
+        sh = net.encoder.shadow()
+        chk = torch.stack([emb.double().sum(), emb.double().abs().sum(), net.w2.detach().double().sum(),
+                           (sh.double().sum() if sh is not None else emb.double().sum())])
         allc = [torch.empty_like(chk) for _ in range(world)]
         dist.all_gather(allc, chk)
         if not all(torch.equal(allc[0], c) for c in allc):
@@ -917,7 +930,9 @@ def main():
                        "views_per_step": world * kv, "views_per_rank": kv,
                        "parallelism": "dp%d (%d view%s per GPU, RCCL all-reduce of gradients, %s on the wire%s)%s"
                                       % (world, kv, "" if kv == 1 else "s", tr,
-                                         ", table in %d pipelined level groups" % groups if groups else "",
+                                         (", table in %d pipelined level groups" % groups if groups else "")
+                                         + ("; row-sharded table optimiser (reduce-scatter / owner steps / all-gather of "
+                                            "the shadow)" if (args.shard_optimizer and groups) else ""),
                                          "; --force-dist: the exchange path on ONE rank (communicator of size 1)"
                                          if args.force_dist else "")},
             "roofline": {"kernel": "k_grid_forward (hash-grid gather, H5)", "bound": "hbm", "achieved": achieved,

@@ -198,6 +198,11 @@ size_t lnerf_grid_encode_backward_workspace_bytes(int num_levels, const int32_t 
  * One block = one 64-byte line of the bf16 table: a sample's 8 vertices touch 2.8 lines on average instead of 4.25.
  * Dense levels are unchanged.  Restated in oracle/nerf_oracle.py (grid_corner_indices(blocked=True)). */
 #define LNERF_GRID_BLOCKED 0x400
+/* variant | LNERF_GRID_TILED (forward AND backward entry points, consistently; not together with LNERF_GRID_BLOCKED): the
+ * upstream encoder's `gridtype = "tiled"` -- a level too large for its table wraps its dense index,
+ * row = (x + y (res + 1) + z (res + 1)^2 mod 2^32) mod rows, instead of hashing the vertex.  Restated in
+ * oracle/nerf_oracle.py (grid_corner_indices(layout="tiled")). */
+#define LNERF_GRID_TILED 0x800
 /* variant | LNERF_SCATTER_DEFER_FINISH: accepted and ignored (ABI 4 deferred a separate finishing pass of the sliced
  * buckets to lnerf_step_tail; pass 2 finishes them itself now). */
 #define LNERF_SCATTER_DEFER_FINISH 0x200
@@ -299,6 +304,22 @@ int lnerf_mlp_backward(const void *feat, int feat_dtype, int64_t level_stride, c
  * compositing backward as grad_weights_sum. */
 int lnerf_opacity_entropy_grad(const float *weights_sum, int64_t N, float scale, float eps, float *grad,
                                lnerf_stream_t stream);
+
+/* ---- trainer helper: the SEEDED SYNTHETIC guidance (the stand-in for `grad = diffusion.train_step(text_z, pred)` of the
+ * reference's src/stable_diffusion.py:248-334 where no diffusion model is available) and, optionally, the entropy gradient
+ * above, in ONE launch and in the renderer's own image layout:
+ *   t = t_lo + floor(u (t_hi - t_lo + 1)),  w = weights[t]   (weights f32 [>= t_hi + 1]: sqrt(a_t)(1 - a_t), :274, :320)
+ *   grad_image[v, p, c] = w * (noise_scale * z + (image[v, p, c] - targets[dirs[v], p, c]))
+ * image / grad_image f32 [n_views, rays_per_view, C]; targets f32 [n_buckets, rays_per_view, C]; dirs int32 [n_views]
+ * (clamped into range).  u and the normal deviates z come from a counter-based generator of (seed, *step_dev, element)
+ * -- *step_dev is only read (the optimiser's device step counter: it advances once per step), so a replayed hipGraph
+ * draws fresh noise without host RNG state.  grad_weights_sum != NULL: also lnerf_opacity_entropy_grad over
+ * weights_sum [n_views * rays_per_view].  Restated in oracle/nerf_oracle.py synthetic_guidance(). */
+int lnerf_synthetic_guidance(const float *image, const float *targets, const int32_t *dirs, const float *weights,
+                             int64_t n_views, int rays_per_view, int C, int n_buckets, int t_lo, int t_hi,
+                             float noise_scale, uint32_t seed, const int32_t *step_dev, float *grad_image,
+                             const float *weights_sum, float ent_scale, float ent_eps, float *grad_weights_sum,
+                             lnerf_stream_t stream);
 
 /* ---- H8/H9: `raymarching.composite_rays_train_forward/backward`.  One wavefront per ray,
  * log-space prefix scan of sigma*dt across lanes.  C = colour channels (3 or 4).

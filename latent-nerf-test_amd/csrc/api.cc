@@ -21,5 +21,9 @@ void set_error(const char *fmt, ...) {
 extern "C" {
 int lnerf_abi_version(void) { return LNERF_ABI_VERSION; }
 const char *lnerf_last_error(void) { return lnerf::g_err; }
+#ifdef LNERF_EXPERIMENTS   // (an experiment build also carries the measured-and-rejected kernel variants)
+const char *lnerf_build_info(void) { return "gfx950;" LNERF_BUILD_TAG ";experiments"; }
+#else
 const char *lnerf_build_info(void) { return "gfx950;" LNERF_BUILD_TAG; }
+#endif
 }

@@ -131,7 +131,8 @@ struct GridMeta {
     int offsets[LNERF_MAX_LEVELS + 1];
     float scales[LNERF_MAX_LEVELS];
     int res[LNERF_MAX_LEVELS];
-    int blocked;   // LNERF_GRID_BLOCKED: hashed levels keep 4 x 2 x 2 vertex blocks together (grid.hip corner_rows)
+    int blocked;   // layout of the levels larger than their table (grid.hip corner_rows): 0 = Instant-NGP vertex hash,
+                   // 1 = LNERF_GRID_BLOCKED (4 x 2 x 2 vertex blocks hashed together), 2 = LNERF_GRID_TILED (dense index wrapped)
 };
 
 }  // namespace lnerf

@@ -37,8 +37,13 @@ __device__ __forceinline__ uint32_t grid_index(uint32_t x, uint32_t y, uint32_t 
 //     row = (hash(x >> 2, y >> 1, z >> 1) mod (hsize / 16)) * 16 + (x & 3) + 4 (y & 1) + 8 (z & 1)
 // -- so that a block is one 64-byte line of the bf16 table: a cell's 8 vertices touch 1.25 x 1.5 x 1.5 = 2.8 lines on
 // average instead of 4.25 (x pairs share a line either way; here y and z neighbours do half the time).
+// tiled (LNERF_GRID_TILED: `gridtype = "tiled"` of the upstream encoder): a level too large for its
+// table wraps its DENSE index instead of hashing the vertex --
+//     row = (x + y (res + 1) + z (res + 1)^2  mod 2^32)  mod hsize
+// -- x-neighbours stay neighbours, whole y / z slabs alias each other.
 __device__ __forceinline__ void corner_rows(uint32_t gx, uint32_t gy, uint32_t gz, uint32_t res, uint32_t hsize,
-                                            uint32_t row[8], bool blocked = false) {
+                                            uint32_t row[8], int layout = 0) {
+    const bool blocked = layout == 1;
     const uint32_t stride = res + 1;
     const uint64_t cube = (uint64_t)stride * stride * stride;
     if (cube <= (uint64_t)hsize) {  // wave-uniform
@@ -47,6 +52,20 @@ __device__ __forceinline__ void corner_rows(uint32_t gx, uint32_t gy, uint32_t g
         const uint32_t base = gx + __umul24(gy, stride) + __umul24(gz, s2);
 #pragma unroll
         for (int c = 0; c < 8; ++c) row[c] = base + (c & 1) + ((c >> 1) & 1) * stride + ((c >> 2) & 1) * s2;
+        return;
+    }
+    if (layout == 2) {  // wave-uniform: tiled
+        const uint32_t s2 = stride * stride;   // (uint32 wrap-around, as the upstream's index arithmetic)
+        const uint32_t base = gx + gy * stride + gz * s2;
+        if ((hsize & (hsize - 1u)) == 0u) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                row[c] = (base + (c & 1) + ((c >> 1) & 1) * stride + ((c >> 2) & 1) * s2) & (hsize - 1u);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                row[c] = (base + (c & 1) + ((c >> 1) & 1) * stride + ((c >> 2) & 1) * s2) % hsize;
+        }
         return;
     }
     if (blocked) {  // wave-uniform
@@ -253,6 +272,9 @@ __global__ void __launch_bounds__(256)
 k_grid_forward(const float *__restrict__ xyzs, float bound, const TT *__restrict__ table, GridMeta meta, int64_t m_host,
                const int32_t *__restrict__ m_dev, int64_t level_stride, TO *__restrict__ feat, int variant,
                int pair_loads, int dedup_max_res, XcdPlan plan) {
+#ifndef LNERF_EXPERIMENTS
+    variant = 0;   // (the XCD-pinned mappings 1 / 2 are compiled into experiment builds only)
+#endif
     int64_t M = m_host;
     if (m_dev) { const int64_t md = *m_dev; M = md < M ? md : M; }
     TileMap tm = tile_map(variant == 2 ? 0 : variant, meta.num_levels);
@@ -286,7 +308,7 @@ k_grid_forward(const float *__restrict__ xyzs, float bound, const TT *__restrict
         p.gx = p.gy = p.gz = 0u; p.fx = p.fy = p.fz = 0.f;
         if (valid) p = level_pos(xyzs, m, bound, scale);
         uint32_t rows[8];
-        corner_rows(p.gx, p.gy, p.gz, res, hsize, rows, meta.blocked != 0);
+        corner_rows(p.gx, p.gy, p.gz, res, hsize, rows, meta.blocked);
         bool fetch = valid;
         int src = lane;
         if (dedup) {
@@ -301,6 +323,10 @@ k_grid_forward(const float *__restrict__ xyzs, float bound, const TT *__restrict
             if (pair_loads && dense) {
 #pragma unroll
                 for (int c = 0; c < 8; c += 2) cell.load_pair(lt, rows[c], c);  // rows[c+1] == rows[c] + 1
+            } else if (meta.blocked == 2) {
+                // tiled: rows follow the dense index mod hsize (no x ^ h structure to pair loads on)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) cell.load_one(lt, rows[c], c);
             } else if (pair_loads == 2 && CellRaw<TT>::kHasQuad && pow2 && (p.gx & 3u) != 3u) {
                 // hashed, x mod 4 != 3: both x-neighbours sit in one aligned group of four rows (row = x ^ h: the group
                 // is (x ^ h) & ~3) -- one 16-byte access instead of one 8-byte or two 4-byte ones
@@ -358,7 +384,7 @@ k_grid_backward_atomic(const float *__restrict__ xyzs, float bound, const TG *__
         const LevelPos p = level_pos(xyzs, m, bound, scale);
         const float2 gg = Feat2<TG>::load(dfeat + ((int64_t)l * level_stride + m) * 2, 0);
         uint32_t rows[8];
-        corner_rows(p.gx, p.gy, p.gz, res, hsize, rows, meta.blocked != 0);
+        corner_rows(p.gx, p.gy, p.gz, res, hsize, rows, meta.blocked);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const uint32_t bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
@@ -718,7 +744,7 @@ k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restri
                 p.gx = (uint32_t)(int)flx; p.gy = (uint32_t)(int)fly; p.gz = (uint32_t)(int)flz;
                 p.fx = px - flx; p.fy = py - fly; p.fz = pz - flz;
             }
-            corner_rows(p.gx, p.gy, p.gz, lv.res, lv.hsize, row, meta.blocked != 0);
+            corner_rows(p.gx, p.gy, p.gz, lv.res, lv.hsize, row, meta.blocked);
             if (lv.compact) {  // wave-uniform: coarse level, merge runs of samples in the same cell first
                 // (the lane number is made opaque per item: the 64-bit lane masks derived from it are cheaper to
                 // recompute than to keep -- hoisted out of the item loop they were spilled to scratch)
@@ -1214,7 +1240,10 @@ __device__ __forceinline__ void scatter_reduce_one(int wg, const GridMeta &meta,
             atomicAdd(&ua[a0], (unsigned long long)to_fixed<FB>((r.a() * fs.sc_a) * fs.sc_b));
             atomicAdd(&ua[a0 + BK_ROWS], (unsigned long long)to_fixed<FB>((r.b() * fs.sc_a) * fs.sc_b));
         };
-        constexpr int U = LNERF_REDUCE_ROUNDS;                        // rounds of loads in flight per lane
+        // rounds of loads in flight per lane.  A 12-byte record is three registers: five rounds in flight are what the
+        // 64 registers of two resident workgroups leave room for (eight spilled 20-36 bytes per lane to scratch, whose
+        // traffic shares the vector-memory queue with the very loads the loop waits for)
+        constexpr int U = REC::kPacked ? LNERF_REDUCE_ROUNDS : (LNERF_REDUCE_ROUNDS < 5 ? LNERF_REDUCE_ROUNDS : 5);
 #ifdef LNERF_EXP_RED_NOREC   // timing-only experiment build: no record loop
         for (int kb = 0; kb < 0; kb += 64) {
 #else
@@ -1369,6 +1398,18 @@ __device__ __forceinline__ void scatter_reduce_one(int wg, const GridMeta &meta,
         // work -- as its own pass behind the launch it was a chain of dependent round trips (~9 us) at the end of the
         // step.  Tiles travel with device-scope (write-through / cache-bypassing) accesses: slices run on different
         // XCDs, whose L2s are not coherent for plain stores, and the addresses are the same every step.
+        //
+        // ORDERING -- by construction on the ISA, not by C++ memory orders (every atomic below is RELAXED):
+        //   writer   tile stores = `global_store_dwordx2 ... sc1` (write-through to device scope); `s_waitcnt vmcnt(0)`:
+        //            every store of the wave ACKNOWLEDGED, i.e. visible at device scope; workgroup barrier: true of all
+        //            16 waves; then ONE returning `global_atomic_add ... sc0` on the bucket's arrival word.
+        //   reader   (the arrival that returned S - 1) its value reaches the other waves through LDS + a barrier, so every
+        //            tile load is issued behind the atomic's return; tile loads = `global_load_dwordx2 ... sc1`: they
+        //            miss this XCD's non-coherent L2 and see the acknowledged stores.
+        // A release / acquire pair at agent scope would be correct by the letter and costs a `buffer_wbl2` -- a write-back
+        // of the XCD's whole L2 -- per workgroup: 106 -> 273 us for this pass.  tests/test_abi_cpu.py
+        // (test_cross_workgroup_handoffs_are_scoped_accesses) checks the compiled kernel for exactly these instructions
+        // and for the absence of L2 write-backs / invalidates, so a compiler that chose otherwise fails the CPU suite.
         unsigned long long *tiles = reinterpret_cast<unsigned long long *>(partials) +
                                     ((int64_t)bm.pstart[l] + (int64_t)b * Smax) * (BK_ROWS * 2);
         unsigned long long *pt = tiles + (int64_t)s * (BK_ROWS * 2);
@@ -1628,13 +1669,16 @@ static int fill_bucket_meta(const GridMeta &meta, int64_t m_host, BucketMeta &bm
 }
 
 static int fill_meta(const char *who, GridMeta &meta, int num_levels, int level_dim, const int32_t *offsets_host,
-                     const float *scales_host, const int32_t *res_host, int blocked = 0) {
+                     const float *scales_host, const int32_t *res_host, int layout_flags = 0) {
     LNERF_REQUIRE(num_levels >= 1 && num_levels <= LNERF_MAX_LEVELS, "%s: num_levels out of range (%d)", who,
                   num_levels);
     LNERF_REQUIRE(level_dim == 2, "%s: only level_dim == 2 is built (got %d)", who, level_dim);
     LNERF_REQUIRE(offsets_host && scales_host && res_host, "%s: null level metadata", who);
     meta.num_levels = num_levels;
-    meta.blocked = blocked ? 1 : 0;
+    LNERF_REQUIRE((layout_flags & (LNERF_GRID_BLOCKED | LNERF_GRID_TILED)) != (LNERF_GRID_BLOCKED | LNERF_GRID_TILED),
+                  "%s: LNERF_GRID_BLOCKED and LNERF_GRID_TILED exclude each other", who);
+    const int blocked = (layout_flags & LNERF_GRID_BLOCKED) ? 1 : 0;
+    meta.blocked = blocked ? 1 : ((layout_flags & LNERF_GRID_TILED) ? 2 : 0);   // layout of the levels beyond their table: 0 hash, 1 blocked, 2 tiled
     for (int l = 0; l <= num_levels; ++l) meta.offsets[l] = offsets_host[l];
     for (int l = 0; l < num_levels; ++l) {
         LNERF_REQUIRE(offsets_host[l + 1] > offsets_host[l], "%s: empty level %d", who, l);
@@ -1671,13 +1715,16 @@ int lnerf_grid_encode_forward(const float *xyzs, float bound, const void *table,
                               const int32_t *res_host, int64_t m_host, const int32_t *m_dev, int64_t level_stride,
                               void *feat, int feat_dtype, int variant, lnerf_stream_t stream) {
     GridMeta meta;
-    const int blocked = variant & LNERF_GRID_BLOCKED;
-    variant &= ~LNERF_GRID_BLOCKED;
+    const int blocked = variant & (LNERF_GRID_BLOCKED | LNERF_GRID_TILED);
+    variant &= ~(LNERF_GRID_BLOCKED | LNERF_GRID_TILED);
     int rc = fill_meta("grid_encode_forward", meta, num_levels, level_dim, offsets_host, scales_host, res_host, blocked);
     if (rc) return rc;
     LNERF_REQUIRE(m_host >= 0 && level_stride >= m_host, "grid_encode_forward: need 0 <= m_host <= level_stride");
     LNERF_REQUIRE(bound > 0.f, "grid_encode_forward: bound must be > 0");
     LNERF_REQUIRE(variant >= 0 && variant <= 2, "grid_encode_forward: unknown variant %d", variant);
+#ifndef LNERF_EXPERIMENTS   // (XCD-pinned levels / XCD-owned level sets: measured no faster; experiment builds only)
+    LNERF_REQUIRE(variant == 0, "grid_encode_forward: variant %d is an experiment variant (build with -DLNERF_EXPERIMENTS)", variant);
+#endif
     LNERF_REQUIRE((table_dtype == LNERF_F32 || table_dtype == LNERF_BF16) &&
                       (feat_dtype == LNERF_F32 || feat_dtype == LNERF_BF16),
                   "grid_encode_forward: bad dtype tag");
@@ -1755,6 +1802,9 @@ int lnerf_set_tuning(const char *key, int value) {
     }
     if (strcmp(key, "mlp_bwd_variant") == 0) {
         LNERF_REQUIRE(value >= 0 && value <= 2, "set_tuning: mlp_bwd_variant must be 0, 1 or 2");
+#ifndef LNERF_EXPERIMENTS
+        LNERF_REQUIRE(value == 0, "set_tuning: mlp_bwd_variant %d is an experiment variant (build with -DLNERF_EXPERIMENTS)", value);
+#endif
         g_mlp_bwd_variant = value;
         return LNERF_OK;
     }
@@ -1765,6 +1815,9 @@ int lnerf_set_tuning(const char *key, int value) {
     }
     if (strcmp(key, "mlp_fwd_wps") == 0) {
         LNERF_REQUIRE(value >= 2 && value <= 4, "set_tuning: mlp_fwd_wps must be 2, 3 or 4");
+#ifndef LNERF_EXPERIMENTS
+        LNERF_REQUIRE(value <= 3, "set_tuning: mlp_fwd_wps 4 is an experiment variant (build with -DLNERF_EXPERIMENTS)");
+#endif
         g_mlp_fwd_wps = value;
         return LNERF_OK;
     }
@@ -1847,8 +1900,8 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
     // something it was launching anyway -- the fill dispatch of this call is skipped
     const bool cleared = (variant & LNERF_SCATTER_CLEARED) != 0;
     // (LNERF_SCATTER_DEFER_FINISH: accepted, without effect -- pass 2 finishes the sliced buckets itself)
-    const int blocked = variant & LNERF_GRID_BLOCKED;
-    variant &= ~(LNERF_SCATTER_CLEARED | LNERF_SCATTER_DEFER_FINISH | LNERF_GRID_BLOCKED);
+    const int blocked = variant & (LNERF_GRID_BLOCKED | LNERF_GRID_TILED);
+    variant &= ~(LNERF_SCATTER_CLEARED | LNERF_SCATTER_DEFER_FINISH | LNERF_GRID_BLOCKED | LNERF_GRID_TILED);
     GridMeta meta;
     int rc = fill_meta("grid_encode_backward", meta, num_levels, level_dim, offsets_host, scales_host, res_host, blocked);
     if (rc) return rc;

@@ -684,6 +684,9 @@ __device__ __forceinline__ void build_selectors(__bf16 *frag, int tid, int nthre
     }
 }
 
+// (operand-swap form of the backward: measured slower than the default at either occupancy, spills at two waves per
+// SIMD -- DESIGN.md section 4 H7; compiled only into experiment builds: -DLNERF_EXPERIMENTS)
+#ifdef LNERF_EXPERIMENTS
 template <int WPS>
 __global__ void __launch_bounds__(256, WPS)
 k_mlp_backward_bf16_sw(MlpArgs a, const float *__restrict__ sigmas, const float *__restrict__ dsigmas,
@@ -940,6 +943,7 @@ k_mlp_backward_bf16_sw(MlpArgs a, const float *__restrict__ sigmas, const float 
         slab[MLP_SL_B3 + c] = gB[2][0];
     }
 }
+#endif  // LNERF_EXPERIMENTS
 
 }  // namespace lnerf
 
@@ -974,8 +978,11 @@ int launch_mlp_fragments_bf16(const MlpArgs &a, void *frag_out, bool backward_to
 }
 
 int launch_mlp_forward_bf16(const MlpArgs &a, float *sigmas, float *rgbs, int blocks, int wps, hipStream_t stream) {
+#ifdef LNERF_EXPERIMENTS   // (four waves per SIMD: 128 registers, 396 bytes of scratch per lane -- measured slower)
     if (wps >= 4) hipLaunchKernelGGL(k_mlp_forward_bf16<4>, dim3((unsigned)blocks), dim3(256), 0, stream, a, sigmas, rgbs);
-    else if (wps == 3) hipLaunchKernelGGL(k_mlp_forward_bf16<3>, dim3((unsigned)blocks), dim3(256), 0, stream, a, sigmas, rgbs);
+    else
+#endif
+    if (wps >= 3) hipLaunchKernelGGL(k_mlp_forward_bf16<3>, dim3((unsigned)blocks), dim3(256), 0, stream, a, sigmas, rgbs);
     else hipLaunchKernelGGL(k_mlp_forward_bf16<2>, dim3((unsigned)blocks), dim3(256), 0, stream, a, sigmas, rgbs);
     LNERF_CHECK_LAUNCH("mlp_forward(bf16)");
     return LNERF_OK;
@@ -983,6 +990,7 @@ int launch_mlp_forward_bf16(const MlpArgs &a, float *sigmas, float *rgbs, int bl
 
 int launch_mlp_backward_bf16(const MlpArgs &a, const float *sigmas, const float *dsigmas, const float *drgbs,
                              float *dfeat, float *slabs, int blocks, int variant, hipStream_t stream) {
+#ifdef LNERF_EXPERIMENTS
     if (variant == 2) {
         hipLaunchKernelGGL(k_mlp_backward_bf16_sw<2>, dim3((unsigned)blocks), dim3(256), 0, stream, a, sigmas, dsigmas,
                            drgbs, dfeat, slabs);
@@ -995,6 +1003,8 @@ int launch_mlp_backward_bf16(const MlpArgs &a, const float *sigmas, const float 
         LNERF_CHECK_LAUNCH("mlp_backward(bf16, operand swap)");
         return LNERF_OK;
     }
+#endif
+    (void)variant;
     hipLaunchKernelGGL((k_mlp_backward_bf16<4, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, a, sigmas, dsigmas,
                        drgbs, dfeat, slabs);
     LNERF_CHECK_LAUNCH("mlp_backward(bf16)");

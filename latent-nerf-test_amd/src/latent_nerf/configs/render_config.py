@@ -57,7 +57,8 @@ class RenderConfig:
     mlp_precision: str = "auto"
     # "f32": gather reads the master table, "bf16": gather reads a bf16 shadow (half the bytes); "auto" as above
     table_dtype: str = "auto"
-    # layout of the hashed levels of the table: "hash" = Instant-NGP's spatial hash of the vertex; "blocked" = opt-in
+    # layout of the hashed levels of the table: "hash" = Instant-NGP's spatial hash of the vertex; "tiled" = the upstream
+    # encoder's other layout (the dense index wrapped into the table: no hash); "blocked" = opt-in
     # variant that hashes 4 x 2 x 2 vertex BLOCKS and keeps a block's 16 rows in one 64-byte line of the bf16 table
     # (2.8 instead of 4.25 cache lines per sample and level in the gather; a different collision pattern, so tables are
     # not interchangeable between the two)

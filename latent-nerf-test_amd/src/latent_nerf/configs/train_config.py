@@ -55,12 +55,18 @@ class OptimConfig:
     # data parallel, bf16: level groups the table gradient is exchanged in (each group's all-reduce is launched behind
     # its own sums while the next group is still being summed); 1 = one collective for the whole table
     exchange_groups: int = 4
+    # data parallel, bf16: shard the hash table's optimiser by rows -- reduce-scatter of the bf16 gradient, the owning rank
+    # runs Adam on its 1/N of the rows, all-gather of the bf16 shadow the gather reads (same wire bytes as the all-reduce,
+    # 1/N of the Adam traffic per rank); the f32 master and the moments are gathered for checkpoints only
+    shard_table_optimizer: bool = False
     # replay the step from captured hipGraphs (graph F: render / eager guidance / graph B: backward + optimiser); the
     # first steps, and the step after every change of the sample budget, run eagerly.  Any number of views per rank (a
     # step's views are rendered as one batch).
     graph_step: bool = True
-    # a guidance object that is itself capturable (guidance.capturable: device ops only, device-side RNG -- the synthetic
-    # one) is captured INSIDE the step graph: one graph launch per step.  False: graph F / eager guidance / graph B always
+    # a guidance object that runs on the device in the renderer's own layout (train_step_image: the synthetic one, ONE HIP
+    # launch, counter-based noise) is called that way -- eager steps and captured steps alike -- and sits INSIDE the step
+    # graph: one graph launch per step.  False: the reference's call shape `train_step(text_z, latents [B,C,H,W])`
+    # (what a real diffusion model gets): graph F / eager guidance / graph B
     graph_guidance: bool = True
     # data parallel on RCCL: the gradient exchange (per-group sums + all-reduces, flat bucket) and the optimiser are
     # captured INTO the step graph (RCCL's collectives are capturable; one graph launch per step on every rank, no eager

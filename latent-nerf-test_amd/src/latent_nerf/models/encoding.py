@@ -17,10 +17,12 @@ class GridLevels:
 
     def __init__(self, num_levels=16, level_dim=2, base_resolution=16, desired_resolution=2048,
                  log2_hashmap_size=19, gridtype="hash"):
-        if gridtype not in ("hash", "blocked"):
-            raise ValueError("gridtype must be 'hash' (Instant-NGP) or 'blocked' (4 x 2 x 2 vertex blocks per 64-byte line)")
-        # flag OR-ed into the `variant` of every gather / scatter call (include/lnerf_hip.h LNERF_GRID_BLOCKED)
-        self.gridtype, self.flag = gridtype, (_b.GRID_BLOCKED if gridtype == "blocked" else 0)
+        if gridtype not in ("hash", "tiled", "blocked"):
+            raise ValueError("gridtype must be 'hash' (Instant-NGP), 'tiled' (the upstream encoder's other layout: dense "
+                             "index wrapped) or 'blocked' (4 x 2 x 2 vertex blocks per 64-byte line)")
+        # flag OR-ed into the `variant` of every gather / scatter call (include/lnerf_hip.h LNERF_GRID_BLOCKED / _TILED)
+        self.gridtype = gridtype
+        self.flag = {"hash": 0, "blocked": _b.GRID_BLOCKED, "tiled": _b.GRID_TILED}[gridtype]
         if level_dim != 2:
             raise ValueError("only level_dim == 2 is built")
         if not (1 <= num_levels <= 32):
@@ -243,6 +245,12 @@ class GradSink:
         self.written = 0
         self.groups = groups
         self.pending = None   # (bound, levels, m_host, level_stride, variant, workspace) of a binned, not yet summed backward
+        # {data_ptr of a small parameter: its view of GradSync's flat bucket}: a backward pass may write such a gradient
+        # there directly (and sets small_written, for good: replays of a captured backward repeat the write without any
+        # Python); None: everything goes through `.grad`
+        self.small_direct = None
+        self.small_written = False
+        self.shard_ranges, self.shard_rest = None, None   # row-sharded optimiser (GradSync._plan_shards)
 
 
 def level_groups(levels: GridLevels, n_groups=4):

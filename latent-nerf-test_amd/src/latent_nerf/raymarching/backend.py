@@ -21,6 +21,7 @@ SCATTER_DEFER_FINISH = 0x200  # flag on the scatter's variant: lnerf_step_tail r
 MLP_DEFER_REDUCE = 0x200      # flag on lnerf_mlp_backward's precision tag: lnerf_step_tail sums the slabs
 TAIL_TICK, TAIL_CLEAR_SCATTER = 1, 2
 GRID_BLOCKED = 0x400          # flag on the gather's / scatter's variant: blocked layout of the hashed levels
+GRID_TILED = 0x800            # ... the upstream's `tiled` layout (dense index wrapped instead of hashed)
 SCATTER_CLEARED = 0x100       # flag on the scatter's variant: the caller cleared the cursors (lnerf_grid_scatter_clear_bytes)
 
 
@@ -82,6 +83,7 @@ _SIGNATURES = {
     "lnerf_composite_rays_train_forward": [_P, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P, _P],
     "lnerf_composite_rays_train_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P],
     "lnerf_opacity_entropy_grad": [_P, _L, _F, _F, _P, _P],
+    "lnerf_synthetic_guidance": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _F, _U, _P, _P, _P, _F, _F, _P, _P],
     "lnerf_occ_cell_points": [_P, _L, _I, _I, _F, _P, _P, _P],
     "lnerf_occ_update": [_P, _P, _L, _P, _F, _P, _P],
     "lnerf_occ_mean": [_P, _L, _P, _P, _P],

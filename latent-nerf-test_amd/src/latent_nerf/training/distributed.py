@@ -135,7 +135,14 @@ class GradSync:
     mixed-precision data parallelism).  Small parameters always travel in f32."""
 
     def __init__(self, big: Iterable[torch.nn.Parameter], small: Iterable[torch.nn.Parameter],
-                 group: Optional[dist.ProcessGroup] = None, transport: torch.dtype = torch.float32):
+                 group: Optional[dist.ProcessGroup] = None, transport: torch.dtype = torch.float32,
+                 shard_optimizer: bool = False):
+        """shard_optimizer (pipelined bf16 exchange only, see allreduce_pipelined): the table's optimiser state is
+        sharded by rows -- reduce-scatter of the bf16 gradient, the OWNING rank steps its 1/N of the rows, all-gather of
+        the bf16 shadow the gather reads.  Same wire bytes as the all-reduce (which is a reduce-scatter + an all-gather
+        of the gradient), a 1/N share of the Adam pass's 30 bytes per table entry, and the direct RS + AG shape xGMI's
+        point-to-point links favour.  The f32 master table and the moments are then only
+        current on their owner: gather_rows() before anything reads them whole (checkpoints)."""
         self.big = list(big)
         self.small = list(small)
         self.group = group
@@ -146,7 +153,9 @@ class GradSync:
         self._flat_views = []
         self._wire = {}
         self._sinks = {}
+        self.shard_optimizer = bool(shard_optimizer)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         # gradients are exchanged: more than one rank -- or a forced exchange (the collectives then run over a
         # communicator of size 1; every buffer, launch and wait of the N > 1 step is the same)
         self.active = exchange_active(group)
@@ -163,14 +172,25 @@ class GradSync:
 
     def _pack_small(self):
         """The small parameters' gradients into the flat bucket: ONE multi-tensor copy (a copy per parameter is a
-        dependent ~5 us dispatch each, twice per step)."""
+        dependent ~5 us dispatch each, twice per step) -- and none at all for the tensors whose backward wrote its
+        gradient straight into its view of the bucket (GradSink.small_direct: the MLP's six tensors)."""
         flat = self._flat_buffer()
-        grads = []
-        for p in self.small:
+        # (small_written is sticky: a replayed hipGraph writes the views again without running any Python that could
+        # raise the flag per step)
+        direct = {}
+        for sink in self._sinks.values():
+            if sink.small_written:
+                direct.update(sink.small_direct or {})
+        dst, src = [], []
+        for p, view in zip(self.small, self._flat_views):
             if p.grad is None:
+                if direct.get(p.data_ptr()) is view:
+                    continue
                 raise RuntimeError("GradSync: a parameter has no gradient on this rank")
-            grads.append(p.grad)
-        torch._foreach_copy_(self._flat_views, grads)
+            dst.append(view)
+            src.append(p.grad)
+        if dst:
+            torch._foreach_copy_(dst, src)
         return flat
 
     def _unpack_small(self):
@@ -199,8 +219,51 @@ class GradSync:
         self._sink_levels = getattr(encoder, "levels", None)
         self._wire[id(p)] = sink.wire
         self._sinks[id(p)] = sink
+        if sink.groups and self.small:
+            # pipelined form: a backward pass that produces small-parameter gradients itself (the fused MLP) may write
+            # them straight into their views of the flat bucket and return no `.grad` for them
+            self._flat_buffer()
+            sink.small_direct = {q.data_ptr(): v for q, v in zip(self.small, self._flat_views)}
+        if self.shard_optimizer:
+            if not sink.groups:
+                raise ValueError("shard_optimizer needs the pipelined exchange (pipeline_groups >= 1)")
+            if encoder.shadow() is None:
+                raise ValueError("shard_optimizer needs the bf16 table shadow (what the all-gather distributes)")
+            self._shadow_of = encoder.shadow
+            self._plan_shards(sink, p)
         encoder.grad_sink = sink
         return sink
+
+    # ---- sharded table optimiser: row ranges
+    def _plan_shards(self, sink, table):
+        """Exchange ranges of the level groups for the row-sharded optimiser.  A rank's shard must start on a multiple of
+        4 rows (16-byte accesses of the Adam kernel on the bf16 gradient), so group boundaries are rounded DOWN to
+        multiples of 4 * world -- rows between a rounded boundary and the level boundary travel with the next group,
+        whose sums exist by then -- and the last < 4 * world rows of the table stay replicated (all-reduce, stepped by
+        every rank).  [(A, B)] per group with (B - A) % (4 * world) == 0, and the replicated remainder [B_last, rows)."""
+        offs = self._sink_levels.offsets
+        gran = 4 * self.world
+        n_rows = table.shape[0]
+        cuts = [0] + [(offs[hi] // gran) * gran for _lo, hi in sink.groups]
+        cuts[-1] = (n_rows // gran) * gran
+        sink.shard_ranges = [(cuts[i], cuts[i + 1]) for i in range(len(sink.groups))]
+        sink.shard_rest = (cuts[-1], n_rows)
+
+    def my_rows(self, a, b):
+        n = (b - a) // self.world
+        return a + self.rank * n, a + (self.rank + 1) * n
+
+    def gather_rows(self, tensors):
+        """Sharded optimiser: make `tensors` ([rows, 2] each: the f32 master table, its moments) whole on every rank
+        from their owners' rows.  Collective; for checkpoints and end-of-run checks, never on the step's path."""
+        if not (self.shard_optimizer and self.active):
+            return
+        sink = next(iter(self._sinks.values()))
+        for t in tensors:
+            for a, b in sink.shard_ranges:
+                if b > a:
+                    lo, hi = self.my_rows(a, b)
+                    dist.all_gather_into_tensor(t[a:b], t[lo:hi].clone(), group=self.group)
 
     def reduced(self):
         """{parameter: tensor holding the reduced gradient} after allreduce(copy_back=False) / allreduce_pipelined():
@@ -259,24 +322,52 @@ class GradSync:
             raise RuntimeError("allreduce_pipelined() needs attach_sink(encoder, pipeline_groups >= 1)")
         offs = self._sink_levels.offsets
         groups = []
-        for lo, hi in sink.groups:
+        gathers = []
+        for gi, (lo, hi) in enumerate(sink.groups):
             grid_scatter_reduce_group(sink, lo, hi)
-            rows = sink.wire[offs[lo]:offs[hi]]
-            work = dist.all_reduce(rows, group=self.group, async_op=True) if self.active else None
-            groups.append((offs[lo], offs[hi], work))
+            if not self.shard_optimizer:
+                rows = sink.wire[offs[lo]:offs[hi]]
+                work = dist.all_reduce(rows, group=self.group, async_op=True) if self.active else None
+                groups.append((offs[lo], offs[hi], work))
+                continue
+            # row-sharded optimiser: this rank receives the SUM of its 1/N of the group's rows, steps them, and hands
+            # their new bf16 shadow rows to everybody (the all-gather is launched by the optimiser right behind that
+            # group's Adam launch: `after`)
+            a, b = sink.shard_ranges[gi]
+            if b > a:
+                r0, r1 = self.my_rows(a, b)
+                mine = sink.wire[r0:r1]     # in place: the reduce-scatter's output is this rank's slice of its input
+                work = dist.reduce_scatter_tensor(mine, sink.wire[a:b], group=self.group, async_op=True) if self.active else None
+
+                def after(a=a, b=b, r0=r0, r1=r1):
+                    sh = self._shadow_of()
+                    gathers.append(dist.all_gather_into_tensor(sh[a:b], sh[r0:r1], group=self.group, async_op=True))
+                groups.append((r0, r1, work, after))
+            if gi == len(sink.groups) - 1 and sink.shard_rest[1] > sink.shard_rest[0]:
+                ra, rb = sink.shard_rest   # the table's last few rows: replicated (see _plan_shards)
+                work = dist.all_reduce(sink.wire[ra:rb], group=self.group, async_op=True) if self.active else None
+                groups.append((ra, rb, work))
         sink.written += 1     # (`pending` stays: a replayed hipGraph bins again without running any Python)
         small_work = None
         if self.small:
             flat = self._pack_small()
             if self.active:
                 small_work = dist.all_reduce(flat, group=self.group, async_op=True)
-        return PendingExchange(groups, self, small_work)
+        return PendingExchange(groups, self, small_work, gathers)
 
 
 class PendingExchange:
-    def __init__(self, table_groups, sync, small_work):
+    def __init__(self, table_groups, sync, small_work, gathers=None):
         self.table_groups = table_groups
         self._sync, self._work = sync, small_work
+        self._gathers = gathers if gathers is not None else []
+
+    def finish_gathers(self):
+        """Sharded optimiser: orders the current stream behind the all-gathers of the shadow rows the optimiser step
+        launched (call after optimizer.step(): the next gather reads the whole shadow)."""
+        for w in self._gathers:
+            w.wait()
+        del self._gathers[:]
 
     def finish_small(self, copy_back=False):
         """Orders the current stream behind the flat bucket's all-reduce.  The sums stay in the bucket

@@ -80,7 +80,9 @@ class SyntheticGuidance(Guidance):
         self.min_step, self.max_step = 20, 980
         betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000) ** 2   # SD "scaled_linear" schedule
         self.alphas = torch.cumprod(1.0 - betas, 0).to(device)
-        self.weights = torch.sqrt(self.alphas) * (1 - self.alphas)
+        self.weights = (torch.sqrt(self.alphas) * (1 - self.alphas)).contiguous()
+        self.seed = int(seed)
+        self._targets_rows = {}     # (H, W) -> targets as [6, H*W, C] rows (the renderer's image layout)
 
     def get_text_embeds(self, prompt):
         return torch.zeros(2, 77, 768, device=self.device)
@@ -107,6 +109,37 @@ class SyntheticGuidance(Guidance):
         grad = torch.randn_like(latents).mul_(self.noise_scale)
         grad.add_(latents - target)
         return grad.mul_(w)
+
+    @torch.no_grad()
+    def train_step_image(self, image, dirs_dev, H, W, step_dev, weights_sum=None, sparsity_scale=0.0, eps=1e-5):
+        """The same guidance as ONE HIP launch on the renderer's own layout (lnerf_synthetic_guidance): image
+        [B, H*W, C] -> (gradient w.r.t. image [B, H*W, C], gradient of sparsity_scale * sparsity_loss(weights_sum) or
+        None).  dirs_dev: int32 [B] on the device; step_dev: the optimiser's device step counter (noise and timestep are
+        counter-based functions of (seed, *step_dev, element): capturable, fresh on every graph replay).  What the NeRF
+        trainer calls, eager and captured alike; the [B,C,H,W] forms above keep the reference's call shape."""
+        from ..raymarching import backend as _b
+        from ..raymarching.raymarching import _chk, _p, _stream
+        B, N, C = image.shape
+        key = (int(H), int(W))
+        rows = self._targets_rows.get(key)
+        if rows is None:
+            t = self.targets
+            if t.shape[-2:] != key:
+                t = torch.nn.functional.interpolate(t, size=key, mode="bilinear", align_corners=False)
+            rows = t.permute(0, 2, 3, 1).reshape(t.shape[0], N, C).contiguous()
+            self._targets_rows[key] = rows
+        img = image.detach()
+        grad = torch.empty_like(img)
+        gws = None
+        if weights_sum is not None and sparsity_scale > 0:
+            weights_sum = weights_sum.detach().contiguous()
+            gws = torch.empty_like(weights_sum)
+        _b.call("lnerf_synthetic_guidance", _chk(img, "image"), _p(rows), _chk(dirs_dev, "dirs", torch.int32),
+                _p(self.weights), int(B), int(N), int(C), int(rows.shape[0]), int(self.min_step), int(self.max_step),
+                float(self.noise_scale), self.seed & 0xFFFFFFFF, _chk(step_dev, "step_dev", torch.int32), _p(grad),
+                None if gws is None else _p(weights_sum), float(sparsity_scale), float(eps), None if gws is None else _p(gws),
+                _stream())
+        return grad, gws
 
     @torch.no_grad()
     def train_step(self, text_z, latents, dirs=None):

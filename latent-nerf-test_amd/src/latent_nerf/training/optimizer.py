@@ -136,8 +136,10 @@ class FusedAdam:
     def step(self, grad_scale=None, set_to_none=True, grads=None, row_groups=None):
         """grads: optional {parameter: gradient tensor} overriding `.grad` for the big tensors -- f32, or the bf16
         wire buffer of GradSync (`GradSync.reduced()`), which the Adam kernel then reads directly.
-        row_groups: optional {parameter: [(row_lo, row_hi, work), ...]} -- that parameter is stepped one row range at a
-        time, each after `work.wait()` (a pipelined exchange: PendingExchange.table_groups); `work` may be None."""
+        row_groups: optional {parameter: [(row_lo, row_hi, work[, after]), ...]} -- that parameter is stepped one row range
+        at a time, each after `work.wait()` (a pipelined exchange: PendingExchange.table_groups); `work` may be None;
+        `after()` is called right behind that range's launch (the sharded optimiser's all-gather of the new shadow rows).
+        Ranges need not cover the parameter (a rank of the row-sharded optimiser steps only the rows it owns)."""
         if grad_scale is None:
             grad_scale = self.grad_scale
         elif self.fused is not None and float(grad_scale) != float(self.grad_scale):
@@ -162,13 +164,15 @@ class FusedAdam:
             shadow = enc.shadow() if (enc is not None and p is enc.embeddings) else None
             gdt = _b.F32 if g.dtype == torch.float32 else _b.BF16
             ranges = [(0, p.shape[0], None)] if (row_groups is None or p not in row_groups) else row_groups[p]
-            for r0, r1, work in ranges:
+            for r0, r1, work, *rest in ranges:
                 if work is not None:
-                    work.wait()        # (orders the current stream behind that group's all-reduce)
+                    work.wait()        # (orders the current stream behind that group's collective)
                 sl = slice(r0, r1)
                 _b.call("lnerf_adam_step", _p(p.data[sl]), _p(g[sl]), gdt, _p(m[sl]), _p(v[sl]),
                         None if shadow is None else _p(shadow[sl]), p.data[sl].numel(), lr, b1, b2, self.eps,
                         self.step_no, _p(self.step_dev), float(grad_scale), 0, _stream())
+                if rest and rest[0] is not None:
+                    rest[0]()
         pend = self.fused.pending_tail if self.fused is not None else None
         if self.fused is not None and self.fused.closed:
             self.fused.closed = False      # the armed backward closed the step: nothing left to launch

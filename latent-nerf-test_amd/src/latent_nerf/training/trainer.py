@@ -10,6 +10,7 @@ Every render/backward/optimiser op runs on the HIP library; this file is plumbin
 import json
 import math
 import os
+import time
 from pathlib import Path
 
 import numpy as np
@@ -78,14 +79,17 @@ class Trainer:
         # `torch.cuda.stream(trainer.stream)` (or set optim.graph_step = false).
         self.stream = torch.cuda.Stream(device=self.device)
         self._gstep, self._gstep_capacity, self._static, self._whole = None, None, None, False
-        self.graph_stats = {"captures": 0, "replayed_steps": 0, "eager_steps": 0}
+        # (host_s: host time spent enqueueing replayed steps -- pose, upload, graph launch; refreshes not included)
+        self.graph_stats = {"captures": 0, "replayed_steps": 0, "eager_steps": 0, "host_s": 0.0}
         small = [p for p in self.nerf.parameters() if p is not self.nerf.encoder.embeddings]
         # exchange: bf16 on the wire with the bf16 configuration (f32 otherwise); with one view per rank and step the
         # backward pass writes the wire buffer itself and the table travels in level groups (pipelined with the sums)
         bf16 = cfg.render.precision("mlp_precision") == "bf16"
-        self.grad_sync = D.GradSync([self.nerf.encoder.embeddings], small,
-                                    transport=torch.bfloat16 if bf16 else torch.float32)
         self.pipelined = self.exchange and bf16
+        # optim.shard_table_optimizer: reduce-scatter / owner steps its rows / all-gather of the shadow (GradSync)
+        self.sharded = bool(getattr(cfg.optim, "shard_table_optimizer", False)) and self.pipelined
+        self.grad_sync = D.GradSync([self.nerf.encoder.embeddings], small,
+                                    transport=torch.bfloat16 if bf16 else torch.float32, shard_optimizer=self.sharded)
         # The exchange goes into the captured step where the collectives can be captured (RCCL; not gloo's host staging)
         # AND the form has been seen to reproduce the eager exchange: optim.graph_collectives = "auto" (default) takes it
         # for a communicator of ONE rank (LNERF_FORCE_DIST; tests/test_gpu_distributed.py pins captured == eager bit for
@@ -172,14 +176,15 @@ class Trainer:
             return self.diffusion.train_step(self.text_z[int(dirs[0])], pred)
         return torch.cat([self.diffusion.train_step(self.text_z[int(d)], pred[i:i + 1]) for i, d in enumerate(dirs)])
 
-    def _backward(self, out, pred, grad):
+    def _backward(self, out, pred, grad, grad_ws=None):
         """SDS: d(loss)/d(pred) = grad (src/latent_paint_mesh/training/trainer.py:657-658).  The sparsity term's gradient
-        w.r.t. weights_sum comes from one HIP launch and enters the compositing backward beside it; the shape term (a
-        function of the samples) goes through autograd."""
+        w.r.t. weights_sum comes from one HIP launch (`grad_ws` when the caller already has it) and enters the
+        compositing backward beside it; the shape term (a function of the samples) goes through autograd."""
         tensors, grads = [pred], [grad]
         if self.cfg.optim.lambda_sparsity > 0:
             tensors.append(out["weights_sum"])
-            grads.append(sparsity_loss_grad(out["weights_sum"], self.cfg.optim.lambda_sparsity))
+            grads.append(grad_ws if grad_ws is not None
+                         else sparsity_loss_grad(out["weights_sum"], self.cfg.optim.lambda_sparsity))
         if self.shape_loss is not None and self.cfg.optim.lambda_shape > 0:
             loss = self.cfg.optim.lambda_shape * self.shape_loss(out["xyzs"], out["sigmas"], out["counter"])
             tensors.append(loss)
@@ -213,6 +218,7 @@ class Trainer:
             ex.finish_small()
             self.optimizer.step(grad_scale=scale, grads=self.grad_sync.reduced(),
                                 row_groups={self.nerf.encoder.embeddings: ex.table_groups})
+            ex.finish_gathers()     # (sharded optimiser: the new shadow rows of every owner; no-op otherwise)
         else:
             self.grad_sync.allreduce()
             self.optimizer.step(grad_scale=scale)
@@ -271,8 +277,30 @@ class Trainer:
         st, r = self._static, self.cfg.render
         return (st["poses"], st["intr"], r.train_h, r.train_w)
 
+    def _device_guidance(self):
+        """The guidance runs as ONE HIP launch on the render's own image layout, together with the sparsity gradient
+        (SyntheticGuidance.train_step_image): eager and captured steps alike, so that the two stay bit-identical.
+        optim.graph_guidance = false keeps the `train_step(text_z, latents [B,C,H,W])` call shape of the reference."""
+        return (hasattr(self.diffusion, "train_step_image") and bool(getattr(self.cfg.optim, "graph_guidance", True))
+                and self.optimizer.step_dev is not None)
+
+    def _device_guided_backward(self):
+        """render -> fused guidance + sparsity gradient -> backward (+ exchange + optimiser) on the static views."""
+        st, r = self._static, self.cfg.render
+        out = self.nerf.render(None, None, staged=False, perturb=True, bg_color=None, force_all_rays=True,
+                               camera=self._camera())
+        gi, gws = self.diffusion.train_step_image(out["image"], st["dirs"], r.train_h, r.train_w, self.optimizer.step_dev,
+                                                  out["weights_sum"], float(self.cfg.optim.lambda_sparsity))
+        self.optimizer.arm()          # no exchange: the scatter applies the table's Adam step (no-op otherwise)
+        self._backward(out, out["image"], gi, gws)
+        return out
+
     def _eager_step(self):
         dirs = self._upload_views()
+        if self._device_guidance():
+            out = self._device_guided_backward()
+            self._exchange_and_step(len(self.views))
+            return None, out
         out, pred = self._render_train(self._camera())
         grad = self._guidance_grad(pred, dirs)
         self.optimizer.arm()          # no exchange: the scatter applies the table's Adam step (no-op otherwise)
@@ -312,21 +340,17 @@ class Trainer:
             if solo or inline:
                 self._exchange_and_step(n_views)   # (inline: collectives and the optimiser's waits on them are captured)
 
-        # a guidance that is itself capturable (the synthetic one) goes INSIDE the graph: one launch per step
-        self._whole = bool(getattr(self.diffusion, "capturable", False)) and hasattr(self.diffusion, "train_step_device") \
-            and bool(getattr(self.cfg.optim, "graph_guidance", True))
+        # a guidance that runs on the device (the synthetic one: one HIP launch) goes INSIDE the graph: one graph launch
+        # per step
+        self._whole = self._device_guidance()
         if self._whole:
             from .graph_step import GraphedWholeStep
 
             def whole():
-                out, pred = forward()
-                grad = self.diffusion.train_step_device(pred, st["dirs"])
-                if solo:
-                    opt.arm()
-                self._backward(out, pred, grad)
+                out = self._device_guided_backward()
                 if solo or inline:
                     self._exchange_and_step(n_views)
-                return out, pred
+                return out, out["image"]
 
             build = lambda: GraphedWholeStep(whole, list(self.nerf.parameters()), self.stream)
         else:
@@ -397,7 +421,9 @@ class Trainer:
                 if use_graph and self._gstep is None and eager_left <= 0:
                     self._capture()
                 if use_graph and self._gstep is not None:
+                    t0 = time.perf_counter()
                     self._graphed_step()
+                    self.graph_stats["host_s"] += time.perf_counter() - t0
                 else:
                     eager_left -= 1
                     self.graph_stats["eager_steps"] += 1
@@ -458,6 +484,9 @@ class Trainer:
     # ------------------------------------------------------------------ checkpoints
     # schema of src/latent_paint/training/trainer.py:288-310: {'train_step', 'checkpoints', 'model'[, 'optimizer']}
     def save_checkpoint(self, full=False):
+        if self.sharded:   # (collective: every rank calls save_checkpoint) master table and moments whole again
+            big = self.optimizer.big[0]
+            self.grad_sync.gather_rows([self.nerf.encoder.embeddings.data, big[1], big[2]])
         if self.rank != 0:
             return None
         name = "step_%06d" % self.train_step

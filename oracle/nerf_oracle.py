@@ -340,6 +340,7 @@ class GridLevels:
     scales: list           # float32 per-level scale  (exp2(l*S)*base - 1)
     resolutions: list      # ceil(scale)+1
     blocked: bool = False  # opt-in layout of the hashed levels (grid_corner_indices)
+    tiled: bool = False    # the upstream encoder's `gridtype = "tiled"`: dense index wrapped instead of hashed
 
     @property
     def n_rows(self) -> int:
@@ -347,7 +348,7 @@ class GridLevels:
 
 
 def make_grid_levels(num_levels=16, level_dim=2, base_resolution=16, desired_resolution=2048,
-                     log2_hashmap_size=19, blocked=False) -> GridLevels:
+                     log2_hashmap_size=19, blocked=False, tiled=False) -> GridLevels:
     """Level table of the Instant-NGP hash grid (align_corners=False convention: a level with
     resolution R stores (R+1)^3 vertices, capped at 2^log2_hashmap_size, rounded up to 8)."""
     max_params = 2 ** log2_hashmap_size
@@ -366,18 +367,24 @@ def make_grid_levels(num_levels=16, level_dim=2, base_resolution=16, desired_res
         scales.append(scale)
         ress.append(int(math.ceil(scale)) + 1)
     return GridLevels(num_levels, level_dim, base_resolution, desired_resolution, log2_hashmap_size,
-                      offsets, scales, ress, bool(blocked))
+                      offsets, scales, ress, bool(blocked), bool(tiled))
 
 
 _PRIMES = (1, 2654435761, 805459861)
 
 
-def grid_corner_indices(pos_grid: torch.Tensor, res: int, hashmap_size: int, blocked: bool = False) -> torch.Tensor:
+def grid_corner_indices(pos_grid: torch.Tensor, res: int, hashmap_size: int, blocked: bool = False,
+                        tiled: bool = False) -> torch.Tensor:
     """pos_grid int64 [...,3] -> row index inside the level (uint32 arithmetic).
+    tiled (the upstream gridencoder's `gridtype = "tiled"`, SURVEY.md Appendix A [UPSTREAM-RECALL]): the dense index
+    x + y (res + 1) + z (res + 1)^2, wrapped to 32 bits, modulo the table size -- no hash.
     blocked (our own opt-in variant, include/lnerf_hip.h LNERF_GRID_BLOCKED; dense levels unchanged): on a hashed level
     the lattice is cut into blocks of 4 x 2 x 2 vertices, the block coordinate is hashed, a block's 16 rows are
     consecutive: row = (hash(x >> 2, y >> 1, z >> 1) mod (hashmap_size // 16)) * 16 + (x & 3) + 4 (y & 1) + 8 (z & 1)."""
     m = 0xFFFFFFFF
+    if tiled and (res + 1) ** 3 > hashmap_size:
+        st = res + 1
+        return ((pos_grid[..., 0] + pos_grid[..., 1] * st + pos_grid[..., 2] * st * st) & m) % hashmap_size
     if blocked and (res + 1) ** 3 > hashmap_size:
         x, y, z = pos_grid[..., 0], pos_grid[..., 1], pos_grid[..., 2]
         h = (((x >> 2) * _PRIMES[0]) & m) ^ (((y >> 1) * _PRIMES[1]) & m) ^ (((z >> 1) * _PRIMES[2]) & m)
@@ -450,7 +457,8 @@ def grid_encode(x01: torch.Tensor, table: torch.Tensor, lv: GridLevels, rec8: bo
             wz = frac[:, 2] if bz else 1.0 - frac[:, 2]
             w = (wx * wy) * wz
             corner = pg + torch.tensor([bx, by, bz], dtype=torch.int64)
-            idx = grid_corner_indices(corner, res, hsize, getattr(lv, "blocked", False)) + lv.offsets[l]
+            idx = grid_corner_indices(corner, res, hsize, getattr(lv, "blocked", False), getattr(lv, "tiled", False)) \
+                + lv.offsets[l]
             acc = acc + (_CornerGather.apply(table, idx, w, True) if rec8 else w[:, None] * table[idx])
         outs.append(acc)
     return torch.cat(outs, dim=-1)
@@ -716,3 +724,29 @@ def adam_step(p, g, m, v, step: int, lr: float, beta1=0.9, beta2=0.99, eps=1e-15
     vhat = v / (1 - beta2 ** step)
     p = p - lr * mhat / (torch.sqrt(vhat) + eps)
     return p, m, v
+
+
+def synthetic_guidance(image, targets_rows, dirs, weights, seed: int, step: int, t_lo: int = 20, t_hi: int = 980,
+                       noise_scale: float = 0.05):
+    """The trainer's seeded synthetic guidance as csrc/guidance.hip computes it (lnerf_synthetic_guidance; our own
+    stand-in for `diffusion.train_step` of the reference's src/stable_diffusion.py:248-334 -- weighting form of :274,
+    :320-321): image [B, P, C], targets_rows [6, P, C], dirs [B] ->  w(t) (noise_scale z + image - target_dir)  with the
+    timestep and the normal deviates from occ_hash-style counters of (seed, step, element): Box-Muller on two 24-bit
+    uniforms per channel pair.  float64 transcendental functions here, f32 on the device: compare to ~1e-5."""
+    import numpy as np
+    B, P, C = image.shape
+    n_t = t_hi - t_lo + 1
+    h = int(occ_hash(np.array([0xFFFFFFFF], dtype=np.uint64), seed, step, 7)[0])
+    t = t_lo + ((h * n_t) >> 32)
+    w = float(weights[t])
+    r = np.arange(B * P, dtype=np.uint64)
+    z = np.zeros((B * P, 4), dtype=np.float64)
+    for c in (0, 2):
+        u1 = ((occ_hash(r, seed, step, c) >> np.uint64(8)).astype(np.float64) + 1.0) / 16777216.0
+        u2 = (occ_hash(r, seed, step, c + 1) >> np.uint64(8)).astype(np.float64) / 16777216.0
+        rad = np.sqrt(-2.0 * np.log(u1))
+        z[:, c] = rad * np.cos(2.0 * np.pi * u2)
+        z[:, c + 1] = rad * np.sin(2.0 * np.pi * u2)
+    zt = torch.from_numpy(z[:, :C]).to(torch.float32).reshape(B, P, C)
+    tgt = targets_rows[dirs.long().clamp(0, targets_rows.shape[0] - 1)]
+    return (zt * noise_scale + (image - tgt)) * w, t

@@ -12,7 +12,15 @@ for p in (ROOT, os.path.join(ROOT, "latent-nerf-test_amd")):
 
 
 def digest(t):
-    return hashlib.sha256(t.detach().contiguous().cpu().numpy().tobytes()).hexdigest()
+    t = t.detach().contiguous().cpu()
+    if t.dtype == torch_bf16():
+        t = t.view(__import__("torch").int16)
+    return hashlib.sha256(t.numpy().tobytes()).hexdigest()
+
+
+def torch_bf16():
+    import torch
+    return torch.bfloat16
 
 
 def main():
@@ -29,7 +37,8 @@ def main():
         "log.save_interval": 10000, "log.eval_size": 1, "log.full_eval_size": 2, "optim.fp16": precision == "bf16",
         "guide.text": "a lego man",
         "optim.views_per_step": world, "optim.exchange_groups": groups,
-        "optim.graph_collectives": os.environ.get("LNERF_TEST_GRAPH_COLLECTIVES", "1") != "0"})
+        "optim.graph_collectives": os.environ.get("LNERF_TEST_GRAPH_COLLECTIVES", "1") != "0",
+        "optim.shard_table_optimizer": os.environ.get("LNERF_TEST_SHARD", "0") == "1"})
     tr = Trainer(cfg, device=dev)
     table0 = tr.nerf.encoder.embeddings.detach().clone()
     if save:   # the table after the FIRST step too (Adam's first step is lr * sign(g): an exact comparison point)
@@ -49,6 +58,21 @@ def main():
            "finite": bool(torch.isfinite(tr.nerf.encoder.embeddings).all()),
            "bits_set": int(tr.nerf.density_bitfield.count_nonzero()),
            "noise_seed": int(cfg.render.noise_seed)}
+    sh = tr.nerf.encoder.shadow()
+    res["shadow"] = digest(sh) if sh is not None else None
+    res["sharded"] = bool(getattr(tr, "sharded", False))
+    if res["sharded"]:
+        # the f32 master is only current on each row's owner until it is gathered -- which the checkpoint does (collective:
+        # every rank calls it); the file rank 0 wrote must then hold the table every rank now has
+        res["table_before_gather"] = res["table"]
+        path = tr.save_checkpoint(full=True)
+        torch.cuda.synchronize()
+        res["table"] = digest(tr.nerf.encoder.embeddings)
+        res["moments"] = [digest(tr.optimizer.big[0][1]), digest(tr.optimizer.big[0][2])]
+        if rank == 0:
+            state = torch.load(path, map_location="cpu", weights_only=True)
+            res["ckpt_table"] = hashlib.sha256(state["model"]["encoder.embeddings"].contiguous().numpy().tobytes()).hexdigest()
+            res["ckpt_m"] = hashlib.sha256(state["optimizer"]["exp_avg"][0].contiguous().numpy().tobytes()).hexdigest()
     res["exchange"] = bool(tr.exchange)
     res["capture_exchange"] = bool(tr.capture_exchange)
     res["graph_stats"] = dict(tr.graph_stats)

@@ -2,6 +2,7 @@
 points include/lnerf_hip.h declares.  Only host-side argument validation is exercised here:
 no kernel is launched on a CPU-only machine."""
 import ctypes
+import os
 import re
 import subprocess
 
@@ -135,3 +136,62 @@ def test_scatter_planning_and_new_entry_points_validate(built_lib):
     assert lib.lnerf_set_tuning(b"no_such_knob", 1) == -1 and b"unknown key" in lib.lnerf_last_error()
     # the round-1 switch that produced wrong sums for timing experiments is gone from the library
     assert lib.lnerf_set_tuning(b"scatter_bin_debug", 0) == -1 and b"unknown key" in lib.lnerf_last_error()
+
+
+def _device_asm(src):
+    """gfx950 assembly of one HIP source (device side only), as text."""
+    import subprocess
+    import tempfile
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "latent-nerf-test_amd", "csrc")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "dev.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                               '-DLNERF_BUILD_TAG="asm"', "--cuda-device-only", "-S", "-o", out, os.path.join(csrc, src)],
+                              stderr=subprocess.DEVNULL)
+        return open(out).read()
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_cross_workgroup_handoffs_are_scoped_accesses():
+    """The scatter's pass 2 hands partial tiles between workgroups on different XCDs with RELAXED device-scope accesses
+    plus a hand-written s_waitcnt (csrc/grid.hip, "ORDERING"): correct on gfx950 because the stores are write-through
+    (sc1), acknowledged before the arrival atomic is issued, and the last arriver's loads bypass its L2 (sc1) -- not
+    because of the C++ memory orders.  This pins the ISA the argument rests on: the instructions are there, and no
+    agent-scope fence (an L2 write-back / invalidate per workgroup: 2.6 x the pass's time) has crept in."""
+    import re
+    asm = _device_asm("grid.hip")
+    kernels = re.findall(r"^(_ZN5lnerf16k_scatter_reduceILi1024E\w+):.*?\n(.*?)^\.Lfunc_end", asm, flags=re.S | re.M)
+    fused = [(n, body) for n, body in kernels if "Lb1E" in n]          # FUSE = true: the closing form
+    assert len(fused) == 2                                            # Rec8 and Rec12
+    for name, body in fused:
+        lines = [l.strip() for l in body.splitlines()]
+        st = [i for i, l in enumerate(lines) if l.startswith("global_store_dwordx2") and l.endswith("sc1")]
+        ld = [i for i, l in enumerate(lines) if l.startswith("global_load_dwordx2") and l.endswith("sc1")]
+        at = [i for i, l in enumerate(lines) if l.startswith("global_atomic_add") and "sc0" in l]
+        assert len(st) >= 4 and len(ld) >= 4 and len(at) >= 2, (name, len(st), len(ld), len(at))
+        assert not any(l.startswith(("buffer_wbl2", "buffer_inv")) for l in lines), name
+        # tile stores -> s_waitcnt vmcnt(0) -> barrier -> the slice's arrival atomic -> ... -> tile loads
+        arrive = min(i for i in at if i > st[-1])
+        between = lines[st[-1]:arrive]
+        assert any(l.startswith("s_waitcnt") and "vmcnt(0)" in l for l in between), name
+        assert any(l.startswith("s_barrier") for l in between), name
+        assert ld[0] > arrive, name
+        # the level maximum is ONE device-scope load (the closing arrival zeroes it later in the same launch)
+        assert any(l.startswith("global_load_dword ") and l.endswith("sc1") for l in lines), name
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_no_kernel_of_the_product_build_spills():
+    """Scratch traffic shares the vector-memory queue with the loads a streaming loop waits for: a spilling kernel is a
+    slow kernel on this path.  The product build (no -DLNERF_EXPERIMENTS) compiles every kernel without scratch."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("resource_usage", os.path.join(root, "tools", "resource_usage.py"))
+    ru = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ru)
+    rows = ru.usage()
+    assert len(rows) > 50
+    assert [r["kernel"] for r in rows if r["scratch"] > 0] == []
+    by = {r["kernel"]: r for r in rows}
+    assert by["k_scatter_reduce<1024, Rec8, true>"]["Occupancy [waves/SIMD]"] == 8      # two 1024-thread workgroups per CU
+    assert by["k_scatter_reduce<1024, Rec12, true>"]["Occupancy [waves/SIMD]"] == 8

@@ -55,3 +55,26 @@ def test_blocked_encode_is_differentiable_and_lines_per_sample_drop():
         return n / x.shape[0]
     a, b = lines(lv0), lines(lv)
     assert 3.9 < a < 4.6 and 2.4 < b < 3.2, (a, b)
+
+
+def test_tiled_indices_wrap_the_dense_index():
+    """gridtype = "tiled" (the upstream encoder's other layout): a level too large for its table wraps its dense index
+    -- x-neighbours stay neighbours (mod table size), whole slabs alias -- and dense levels are unchanged."""
+    res, hs = 100, 2 ** 12
+    g = torch.Generator().manual_seed(0)
+    pos = torch.randint(0, res, (2000, 3), generator=g)
+    idx = O.grid_corner_indices(pos, res, hs, tiled=True)
+    assert int(idx.min()) >= 0 and int(idx.max()) < hs
+    st = res + 1
+    assert torch.equal(idx, (pos[:, 0] + pos[:, 1] * st + pos[:, 2] * st * st) % hs)
+    nxt = O.grid_corner_indices(pos + torch.tensor([1, 0, 0]), res, hs, tiled=True)
+    assert torch.equal(nxt, (idx + 1) % hs)
+    small = torch.randint(0, 16, (100, 3), generator=g)
+    assert torch.equal(O.grid_corner_indices(small, 16, hs * 4, tiled=True), O.grid_corner_indices(small, 16, hs * 4))
+    assert not torch.equal(idx, O.grid_corner_indices(pos, res, hs))
+    # 32-bit wrap of the dense index on the finest default level (2049^3 > 2^32), then the table size
+    big = torch.tensor([[2047, 2047, 2047]])
+    want = ((2047 + 2047 * 2049 + 2047 * 2049 * 2049) & 0xFFFFFFFF) % (2 ** 19)
+    assert int(O.grid_corner_indices(big, 2048, 2 ** 19, tiled=True)[0]) == want
+    lv = O.make_grid_levels(tiled=True)
+    assert lv.tiled and lv.offsets == O.make_grid_levels().offsets

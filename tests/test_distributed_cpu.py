@@ -138,3 +138,105 @@ def test_gradsync_single_process_is_noop():
     p.grad = torch.ones(4)
     D.GradSync([p], []).allreduce()
     assert torch.equal(p.grad, torch.ones(4))
+
+
+def _shard_worker(rank, world, port, out):
+    """Row-sharded table optimiser (GradSync(shard_optimizer=True)) with the HIP pieces replaced by plain tensor code:
+    the per-group reduce launch fills the wire rows with this rank's gradient, the 'optimiser' steps the rows it is
+    handed from the reduced gradient and writes the shadow.  Every rank must end with the same, complete shadow --
+    the one a replicated optimiser would have produced -- and gather_rows() must make the master whole."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from src.latent_nerf.models import encoding as E
+
+        class _Levels:
+            num_levels = 6
+            offsets = [0, 40, 112, 312, 824, 1336, 1848 + 8]     # level sizes: multiples of 8 rows, as GridLevels makes them
+            n_rows = offsets[-1]
+
+        n_rows = _Levels.n_rows
+        torch.manual_seed(0)
+        table = torch.nn.Parameter(torch.randn(n_rows, 2))
+        master0 = table.detach().clone()
+        small = [torch.nn.Parameter(torch.randn(8, 4))]
+        shadow = table.detach().to(torch.bfloat16).clone()
+
+        class _Enc:
+            levels = _Levels
+            embeddings = table
+            grad_sink = None
+
+            @staticmethod
+            def shadow():
+                return shadow
+
+        g = torch.Generator().manual_seed(100 + rank)
+        my_grad = torch.randn(n_rows, 2, generator=g).to(torch.bfloat16)
+
+        def fake_reduce(sink, lo, hi):   # pass 2 of levels [lo, hi): this rank's gradient rows into the wire buffer
+            a, b = _Levels.offsets[lo], _Levels.offsets[hi]
+            sink.wire[a:b] = my_grad[a:b]
+
+        real = E.grid_scatter_reduce_group
+        E.grid_scatter_reduce_group = fake_reduce
+        try:
+            sync = D.GradSync([table], small, transport=torch.bfloat16, shard_optimizer=True)
+            sink = sync.attach_sink(_Enc, pipeline_groups=3)
+            gran = 4 * world
+            assert all((b - a) % gran == 0 and a % gran == 0 for a, b in sink.shard_ranges)
+            assert sink.shard_ranges[0][0] == 0 and sink.shard_rest[1] == n_rows and sink.shard_rest[1] - sink.shard_rest[0] < gran
+            assert [b for _a, b in sink.shard_ranges[:-1]] == [a for a, _b in sink.shard_ranges[1:]]   # contiguous
+            sink.pending = True
+            small[0].grad = torch.full((8, 4), float(rank + 1))
+            ex = sync.allreduce_pipelined()
+            ex.finish_small()
+            stepped = torch.zeros(n_rows, dtype=torch.bool)
+            for r0, r1, work, *rest in ex.table_groups:          # what FusedAdam.step(row_groups=...) does
+                if work is not None:
+                    work.wait()
+                assert r0 % 4 == 0                                 # 16-byte accesses on the bf16 gradient
+                table.data[r0:r1] -= 0.5 * sink.wire[r0:r1].float()
+                shadow[r0:r1] = table.data[r0:r1].to(torch.bfloat16)
+                stepped[r0:r1] = True
+                if rest and rest[0] is not None:
+                    rest[0]()
+            ex.finish_gathers()
+            assert float(sync.reduced()[small[0]].mean()) == sum(range(1, world + 1))
+        finally:
+            E.grid_scatter_reduce_group = real
+        # reference: the replicated optimiser on the bf16 sum of every rank's gradient
+        grads = [torch.empty_like(my_grad) for _ in range(world)]
+        dist.all_gather(grads, my_grad)
+        total = grads[0].clone()
+        for x in grads[1:]:
+            total = (total.float() + x.float()).to(torch.bfloat16)   # (pairwise bf16 sums: exact order for 2 ranks)
+        want_master = master0 - 0.5 * total.float()
+        owners = int(stepped.sum())
+        assert n_rows // world <= owners <= n_rows // world + 4 * world      # a 1/N share (+ the replicated remainder)
+        if world == 2:
+            assert torch.equal(shadow, want_master.to(torch.bfloat16))         # complete and identical to the replicated step
+        shadows = [torch.empty_like(shadow) for _ in range(world)]
+        dist.all_gather(shadows, shadow)
+        assert all(torch.equal(shadows[0], s) for s in shadows)
+        assert not torch.equal(table.data, want_master) or world == 1         # the master is only current on its owner ...
+        sync.gather_rows([table.data])
+        masters = [torch.empty_like(table.data) for _ in range(world)]
+        dist.all_gather(masters, table.data)
+        assert all(torch.equal(masters[0], m) for m in masters)                # ... until gather_rows()
+        if world == 2:
+            assert torch.equal(table.data, want_master)
+        assert torch.equal(table.data.to(torch.bfloat16), shadow)
+        out[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_sharded_table_optimiser_gloo(world):
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_shard_worker, args=(world, port, out), nprocs=world, join=True)
+    assert dict(out) == {r: "ok" for r in range(world)}

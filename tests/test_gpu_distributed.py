@@ -22,7 +22,7 @@ def _free_port():
 
 
 def _run(tmp_path, world, groups, steps=20, precision="bf16", backend="gloo", force=False, save=False, tag="",
-         graph_collectives=True):
+         graph_collectives=True, shard=False):
     out = tmp_path / ("w%d_g%d_%s%s" % (world, groups, precision, tag))
     out.mkdir()
     port = _free_port()
@@ -31,7 +31,8 @@ def _run(tmp_path, world, groups, steps=20, precision="bf16", backend="gloo", fo
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), LNERF_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0",
                    LNERF_FORCE_DIST="1" if force else "0",
-                   LNERF_TEST_GRAPH_COLLECTIVES="1" if graph_collectives else "0")
+                   LNERF_TEST_GRAPH_COLLECTIVES="1" if graph_collectives else "0",
+                   LNERF_TEST_SHARD="1" if shard else "0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(out), str(groups),
                                        str(steps), precision] + (["save"] if save else []), env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
@@ -61,6 +62,26 @@ def test_two_rank_replicas_stay_bit_identical(built_lib, tmp_path, groups):
     assert a["noise_seed"] != b["noise_seed"]                              # per-rank march jitter
     for key in ("table", "mlp", "density_grid", "bitfield", "mean_density"):
         assert a[key] == b[key], key
+
+
+def test_row_sharded_table_optimiser_two_ranks(built_lib, tmp_path):
+    """optim.shard_table_optimizer: reduce-scatter of the bf16 table gradient, every rank runs Adam on the rows it owns,
+    all-gather of the bf16 shadow the gather reads (the direct RS + AG shape).  Two ranks on one
+    card (gloo), 20 steps with two occupancy refreshes: the SHADOWS (what renders) are bit-identical on both ranks, the
+    f32 masters differ until gathered (each rank only steps its rows) and are bit-identical after the checkpoint's
+    gather; the checkpoint file holds that table and its gathered moments.  Everything downstream of the shadow --
+    density grid, bitfield -- is identical too.  (RCCL's reduce-scatter cannot run on a one-GPU box: unmeasured.)"""
+    a, b = _run(tmp_path, 2, 4, shard=True)
+    assert a["sharded"] and b["sharded"] and a["pipelined"] and a["steps"] == 20
+    assert a["shadow"] == b["shadow"] and a["shadow"] is not None
+    assert a["table_before_gather"] != b["table_before_gather"]      # each master current on its owner's rows only
+    for key in ("table", "moments", "mlp", "density_grid", "bitfield"):
+        assert a[key] == b[key], key
+    assert a["ckpt_table"] == a["table"] and a["ckpt_m"] == a["moments"][0]
+    assert a["finite"] and a["table_moved"] > 0 and a["bits_set"] > 0
+    # the exchange also runs un-sharded in the same worker (default): same shadows on both ranks there as well
+    c, d = _run(tmp_path, 2, 4, tag="_plain")
+    assert not c["sharded"] and c["shadow"] == d["shadow"] and c["table"] == d["table"]
 
 
 def test_f32_exchange_and_single_rank_paths(built_lib, tmp_path):

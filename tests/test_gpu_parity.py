@@ -216,6 +216,7 @@ def _rand_points(M, bound=1.0, seed=0):
 @pytest.mark.parametrize("cfg", ["small", "full"])
 def test_grid_encode_forward_backward(dev, variant, cfg):
     from src.latent_nerf.models import encoding as E
+    from src.latent_nerf.raymarching import backend as B
     if cfg == "small":
         kw = dict(num_levels=16, base_resolution=4, desired_resolution=128, log2_hashmap_size=12)
         M = 3001
@@ -234,7 +235,9 @@ def test_grid_encode_forward_backward(dev, variant, cfg):
     ref = O.grid_encode((x + 1.0) / 2.0, tref, lv)                      # [M, 32]
     stride = M + 37                                                      # level_stride > M on purpose
     m_dev = torch.tensor([M], dtype=torch.int32, device=dev)
-    feat = E.grid_encode_forward(x.to(dev), 1.0, table.to(dev), levels, stride, m_dev, stride, variant=min(variant, 1))
+    # (gather mapping 1 -- levels pinned to XCDs -- exists in experiment builds only)
+    gv = min(variant, 1) if "experiments" in B.get_lib().lnerf_build_info().decode() else 0
+    feat = E.grid_encode_forward(x.to(dev), 1.0, table.to(dev), levels, stride, m_dev, stride, variant=gv)
     got = feat[:, :M, :].permute(1, 0, 2).reshape(M, 32)
     _close(got, ref, 1e-4, 1e-6, "features")
     # backward (scatter-add) vs autograd of the oracle
@@ -250,12 +253,15 @@ def test_grid_encode_forward_backward(dev, variant, cfg):
     _close(dtable, 2 * tref.grad, 1e-3, 2e-5, "dtable accumulates")
 
 
+@pytest.mark.parametrize("gridtype", ["blocked", "tiled"])
 @pytest.mark.parametrize("table_dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("cfg", ["small", "full"])
-def test_blocked_layout_forward_backward(dev, cfg, table_dtype):
-    """gridtype = "blocked" (LNERF_GRID_BLOCKED: hashed levels keep 4 x 2 x 2 vertex blocks in 16 consecutive rows): the
-    gather with every load path (single / pair / aligned quad), the atomic scatter and the bucketed scatter (12- and
-    8-byte records) against the oracle's restatement of the same layout; dense levels unchanged."""
+def test_blocked_and_tiled_layouts_forward_backward(dev, cfg, table_dtype, gridtype):
+    """gridtype = "blocked" (LNERF_GRID_BLOCKED: hashed levels keep 4 x 2 x 2 vertex blocks in 16 consecutive rows) and
+    gridtype = "tiled" (LNERF_GRID_TILED: the upstream encoder's other layout, the dense index wrapped into the table --
+    SURVEY.md Appendix A suggests {hash, tiled} x {16, 19}): the gather with every load path (single / pair / aligned
+    quad), the atomic scatter and the bucketed scatter (12- and 8-byte records) against the oracle's restatement of the
+    same layout; dense levels unchanged."""
     from src.latent_nerf.models import encoding as E
     if cfg == "small":
         kw = dict(num_levels=16, base_resolution=4, desired_resolution=128, log2_hashmap_size=12)
@@ -263,9 +269,9 @@ def test_blocked_layout_forward_backward(dev, cfg, table_dtype):
     else:
         kw = dict(num_levels=16, base_resolution=16, desired_resolution=2048, log2_hashmap_size=19)
         M = 20000
-    lv = O.make_grid_levels(blocked=True, **kw)
+    lv = O.make_grid_levels(blocked=gridtype == "blocked", tiled=gridtype == "tiled", **kw)
     levels = E.GridLevels(kw["num_levels"], 2, kw["base_resolution"], kw["desired_resolution"], kw["log2_hashmap_size"],
-                          gridtype="blocked")
+                          gridtype=gridtype)
     torch.manual_seed(5)
     table = torch.randn(lv.n_rows, 2) * 0.1
     if table_dtype == "bf16":
@@ -276,7 +282,7 @@ def test_blocked_layout_forward_backward(dev, cfg, table_dtype):
     m_dev = torch.tensor([M], dtype=torch.int32, device=dev)
     src = table.to(dev).to(torch.bfloat16) if table_dtype == "bf16" else table.to(dev)
     feat = E.grid_encode_forward(x.to(dev), 1.0, src, levels, M, m_dev, M)
-    _close(feat.permute(1, 0, 2).reshape(M, 32), ref, 1e-4, 1e-6, "blocked features")
+    _close(feat.permute(1, 0, 2).reshape(M, 32), ref, 1e-4, 1e-6, gridtype + " features")
     plain = E.grid_encode_forward(x.to(dev), 1.0, src, E.GridLevels(kw["num_levels"], 2, kw["base_resolution"],
                                                                      kw["desired_resolution"], kw["log2_hashmap_size"]), M, m_dev, M)
     dense = [l for l in range(16) if (lv.resolutions[l] + 1) ** 3 <= lv.offsets[l + 1] - lv.offsets[l]]
@@ -289,7 +295,7 @@ def test_blocked_layout_forward_backward(dev, cfg, table_dtype):
     for variant, atol in ((0, 1e-5), (2, 1e-5), (3, 5e-5)):
         dtable = torch.zeros(lv.n_rows, 2, device=dev)
         E.grid_encode_backward(x.to(dev), 1.0, dfeat, levels, M, m_dev, M, dtable, variant=variant)
-        _close(dtable, tref.grad, 1e-3, atol, "blocked dtable v%d" % variant)
+        _close(dtable, tref.grad, 1e-3, atol, gridtype + " dtable v%d" % variant)
 
 
 @pytest.mark.parametrize("variant", [2, 3])
@@ -523,6 +529,11 @@ def test_mlp_backward_operand_swap_variant_matches_the_default(dev):
     chain is the same arithmetic (dfeat bit-identical), the weight gradients differ by summation order only."""
     from src.latent_nerf.models.network_grid import _SigmaLatentMLP
     from src.latent_nerf.raymarching import backend as B
+    if "experiments" not in B.get_lib().lnerf_build_info().decode():
+        # the product build leaves the rejected variants out: asking for one must fail loudly
+        with pytest.raises(B.LnerfError, match="experiment variant"):
+            B.call("lnerf_set_tuning", b"mlp_bwd_variant", 1)
+        pytest.skip("operand-swap backward: experiment builds only (LNERF_EXPERIMENTS=1 python latent-nerf-test_amd/build.py)")
     M = 70001
     feat, xyz, p = _mlp_inputs(M, seed=5)
     lm0 = feat.reshape(M, 16, 2).permute(1, 0, 2).contiguous().to(dev).to(torch.bfloat16)

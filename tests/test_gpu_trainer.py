@@ -291,12 +291,15 @@ def test_graphed_trainer_matches_eager_trainer_bit_for_bit(dev, tmp_path):
     from src.latent_nerf.training.trainer import Trainer
     for fp16 in (False, True):
         states = []
-        # whole: ONE graph per step (the synthetic guidance is capturable and sits inside it); split: graph F / eager
-        # guidance / graph B (what a real diffusion model gets); eager: no graphs
-        for mode in ("whole", "split", "eager"):
+        # whole: ONE graph per step (the synthetic guidance is one HIP launch on the render's own layout and sits inside
+        # it) against the same guidance called eagerly; split: graph F / eager guidance through the reference's call shape
+        # train_step(text_z, latents [B,C,H,W]) / graph B (what a real diffusion model gets) against that loop without
+        # graphs.  (The two guidance forms draw their noise from different generators: compared pairwise.)
+        for mode, graph, device_guidance in (("whole", True, True), ("eagerdev", False, True), ("split", True, False),
+                                             ("eager", False, False)):
             cfg = _cfg(tmp_path, **{"optim.iters": 20, "log.save_interval": 1000, "optim.fp16": fp16,
-                                    "log.exp_name": "g%d%s" % (fp16, mode), "optim.graph_step": mode != "eager",
-                                    "optim.graph_guidance": mode == "whole", "log.full_eval_size": 1})
+                                    "log.exp_name": "g%d%s" % (fp16, mode), "optim.graph_step": graph,
+                                    "optim.graph_guidance": device_guidance, "log.full_eval_size": 1})
             torch.manual_seed(7)
             torch.cuda.manual_seed(7)
             tr = Trainer(cfg, device=dev)
@@ -304,7 +307,7 @@ def test_graphed_trainer_matches_eager_trainer_bit_for_bit(dev, tmp_path):
             torch.cuda.manual_seed(11)
             tr.train()
             assert tr.train_step == 20
-            if mode != "eager":
+            if graph:
                 assert tr.graph_stats["captures"] >= 1 and tr.graph_stats["replayed_steps"] >= 15, tr.graph_stats
                 assert tr._whole == (mode == "whole")
             else:
@@ -316,11 +319,11 @@ def test_graphed_trainer_matches_eager_trainer_bit_for_bit(dev, tmp_path):
                            "b2": tr.nerf.b2.detach().clone(), "grid": tr.nerf.density_grid.clone(),
                            "bits": tr.nerf.density_bitfield.clone(), "step": opt.step_no,
                            "step_dev": int(opt.step_dev[0].item())})
-        b = states[-1]
-        for a in states[:-1]:
+        for a, b in ((states[0], states[1]), (states[2], states[3])):
             assert a["step"] == b["step"] == 20 and a["step_dev"] == b["step_dev"] == 21
             for k in ("table", "m", "v", "w1", "w3", "b2", "grid", "bits"):
                 assert torch.equal(a[k], b[k]), (fp16, k, float((a[k].float() - b[k].float()).abs().max()))
+        b = states[-1]
         assert float((b["table"] - 0).abs().max()) > 0
 
 
@@ -356,3 +359,34 @@ def test_opacity_entropy_gradient_matches_autograd(dev):
     got = sparsity_loss_grad(ws, 3e-3)
     assert float((got - ref.grad).abs().max()) <= 1e-6 * float(ref.grad.abs().max()) + 1e-12
     assert float(got[0]) == 0.0 and float(got[1]) == 0.0 and float(got[6]) == 0.0 and float(got[5]) == 0.0
+
+
+def test_fused_synthetic_guidance_matches_oracle_and_is_a_counter_function(dev):
+    """lnerf_synthetic_guidance (SyntheticGuidance.train_step_image): the guidance gradient and the sparsity gradient of
+    one step in ONE launch, in the renderer's image layout.  Against the oracle's restatement (integer hash bit-exact,
+    Box-Muller in f32 vs f64: 1e-5), against lnerf_opacity_entropy_grad (bit-exact), and as a FUNCTION of the device
+    step counter: same counter -> same values, next counter -> fresh noise and timestep (what a replayed graph relies on)."""
+    from oracle import nerf_oracle as O
+    from src.latent_nerf.training.guidance import SyntheticGuidance, sparsity_loss_grad
+    B, H, W, C = 3, 16, 16, 4
+    g = SyntheticGuidance(dev, channels=C, size=H, seed=5)
+    torch.manual_seed(0)
+    image = torch.randn(B, H * W, C, device=dev)
+    ws = torch.rand(B, H * W, device=dev)
+    ws[0, :4] = torch.tensor([0.0, 1.0, 1e-6, 0.5], device=dev)
+    dirs = torch.tensor([2, 5, 0], device=dev, dtype=torch.int32)
+    step_dev = torch.tensor([9, 0], device=dev, dtype=torch.int32)
+    gi, gws = g.train_step_image(image, dirs, H, W, step_dev, ws, 5e-4)
+    rows = g.targets.permute(0, 2, 3, 1).reshape(6, H * W, C).cpu()
+    want, t = O.synthetic_guidance(image.cpu(), rows, dirs.cpu(), g.weights.cpu(), 5, 9, g.min_step, g.max_step, g.noise_scale)
+    assert g.min_step <= t <= g.max_step
+    assert float((gi.cpu() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    assert torch.equal(gws, sparsity_loss_grad(ws, 5e-4))
+    # the noise has unit variance and zero mean (B*H*W*C = 3072 deviates)
+    z = (gi.cpu() / float(g.weights[t]) - (image.cpu() - rows[dirs.cpu().long()])) / g.noise_scale
+    assert abs(float(z.mean())) < 0.08 and abs(float(z.std()) - 1.0) < 0.08
+    again, _ = g.train_step_image(image, dirs, H, W, step_dev, None, 0.0)
+    assert torch.equal(again, gi)
+    step_dev[0] += 1
+    fresh, none = g.train_step_image(image, dirs, H, W, step_dev, None, 0.0)
+    assert none is None and not torch.equal(fresh, gi)

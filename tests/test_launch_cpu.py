@@ -1,11 +1,15 @@
 """The rank launcher and the pre-group control plane (src/latent_nerf/training/launch.py) on the CPU: children get a
 complete rendezvous environment, rank 0's stdout comes back, the worst exit code wins, a failing or hanging rank takes
 the job down instead of leaving the others at a barrier, and `agree()` hands every rank the same list of votes."""
+import os
 import sys
 import time
 
 from src.latent_nerf.training import distributed as D
 from src.latent_nerf.training import launch as L
+
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _py(code):
@@ -45,13 +49,12 @@ def test_agree_gives_every_rank_the_same_votes():
             "votes = L.agree(st, 'vote', r, w, 10 * (r + 1), timeout_s=60); "
             "assert votes == ['10', '20'], votes; "
             "L.agree(st, 'done', r, w, 1, timeout_s=60); "     # (rank 0 hosts the store: leave together)
-            "print('ok')") % (sys.path[:2],)
+            "print('ok')") % ([_ROOT, os.path.join(_ROOT, "latent-nerf-test_amd")],)
     rc, out = L.spawn_ranks(_py(code), 2, timeout_s=120)
     assert rc == 0 and out.strip() == "ok"
 
 
 def test_run_child_kills_at_the_limit():
-    import os
     t0 = time.monotonic()
     assert L.run_child(_py("import time; time.sleep(60)"), dict(os.environ), 1.0) == 124
     assert time.monotonic() - t0 < 20

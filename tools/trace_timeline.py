@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-step timeline from a rocprofv3 kernel trace (tools/run_trace.sh): finds the steady-state steps (delimited by the
+"""Per-step timeline from a rocprofv3 kernel trace (tools/run_profile.sh timeline): finds the steady-state steps (delimited by the
 ray-generation kernel (or the march count pass)), and prints for each kernel of a step its mean duration and the mean idle gap BEFORE it.
 
     python tools/trace_timeline.py gpurun_out/<name>_kernel_trace.csv [--json out.json]
