@@ -16,8 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "liblnerf_hip.so")
-SOURCES = ["api.cc", "rays.hip", "grid.hip", "mlp.hip", "mlp_bf16.hip", "composite.hip", "optim.hip", "bg.hip", "mesh.hip", "raster.hip", "guidance.hip"]
-DEPS = ["common.h", "mlp_shared.h", "adam_shared.h", os.path.join("..", "..", "include", "lnerf_hip.h")]
+SOURCES = ["api.cc", "rays.hip", "grid_gather.hip", "grid_bin.hip", "grid.hip", "mlp.hip", "mlp_bf16.hip", "composite.hip", "optim.hip", "bg.hip", "mesh.hip", "raster.hip", "guidance.hip"]
+DEPS = ["common.h", "mlp_shared.h", "adam_shared.h", "grid_shared.h", os.path.join("..", "..", "include", "lnerf_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 # LNERF_EXPERIMENTS=1 in the environment: also compile the measured-and-rejected kernel variants (operand-swap MLP backward,
 # four-wave MLP forward, XCD-pinned gather mappings) that DESIGN.md's experiment log refers to; the product build leaves

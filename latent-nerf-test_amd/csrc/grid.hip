@@ -1,905 +1,9 @@
-// H5/H6 multiresolution hash grid (Instant-NGP encoding, F = 2 features per vertex).
-//
-// Forward is the roofline kernel of the path: per sample and level it gathers
-// 8 vertices x 2 features.  One thread handles one (sample, level); a wavefront handles 64
-// consecutive samples of ONE level, so its 8 gather instructions hit one level's table and its
-// output is 512 contiguous bytes (level-major feature layout).
-//
-// variant 0: blockIdx.y = level.
-// variant 1: XCD-aware.  Workgroups are dealt round-robin over the 8 XCDs (observed, used for
-//            speed only -- correctness never depends on it), so workgroup b serves levels
-//            {b % 8, b % 8 + 8, ...}: each XCD's private 4 MiB L2 then only ever holds the
-//            tables of its own levels instead of all 16.
-#include "common.h"
-#include "adam_shared.h"
-#include "mlp_shared.h"
-
-#include <stdlib.h>
-#include <string.h>
+// H6, pass 2 of the bucketed scatter (fixed-point LDS sums, fused Adam step of the table, the step's tail), the host-side
+// driver of both passes and the C entry points of the scatter.  Gather: grid_gather.hip; pass 1: grid_bin.hip; what
+// the passes share: grid_shared.h.
+#include "grid_shared.h"
 
 namespace lnerf {
-
-__device__ __forceinline__ uint32_t grid_index(uint32_t x, uint32_t y, uint32_t z, uint32_t res, uint32_t hsize) {
-    // dense while the (res+1)^3 vertex lattice fits the level, spatial hash otherwise.
-    // res/hsize are wave-uniform, so both branches below are scalar branches.
-    const uint32_t stride = res + 1;
-    const uint64_t cube = (uint64_t)stride * stride * stride;  // (res+1) <= 2^20: no overflow
-    if (cube <= (uint64_t)hsize) return x + y * stride + z * stride * stride;  // < hsize already
-    const uint32_t index = (x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u);
-    if ((hsize & (hsize - 1u)) == 0u) return index & (hsize - 1u);
-    return index % hsize;
-}
-
-// rows of the 8 vertices of a cell at once: the two integer multiplies of the spatial hash (quarter-rate
-// VALU) are shared by all corners ((y+1)*P == y*P + P mod 2^32), dense levels add strides to one base.
-// blocked (LNERF_GRID_BLOCKED, an opt-in layout of the HASHED levels, not Instant-NGP's): the lattice is cut into blocks
-// of 4 x 2 x 2 vertices, the BLOCK coordinate is hashed and a block's 16 rows are consecutive --
-//     row = (hash(x >> 2, y >> 1, z >> 1) mod (hsize / 16)) * 16 + (x & 3) + 4 (y & 1) + 8 (z & 1)
-// -- so that a block is one 64-byte line of the bf16 table: a cell's 8 vertices touch 1.25 x 1.5 x 1.5 = 2.8 lines on
-// average instead of 4.25 (x pairs share a line either way; here y and z neighbours do half the time).
-// tiled (LNERF_GRID_TILED: `gridtype = "tiled"` of the upstream encoder): a level too large for its
-// table wraps its DENSE index instead of hashing the vertex --
-//     row = (x + y (res + 1) + z (res + 1)^2  mod 2^32)  mod hsize
-// -- x-neighbours stay neighbours, whole y / z slabs alias each other.
-__device__ __forceinline__ void corner_rows(uint32_t gx, uint32_t gy, uint32_t gz, uint32_t res, uint32_t hsize,
-                                            uint32_t row[8], int layout = 0) {
-    const bool blocked = layout == 1;
-    const uint32_t stride = res + 1;
-    const uint64_t cube = (uint64_t)stride * stride * stride;
-    if (cube <= (uint64_t)hsize) {  // wave-uniform
-        // (a dense level has stride^3 <= hsize < 2^31: all factors below 2^24 -- full-rate 24-bit multiplies)
-        const uint32_t s2 = stride * stride;
-        const uint32_t base = gx + __umul24(gy, stride) + __umul24(gz, s2);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) row[c] = base + (c & 1) + ((c >> 1) & 1) * stride + ((c >> 2) & 1) * s2;
-        return;
-    }
-    if (layout == 2) {  // wave-uniform: tiled
-        const uint32_t s2 = stride * stride;   // (uint32 wrap-around, as the upstream's index arithmetic)
-        const uint32_t base = gx + gy * stride + gz * s2;
-        if ((hsize & (hsize - 1u)) == 0u) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-                row[c] = (base + (c & 1) + ((c >> 1) & 1) * stride + ((c >> 2) & 1) * s2) & (hsize - 1u);
-        } else {
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-                row[c] = (base + (c & 1) + ((c >> 1) & 1) * stride + ((c >> 2) & 1) * s2) % hsize;
-        }
-        return;
-    }
-    if (blocked) {  // wave-uniform
-        const uint32_t nblk = hsize >> 4;
-        const uint32_t x1 = gx + 1u;
-        const uint32_t hx[2] = {gx >> 2, x1 >> 2};
-        const uint32_t y0 = (gy >> 1) * 2654435761u, z0 = (gz >> 1) * 805459861u;
-        // (y + 1) >> 1 is the next block exactly when y is odd
-        const uint32_t hy[2] = {y0, (gy & 1u) ? y0 + 2654435761u : y0};
-        const uint32_t hz[2] = {z0, (gz & 1u) ? z0 + 805459861u : z0};
-        const uint32_t wx[2] = {gx & 3u, x1 & 3u};
-        const uint32_t wy[2] = {(gy & 1u) << 2, ((gy + 1u) & 1u) << 2};
-        const uint32_t wz[2] = {(gz & 1u) << 3, ((gz + 1u) & 1u) << 3};
-        if ((nblk & (nblk - 1u)) == 0u) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-                row[c] = (((hx[c & 1] ^ hy[(c >> 1) & 1] ^ hz[(c >> 2) & 1]) & (nblk - 1u)) << 4) |
-                         (wx[c & 1] | wy[(c >> 1) & 1] | wz[(c >> 2) & 1]);
-        } else {
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-                row[c] = (((hx[c & 1] ^ hy[(c >> 1) & 1] ^ hz[(c >> 2) & 1]) % nblk) << 4) |
-                         (wx[c & 1] | wy[(c >> 1) & 1] | wz[(c >> 2) & 1]);
-        }
-        return;
-    }
-    const uint32_t hx[2] = {gx, gx + 1u};
-    const uint32_t y0 = gy * 2654435761u, z0 = gz * 805459861u;
-    const uint32_t hy[2] = {y0, y0 + 2654435761u};
-    const uint32_t hz[2] = {z0, z0 + 805459861u};
-    if ((hsize & (hsize - 1u)) == 0u) {
-        const uint32_t mask = hsize - 1u;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) row[c] = (hx[c & 1] ^ hy[(c >> 1) & 1] ^ hz[(c >> 2) & 1]) & mask;
-    } else {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) row[c] = (hx[c & 1] ^ hy[(c >> 1) & 1] ^ hz[(c >> 2) & 1]) % hsize;
-    }
-}
-
-template <typename T> struct Feat2;
-template <> struct Feat2<float> {
-    static __device__ __forceinline__ float2 load(const float *base, uint32_t row) {
-        return reinterpret_cast<const float2 *>(base)[row];
-    }
-    static __device__ __forceinline__ void store(float *base, int64_t i, float a, float b) {
-        reinterpret_cast<float2 *>(base)[i] = make_float2(a, b);
-    }
-};
-template <> struct Feat2<uint16_t> {  // bf16 pairs in one dword
-    static __device__ __forceinline__ float2 load(const uint16_t *base, uint32_t row) {
-        const uint32_t v = reinterpret_cast<const uint32_t *>(base)[row];
-        return make_float2(__uint_as_float(v << 16), __uint_as_float(v & 0xFFFF0000u));
-    }
-    static __device__ __forceinline__ void store(uint16_t *base, int64_t i, float a, float b) {
-        reinterpret_cast<uint32_t *>(base)[i] = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
-    }
-};
-
-struct LevelPos {
-    uint32_t gx, gy, gz;
-    float fx, fy, fz;
-};
-
-__device__ __forceinline__ LevelPos level_pos_xyz(float x, float y, float z, float bound, float scale) {
-    // x01 = (x + bound) / (2 bound); pos = x01 * scale + 0.5   (op order = oracle grid_encode)
-    const float two_b = 2.0f * bound;
-    float px = x + bound, py = y + bound, pz = z + bound;
-    if ((__float_as_uint(two_b) & 0x007FFFFFu) == 0u) {  // power of two (wave-uniform): x / 2^k == x * 2^-k exactly
-        const float r = 1.0f / two_b;
-        px = px * r; py = py * r; pz = pz * r;
-    } else {
-        px = px / two_b; py = py / two_b; pz = pz / two_b;
-    }
-    px = px * scale; py = py * scale; pz = pz * scale;
-    px = px + 0.5f; py = py + 0.5f; pz = pz + 0.5f;
-    const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
-    LevelPos r;
-    r.gx = (uint32_t)(int)flx; r.gy = (uint32_t)(int)fly; r.gz = (uint32_t)(int)flz;
-    r.fx = px - flx; r.fy = py - fly; r.fz = pz - flz;
-    return r;
-}
-__device__ __forceinline__ LevelPos level_pos(const float *__restrict__ xyzs, int64_t m, float bound, float scale) {
-    return level_pos_xyz(xyzs[m * 3], xyzs[m * 3 + 1], xyzs[m * 3 + 2], bound, scale);
-}
-
-// maps a workgroup to (level, first tile, tile step)
-struct TileMap {
-    int level;
-    int64_t tile0, tstep;
-    bool ok;
-};
-__device__ __forceinline__ TileMap tile_map(int variant, int L) {
-    TileMap t;
-    if (variant == 0) {
-        t.level = blockIdx.y;
-        t.tile0 = blockIdx.x;
-        t.tstep = gridDim.x;
-        t.ok = true;
-    } else {
-        // 1-D grid, gridDim.x = 8 * per_xcd.  slot = position inside the XCD's share.
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
-        const int lv_per_xcd = (L + 7) >> 3;  // levels served by one XCD
-        const int li = slot % lv_per_xcd;
-        t.level = xcd + 8 * li;
-        t.tile0 = slot / lv_per_xcd;
-        t.tstep = per_xcd / lv_per_xcd;
-        t.ok = (t.level < L) && (t.tile0 < t.tstep);
-    }
-    return t;
-}
-
-// Runs of samples that sit in the same grid cell (lanes = consecutive samples of a ray: on coarse levels long
-// runs share all 8 vertices).  `start` = first lane of this lane's run, `tail` = this lane is the last lane of its
-// run.  Computed once per (wave, level) from the cell coordinates; every lane of the wave must call it.
-struct RunInfo {
-    int start;
-    bool tail;
-    unsigned long long heads;  // wave-uniform: bit i = lane i starts a run (bit 0 always set)
-};
-__device__ __forceinline__ RunInfo wave_cell_runs(uint32_t gx, uint32_t gy, uint32_t gz, bool valid, int lane) {
-    const int px = lane_prev_i((int)gx, -1), py = lane_prev_i((int)gy, -1), pz = lane_prev_i((int)gz, -1);
-    const int pv = lane_prev_i((int)valid, 0);
-    const bool head = (lane == 0) || px != (int)gx || py != (int)gy || pz != (int)gz || !valid || !pv;
-    const unsigned long long H = __ballot(head);  // bit 0 is always set
-    RunInfo r;
-    r.start = 63 - __clzll((long long)(H & (~0ull >> (63 - lane))));
-    r.tail = (lane == 63) || ((H >> (lane + 1)) & 1ull);
-    r.heads = H;
-    return r;
-}
-
-// the vertex values of one cell as raw dwords: 8 (bf16 pairs) or 16 (f32 pairs).  load_pair fetches two consecutive
-// table rows with one load (x-adjacent vertices are adjacent rows on dense levels, and on hashed levels when x is
-// even: row(x+1) = row(x) ^ 1): half the cache accesses of those lookups
-template <typename TT> struct CellRaw;
-template <> struct CellRaw<uint16_t> {
-    uint32_t d[8];
-    __device__ __forceinline__ void load_pair(const uint16_t *lt, uint32_t row, int c) {  // rows row, row+1 -> c, c+1
-        const uint2 v = *reinterpret_cast<const uint2 *>(lt + (int64_t)row * 2);
-        d[c] = v.x; d[c + 1] = v.y;
-    }
-    __device__ __forceinline__ void load_one(const uint16_t *lt, uint32_t row, int c) {
-        d[c] = reinterpret_cast<const uint32_t *>(lt)[row];
-    }
-    // rows r0, r1 of ONE aligned group of four rows (16 bytes) with one load -> c, c + 1
-    __device__ __forceinline__ void load_quad(const uint16_t *lt, uint32_t r0, uint32_t r1, int c) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(lt + (int64_t)(r0 & ~3u) * 2);
-        const uint32_t k0 = r0 & 3u, k1 = r1 & 3u;
-        d[c] = (k0 & 2u) ? ((k0 & 1u) ? v.w : v.z) : ((k0 & 1u) ? v.y : v.x);
-        d[c + 1] = (k1 & 2u) ? ((k1 & 1u) ? v.w : v.z) : ((k1 & 1u) ? v.y : v.x);
-    }
-    static constexpr bool kHasQuad = true;
-    __device__ __forceinline__ void swap_pair(int c) { const uint32_t t = d[c]; d[c] = d[c + 1]; d[c + 1] = t; }
-    __device__ __forceinline__ void zero() {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) d[i] = 0u;
-    }
-    __device__ __forceinline__ void take_from_lane(int src) {  // every lane reads lane `src`'s cell
-#pragma unroll
-        for (int i = 0; i < 8; ++i) d[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)d[i]);
-    }
-    __device__ __forceinline__ float2 get(int c) const {
-        return make_float2(__uint_as_float(d[c] << 16), __uint_as_float(d[c] & 0xFFFF0000u));
-    }
-};
-template <> struct CellRaw<float> {
-    float2 d[8];
-    __device__ __forceinline__ void load_pair(const float *lt, uint32_t row, int c) {
-        const float4 v = *reinterpret_cast<const float4 *>(lt + (int64_t)row * 2);  // dword-aligned 16-byte load
-        d[c] = make_float2(v.x, v.y); d[c + 1] = make_float2(v.z, v.w);
-    }
-    __device__ __forceinline__ void load_one(const float *lt, uint32_t row, int c) {
-        d[c] = reinterpret_cast<const float2 *>(lt)[row];
-    }
-    __device__ __forceinline__ void load_quad(const float *, uint32_t, uint32_t, int) {}   // (32 bytes: not used)
-    static constexpr bool kHasQuad = false;
-    __device__ __forceinline__ void swap_pair(int c) { const float2 t = d[c]; d[c] = d[c + 1]; d[c + 1] = t; }
-    __device__ __forceinline__ void zero() {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) d[i] = make_float2(0.f, 0.f);
-    }
-    __device__ __forceinline__ void take_from_lane(int src) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            d[i].x = __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(d[i].x)));
-            d[i].y = __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(d[i].y)));
-        }
-    }
-    __device__ __forceinline__ float2 get(int c) const { return d[c]; }
-};
-
-// variant 2: every XCD serves a fixed SET of levels (workgroups are dealt round-robin over the 8 XCDs -- observed, used
-// for speed only): the 4 MiB L2 of an XCD then holds the whole table of its one fine level (2 MiB bf16) instead of a
-// sixth of all sixteen, and the gather -- bound by the L1's miss concurrency x the latency of a miss -- waits for L2 hits
-// instead of Infinity-Cache hits.  The sets are balanced on the host from a per-level cost estimate.
-struct XcdPlan {
-    int n[8];
-    int lv[8][LNERF_MAX_LEVELS / 8 + 2];
-};
-
-template <typename TT, typename TO>
-__global__ void __launch_bounds__(256)
-k_grid_forward(const float *__restrict__ xyzs, float bound, const TT *__restrict__ table, GridMeta meta, int64_t m_host,
-               const int32_t *__restrict__ m_dev, int64_t level_stride, TO *__restrict__ feat, int variant,
-               int pair_loads, int dedup_max_res, XcdPlan plan) {
-#ifndef LNERF_EXPERIMENTS
-    variant = 0;   // (the XCD-pinned mappings 1 / 2 are compiled into experiment builds only)
-#endif
-    int64_t M = m_host;
-    if (m_dev) { const int64_t md = *m_dev; M = md < M ? md : M; }
-    TileMap tm = tile_map(variant == 2 ? 0 : variant, meta.num_levels);
-    int n_lv = 1;
-    const int xcd = blockIdx.x & 7;
-    if (variant == 2) {
-        n_lv = plan.n[xcd];
-        tm.tile0 = blockIdx.x >> 3;
-        tm.tstep = gridDim.x >> 3;
-        tm.ok = true;
-    }
-    if (!tm.ok) return;
-  for (int li = 0; li < n_lv; ++li) {
-    const int l = variant == 2 ? plan.lv[xcd][li] : tm.level;
-    const float scale = meta.scales[l];
-    const uint32_t res = (uint32_t)meta.res[l];
-    const uint32_t off = (uint32_t)meta.offsets[l];
-    const uint32_t hsize = (uint32_t)(meta.offsets[l + 1] - meta.offsets[l]);
-    const TT *lt = table + (int64_t)off * 2;
-    const bool dense = (uint64_t)(res + 1) * (res + 1) * (res + 1) <= (uint64_t)hsize;  // wave-uniform
-    const bool pow2 = (hsize & (hsize - 1u)) == 0u;
-    // Coarse levels: the 64 lanes of a wave are consecutive samples of a ray and sit in a handful of cells.  The
-    // kernel is bound by the L1's miss path (one cache access per lane gather): only the first lane of
-    // each run of equal cells fetches the 8 vertices, the others take them from it through the LDS crossbar.
-    const bool dedup = (int)res <= dedup_max_res;  // wave-uniform
-    const int lane = lane_id();
-    for (int64_t tile = tm.tile0; tile * 256 < M; tile += tm.tstep) {
-        const int64_t m = tile * 256 + threadIdx.x;
-        const bool valid = m < M;  // (no early exit: the run logic below needs every lane of the wave)
-        LevelPos p;
-        p.gx = p.gy = p.gz = 0u; p.fx = p.fy = p.fz = 0.f;
-        if (valid) p = level_pos(xyzs, m, bound, scale);
-        uint32_t rows[8];
-        corner_rows(p.gx, p.gy, p.gz, res, hsize, rows, meta.blocked);
-        bool fetch = valid;
-        int src = lane;
-        if (dedup) {
-            const RunInfo ri = wave_cell_runs(p.gx, p.gy, p.gz, valid, lane);
-            src = ri.start;
-            fetch = valid && ri.start == lane;
-        }
-        // issue the gathers first, blend afterwards (keeps up to 8 loads in flight per lane)
-        CellRaw<TT> cell;
-        cell.zero();
-        if (fetch) {
-            if (pair_loads && dense) {
-#pragma unroll
-                for (int c = 0; c < 8; c += 2) cell.load_pair(lt, rows[c], c);  // rows[c+1] == rows[c] + 1
-            } else if (meta.blocked == 2) {
-                // tiled: rows follow the dense index mod hsize (no x ^ h structure to pair loads on)
-#pragma unroll
-                for (int c = 0; c < 8; ++c) cell.load_one(lt, rows[c], c);
-            } else if (pair_loads == 2 && CellRaw<TT>::kHasQuad && pow2 && (p.gx & 3u) != 3u) {
-                // hashed, x mod 4 != 3: both x-neighbours sit in one aligned group of four rows (row = x ^ h: the group
-                // is (x ^ h) & ~3) -- one 16-byte access instead of one 8-byte or two 4-byte ones
-#pragma unroll
-                for (int c = 0; c < 8; c += 2) cell.load_quad(lt, rows[c], rows[c + 1], c);
-            } else if (pair_loads && pow2 && !(p.gx & 1u)) {
-                // hashed, x even: the two x-neighbours are the two halves of one aligned pair
-#pragma unroll
-                for (int c = 0; c < 8; c += 2) {
-                    cell.load_pair(lt, rows[c] & ~1u, c);
-                    if (rows[c] & 1u) cell.swap_pair(c);
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) cell.load_one(lt, rows[c], c);
-            }
-        }
-        if (dedup) cell.take_from_lane(src);
-        float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const uint32_t bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
-            const float wx = bx ? p.fx : 1.0f - p.fx;
-            const float wy = by ? p.fy : 1.0f - p.fy;
-            const float wz = bz ? p.fz : 1.0f - p.fz;
-            const float w = (wx * wy) * wz;
-            const float2 v = cell.get(c);
-            a0 = fmaf(w, v.x, a0);
-            a1 = fmaf(w, v.y, a1);
-        }
-        if (valid) Feat2<TO>::store(feat, (int64_t)l * level_stride + m, a0, a1);
-    }
-  }
-}
-
-// Backward, variant 0: one (sample, level) per thread, 16 global float atomics each.
-template <typename TG>
-__global__ void __launch_bounds__(256)
-k_grid_backward_atomic(const float *__restrict__ xyzs, float bound, const TG *__restrict__ dfeat, GridMeta meta,
-                       int64_t m_host, const int32_t *__restrict__ m_dev, int64_t level_stride,
-                       float *__restrict__ dtable, int variant) {
-    int64_t M = m_host;
-    if (m_dev) { const int64_t md = *m_dev; M = md < M ? md : M; }
-    const TileMap tm = tile_map(variant, meta.num_levels);
-    if (!tm.ok) return;
-    const int l = tm.level;
-    const float scale = meta.scales[l];
-    const uint32_t res = (uint32_t)meta.res[l];
-    const uint32_t off = (uint32_t)meta.offsets[l];
-    const uint32_t hsize = (uint32_t)(meta.offsets[l + 1] - meta.offsets[l]);
-    float *lt = dtable + (int64_t)off * 2;
-    for (int64_t tile = tm.tile0; tile * 256 < M; tile += tm.tstep) {
-        const int64_t m = tile * 256 + threadIdx.x;
-        if (m >= M) continue;
-        const LevelPos p = level_pos(xyzs, m, bound, scale);
-        const float2 gg = Feat2<TG>::load(dfeat + ((int64_t)l * level_stride + m) * 2, 0);
-        uint32_t rows[8];
-        corner_rows(p.gx, p.gy, p.gz, res, hsize, rows, meta.blocked);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const uint32_t bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
-            const uint32_t row = rows[c];
-            const float wx = bx ? p.fx : 1.0f - p.fx;
-            const float wy = by ? p.fy : 1.0f - p.fy;
-            const float wz = bz ? p.fz : 1.0f - p.fz;
-            const float w = (wx * wy) * wz;
-            atomicAdd(lt + (int64_t)row * 2, w * gg.x);
-            atomicAdd(lt + (int64_t)row * 2 + 1, w * gg.y);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Backward, variants 2 / 3: two-pass bucketed scatter -- no global atomics anywhere.
-//
-// Scattered 8-byte float atomics run at the memory side at ~20 G requests/s chip-wide
-// (MI355X_MICROARCH.md "Global float atomics"): 55 M vertex updates per frame cost ~10 ms that
-// way.  Instead every level's table is cut into buckets of BK_ROWS consecutive rows (64 KiB of
-// 64-bit accumulators = one LDS tile):
-//   pass 1 (k_scatter_bin)    a work ITEM is 512 consecutive samples of one level.  One thread per sample computes its
-//                             8 (row, w*g) records (runs of samples in one cell merged first on coarse levels) and the
-//                             workgroup groups them by bucket in an LDS stage.  The stage IS the item's chunk of the
-//                             record region: it is copied out as it stands (16 bytes per lane, perfectly coalesced),
-//                             next to one table entry per (item, bucket) = (first slot, count) of the bucket's SEGMENT
-//                             inside the chunk.  No reservations, no cursors, no head-room, no overflow path: an item
-//                             owns ITEM_RECS = 4096 record slots, exactly what 512 samples can emit.
-//   pass 2 (k_scatter_reduce) one workgroup per (bucket, slice) walks the items' segments of its bucket (the wave's
-//                             lanes take consecutive records of the concatenated segments), accumulates them with
-//                             64-bit fixed-point LDS atomics and finishes its 4096 rows (gradient add, bf16 output, or
-//                             the fused Adam step).
-// Every record has a fixed place that depends on the input only, every sum is an exact integer sum: the
-// result is bitwise reproducible for ANY input (round 2's layout reserved spans with global atomics and fell back to
-// float atomics when a bucket's region overflowed).
-#ifndef LNERF_BK_SHIFT
-#define LNERF_BK_SHIFT 12
-#endif
-constexpr int BK_SHIFT = LNERF_BK_SHIFT, BK_ROWS = 1 << BK_SHIFT;  // 4096 rows * 2 features * 8 B = 64 KiB of accumulators
-// threads (= samples) per binning tile: template parameter BIN_T of k_scatter_bin (256 or 512)
-constexpr int BK_MAX_PER_LEVEL = 256;                   // LDS counters per workgroup tile
-
-// One scatter record.
-//   Rec12 (variant 2): row inside the level + two f32 values: exact.
-//   Rec8  (variant 3): row inside the BUCKET (12 bits; the bucket is implied by the region the record sits in)
-//                      + the two values rounded (nearest-even) to 26-bit floats, sign + 8 exponent + 17 mantissa
-//                      bits: relative rounding 2^-18 per addend instead of 2^-24.  One third less record traffic
-//                      in both passes; meant for the bf16 configuration, whose gradients carry 2^-9 already.
-struct Rec12 {
-    uint32_t row;
-    float v0, v1;
-    static constexpr bool kPacked = false;
-    static __device__ __forceinline__ Rec12 make(uint32_t row, float a, float b) {
-        Rec12 r;
-        r.row = row; r.v0 = a; r.v1 = b;
-        return r;
-    }
-    __device__ __forceinline__ uint32_t row_in_bucket() const { return row & (uint32_t)(BK_ROWS - 1); }
-    __device__ __forceinline__ float a() const { return v0; }
-    __device__ __forceinline__ float b() const { return v1; }
-};
-// (native vector types: what __builtin_nontemporal_load / _store take)
-typedef float nt_f4 __attribute__((ext_vector_type(4)));
-typedef float nt_f2 __attribute__((ext_vector_type(2)));
-typedef uint32_t nt_u2 __attribute__((ext_vector_type(2)));
-typedef uint32_t nt_u4 __attribute__((ext_vector_type(4)));
-// LNERF_BIN_NT (bit mask): non-temporal policy in the binning pass -- 1: dfeat loads (read once per step),
-// 2: record stores (216 MB per frame: more than the Infinity Cache keeps until pass 2 reads them).  Measured together
-// with LNERF_REDUCE_NT below, same box, three interleaved rounds (profiles/r03_exp_scatter.jsonl, steps Q / R):
-// 2411 -> 2548 frames/s; bin 94.1 -> 86.5 us, reduce 124.5 -> 117.3, and the GATHER 78.5 -> 75.1 (its 24 MB table
-// is no longer pushed out of the caches by the scatter's streams between two frames)
-#ifndef LNERF_BIN_NT
-#define LNERF_BIN_NT 3
-#endif
-struct alignas(8) Rec8 {
-    uint32_t lo, hi;  // bits [0,12) row in bucket, [12,38) value 0, [38,64) value 1
-    static constexpr bool kPacked = true;
-    static __device__ __forceinline__ uint32_t f26(float v) {
-        uint32_t u = __float_as_uint(v);
-        if ((u & 0x7F800000u) != 0x7F800000u) u += 0x20u;  // finite: round to nearest, ties away from zero
-        return u >> 6;
-    }
-    static __device__ __forceinline__ Rec8 make(uint32_t row, float a, float b) {
-        const uint32_t qa = f26(a), qb = f26(b);
-        Rec8 r;
-        r.lo = (row & (uint32_t)(BK_ROWS - 1)) | (qa << 12);
-        r.hi = (qa >> 20) | (qb << 6);
-        return r;
-    }
-    __device__ __forceinline__ uint32_t row_in_bucket() const { return lo & (uint32_t)(BK_ROWS - 1); }
-    __device__ __forceinline__ float a() const { return __uint_as_float((((lo >> 12) | (hi << 20)) & 0x3FFFFFFu) << 6); }
-    __device__ __forceinline__ float b() const { return __uint_as_float((hi >> 6) << 6); }
-};
-static_assert(BK_SHIFT <= 12, "Rec8 stores 12 row bits");
-// "This record is needed HERE, by every lane": an empty asm that reads the registers.  A load whose result is only used
-// under a lane predicate is otherwise SUNK into the predicated block by the compiler -- one load, one s_waitcnt
-// vmcnt(0), one use at a time instead of a batch of loads in flight (measured on the reduce pass: 2-3x its time).
-__device__ __forceinline__ void pin_record(Rec8 &r) { asm volatile("" : "+v"(r.lo), "+v"(r.hi)); }
-__device__ __forceinline__ void pin_record(Rec12 &r) { asm volatile("" : "+v"(r.row), "+v"(r.v0), "+v"(r.v1)); }
-
-// Distance between two levels' maxima in uint32 words: one 128-byte line each (device-scope atomics that hit ONE line
-// are served one after the other at the memory side, whatever words they name).
-#ifndef LNERF_CUR_STRIDE
-#define LNERF_CUR_STRIDE 32
-#endif
-constexpr int CUR_STRIDE = LNERF_CUR_STRIDE;
-constexpr int ITEM_SAMPLES = 512;                 // samples per work item of pass 1 (= threads per workgroup)
-constexpr int ITEM_RECS = ITEM_SAMPLES * 8;       // record slots of an item's chunk
-// workspace header (bytes): [0, HDR_GMAX) level maxima (cleared before pass 1), then the item count of the last pass 1,
-// then one record count per bucket (written by pass 2 for the finishing pass)
-constexpr size_t HDR_GMAX_BYTES = (size_t)LNERF_MAX_LEVELS * CUR_STRIDE * sizeof(uint32_t);
-constexpr size_t HDR_ITEMS_OFF = HDR_GMAX_BYTES;            // int32 [1] (+ padding to 128 bytes)
-constexpr size_t HDR_ARRIVE_OFF = HDR_GMAX_BYTES + 128;     // int32 [9 x CUR_STRIDE]: arrival counters of the step's tail
-                                                            // launch (root + 8 shards, a line each; zero between launches)
-// slice arrival counters of pass 2, one per bucket, at a FIXED place whatever the level table (a process re-uses one
-// workspace for every encoder: a region whose position depended on the bucket count would overlap another layout's
-// record counts); zero in a fresh workspace (LNERF_SCATTER_ZERO_HEAD_BYTES), left zero by every call
-constexpr size_t HDR_SLICE_ARRIVE_OFF = HDR_ARRIVE_OFF + 9 * CUR_STRIDE * sizeof(int32_t);
-constexpr size_t HDR_BUCKETN_OFF = HDR_SLICE_ARRIVE_OFF + (size_t)LNERF_MAX_LEVELS * 256 * sizeof(int32_t);    // int32 [buckets]
-
-struct BucketMeta {
-    int nb[LNERF_MAX_LEVELS];            // buckets per level
-    int bstart[LNERF_MAX_LEVELS + 1];    // first global bucket id of the level
-    int slices[LNERF_MAX_LEVELS];        // pass-2 workgroups per bucket (worst case; the active count is decided on the device)
-    int compact[LNERF_MAX_LEVELS];       // 1: merge runs of equal rows inside a wavefront before binning
-    int wgstart[LNERF_MAX_LEVELS + 1];   // first pass-2 workgroup of the level
-    int pstart[LNERF_MAX_LEVELS];        // sliced levels: first partial-sum tile of the level (pass 2 -> finish)
-    int fstart[LNERF_MAX_LEVELS];        // sliced levels: first bucket index in the finishing pass's grid
-    int n_items;                         // item capacity: ceil(m_host / ITEM_SAMPLES)
-    int fix_bits;                        // exact 12-byte records: bits of the fixed-point addends (<= 44), chosen so that
-                                         // m_host addends of the level's bound cannot overflow an int64 (see fix_scale)
-    // chunk of (level l, item t): record slot ((int64)l * n_items + t) * ITEM_RECS;
-    // segment table entry of (l, t, bucket b): ((int64)bstart[l] * n_items + (int64)t * nb[l] + b)
-};
-
-// sum of v over this lane's run, valid on the run's tail lane: difference of wave prefix sums
-__device__ __forceinline__ float run_sum(float v, const RunInfo &r) {
-    const float P = wave_inclusive_sum(v);
-    const float Pm = __int_as_float(__builtin_amdgcn_ds_bpermute((r.start - 1) << 2, __float_as_int(P)));
-    return r.start > 0 ? P - Pm : P;
-}
-
-// Phase stamps of the binning pass (diagnostic builds only: -DLNERF_STAMPS, tools/run_bin_stamps.sh).  Wave 0 of
-// every workgroup drains its memory counters, reads the shader clock and adds the time since the previous stamp
-// to a global per-phase total.
-#ifdef LNERF_STAMPS
-__device__ unsigned long long g_bin_stamps[16];
-#define BIN_STAMP(k)                                                                              \
-    do {                                                                                          \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                               \
-        const unsigned long long now__ = __builtin_amdgcn_s_memtime();                            \
-        stamp_acc__[k] += now__ - stamp_prev__;                                                   \
-        stamp_prev__ = now__;                                                                     \
-    } while (0)
-#define BIN_STAMP_INIT()                                                                          \
-    unsigned long long stamp_acc__[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                            \
-    unsigned long long stamp_prev__ = __builtin_amdgcn_s_memtime()
-#define BIN_STAMP_FLUSH()                                                                         \
-    do {                                                                                          \
-        if (threadIdx.x == 0)                                                                     \
-            for (int k__ = 0; k__ < 10; ++k__) atomicAdd(&g_bin_stamps[k__], stamp_acc__[k__]);   \
-    } while (0)
-// per-workgroup log of pass 2: (entry, exit) on the constant 100 MHz clock + where it ran: 4 words per workgroup
-__device__ unsigned long long g_wg_log[4 * 4096];
-#define RED_STAMP(k) BIN_STAMP(k)
-#define RED_STAMP_INIT()                                                                          \
-    unsigned long long stamp_acc__[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};        \
-    unsigned long long stamp_prev__ = __builtin_amdgcn_s_memtime()
-#define RED_STAMP_FLUSH()                                                                         \
-    do {                                                                                          \
-        if (threadIdx.x == 0) {                                                                   \
-            for (int k__ = 10; k__ < 14; ++k__) atomicAdd(&g_bin_stamps[k__], stamp_acc__[k__]);  \
-            atomicAdd(&g_bin_stamps[15], 1ull);                                                   \
-        }                                                                                         \
-    } while (0)
-#else
-#define RED_STAMP(k) do { } while (0)
-#define RED_STAMP_INIT() do { } while (0)
-#define RED_STAMP_FLUSH() do { } while (0)
-#define BIN_STAMP(k) do { } while (0)
-#define BIN_STAMP_INIT() do { } while (0)
-#define BIN_STAMP_FLUSH() do { } while (0)
-#endif
-
-// ---- pass 1: k_scatter_bin ---------------------------------------------------------------------------------------
-// A work item is BIN_T = 512 consecutive samples of ONE level; PERSISTENT workgroups (3 per CU) stride over the
-// tile-major (tile, level) list, the level rotated by one per round, and fetch the next item's inputs while the current
-// one is processed.  Per item: cell, rows, runs -> every record ranked inside its bucket with a returning LDS counter
-// -> (the values w * g, run sums on coarse levels, are computed behind those atomics) -> barrier -> count scan (every
-// wave computes it: no idle waves, no extra barrier) -> records written to their slot of the LDS stage -> barrier ->
-// the stage copied out as the item's chunk, 16 bytes per lane, and the (first slot, count) of every bucket's segment
-// written to the segment table.  Nothing in the item waits for a global round trip: the only global accesses are the
-// prefetch of the next item's inputs and the two coalesced stores at the end.
-// The level's largest |value| (fixed-point scale of pass 2) is bounded from |g| (weights <= 1, runs <= 64 samples),
-// one LDS maximum per level and workgroup; records are packed with bit-field inserts; run sums use fused DPP adds.
-constexpr int BIN_T = ITEM_SAMPLES;        // threads per workgroup = samples per item
-
-// fast f32 -> 26-bit float (round to nearest, ties away from zero: one add on the sign-magnitude bits; symmetric in
-// the sign, and a tie is one value in 64), valid for finite values
-__device__ __forceinline__ uint32_t f26_round(float v) {
-    return __float_as_uint(v) + 0x20u;  // (low 6 bits are dropped by the packing)
-}
-template <typename REC, bool CAREFUL> struct PackRec;
-template <bool CAREFUL> struct PackRec<Rec12, CAREFUL> {
-    static __device__ __forceinline__ Rec12 make(uint32_t row, float a, float b) { return Rec12::make(row, a, b); }
-};
-template <> struct PackRec<Rec8, true> {   // non-finite values present in the wavefront: the reference packing
-    static __device__ __forceinline__ Rec8 make(uint32_t row, float a, float b) { return Rec8::make(row, a, b); }
-};
-template <> struct PackRec<Rec8, false> {  // bits [0,12) row, [12,38) value 0, [38,64) value 1 -- same layout, fewer ops
-    static __device__ __forceinline__ Rec8 make(uint32_t row, float a, float b) {
-        const uint32_t ua = f26_round(a), ub = f26_round(b);
-        Rec8 r;
-        r.lo = ((ua << 6) & 0xFFFFF000u) | (row & 0xFFFu);
-        r.hi = (ua >> 26) | (ub & 0xFFFFFFC0u);
-        return r;
-    }
-};
-
-// maximum over the wave of unsigned values, returned in every lane: one fused DPP max per step (a dependent chain:
-// every DPP read needs the two wait states after the VALU write, which the compiler cannot see inside inline asm)
-__device__ __forceinline__ unsigned int wave_max_u32(unsigned int v) {
-    asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                 "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                 "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                 "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                 "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-                 "s_nop 1"
-                 : "+v"(v));
-    return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
-}
-
-// Sums over RUNS of lanes (RunInfo), valid on every lane as the sum from the run's first lane up to the lane itself:
-// a segmented Hillis-Steele scan, one fused DPP multiply-add per value and step -- the addend of a lane whose source
-// lies before its run's first lane is multiplied by 0.  Unlike "wave prefix sum minus the prefix before the run" it
-// needs no lane permutes, no subtraction (and has none of its cancellation), and a wave whose longest run is short
-// skips the long-distance steps: all conditions are wave-uniform scalar tests on the run-head mask.
-__device__ __forceinline__ void wave_run_sums_x16(float (&a)[8], float (&b)[8], const RunInfo &r, int lane) {
-    const int d = lane - r.start;  // lanes of the run before this one
-    const unsigned long long H = r.heads;
-    const unsigned long long H2 = H | (H << 1), H4 = H2 | (H2 << 2), H8 = H4 | (H4 << 4);
-#define LNERF_SEG_STEP(ctrl, cond)                                                                                  \
-    {                                                                                                               \
-        const float f = (cond) ? 1.0f : 0.0f;                                                                       \
-        asm volatile("s_nop 1" ::: );                                                                               \
-        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                             \
-            asm volatile("v_fmac_f32_dpp %0, %0, %1 " ctrl : "+v"(a[i]) : "v"(f));                                  \
-            asm volatile("v_fmac_f32_dpp %0, %0, %1 " ctrl : "+v"(b[i]) : "v"(f));                                  \
-        }                                                                                                           \
-        asm volatile("s_nop 1" ::: );                                                                               \
-    }
-    if (H != ~0ull) LNERF_SEG_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0", d >= 1)
-    if (H2 != ~0ull) LNERF_SEG_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0", d >= 2)
-    if (H4 != ~0ull) LNERF_SEG_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0", d >= 4)
-    if (H8 != ~0ull) LNERF_SEG_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0", d >= 8)
-    // runs that continue over a row of 16 lanes: the previous row's last lane holds the run's sum so far
-    if ((H & 0x0001000000010000ull) != 0x0001000000010000ull)
-        LNERF_SEG_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf", d > (lane & 15))
-    if (!((H >> 32) & 1ull)) LNERF_SEG_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf", r.start < 32)
-#undef LNERF_SEG_STEP
-}
-
-// what the binning pass needs to know about a level (read from the kernel arguments in the kernel body only: the
-// lambdas below take it by value, so the argument structs are never copied to scratch)
-struct BinLevel {
-    float scale;
-    uint32_t res, hsize;
-    int level, nb, b0;
-    bool compact;
-};
-#define LNERF_BIN_LEVEL(lv)                                                                                          \
-    BinLevel {                                                                                                       \
-        meta.scales[lv], (uint32_t)meta.res[lv], (uint32_t)(meta.offsets[(lv) + 1] - meta.offsets[lv]), (lv),        \
-            bm.nb[lv], bm.bstart[lv], bm.compact[lv] != 0                                                            \
-    }
-
-template <typename REC>
-__global__ void __launch_bounds__(BIN_T, (sizeof(REC) == 8 ? 6 : 4))
-k_scatter_bin(const float *__restrict__ xyzs, float bound, const float *__restrict__ dfeat, GridMeta meta, BucketMeta bm,
-              int64_t m_host, const int32_t *__restrict__ m_dev, int64_t level_stride, unsigned int *__restrict__ gmax,
-              int32_t *__restrict__ items_out, uint32_t *__restrict__ segtab, REC *__restrict__ recs, int skip_zero,
-              int lv_lo, int lv_hi) {
-    __shared__ int s_cnt[2][BK_MAX_PER_LEVEL];  // records of the item per bucket (two sets: items alternate)
-    __shared__ int s_off[BK_MAX_PER_LEVEL];     // first slot of the bucket's segment in the stage (= in the chunk)
-    __shared__ __attribute__((aligned(16))) REC s_stage[ITEM_RECS];  // the item's chunk (48 KiB, 32 KiB packed)
-    __shared__ unsigned int s_lmax[LNERF_MAX_LEVELS];         // per level: bound of |value| seen by this workgroup
-    int32_t M = (int32_t)m_host;
-    if (m_dev) { const int32_t md = *m_dev; M = md < M ? md : M; }
-    const int L = lv_hi - lv_lo;   // levels of this launch: [lv_lo, lv_hi)
-    const int tid = threadIdx.x, lane = tid & 63;
-    // item k of this workgroup: tile t0 + k * tstep, level lv_lo + (l0 + k) mod L   (gridDim.x is a multiple of L)
-    const int tstep = gridDim.x / L;
-    const float two_b = 2.0f * bound;
-    const bool pow2_bound = (__float_as_uint(two_b) & 0x007FFFFFu) == 0u;
-    // (exact when the bound is a power of two, the only case it is used in; wave-uniform, kept in a scalar register)
-    float inv_two_b;
-    asm("v_readfirstlane_b32 %0, %1" : "=s"(inv_two_b) : "v"(1.0f / two_b));
-    for (int i = tid; i < 2 * BK_MAX_PER_LEVEL; i += BIN_T) (&s_cnt[0][0])[i] = 0;
-    if (tid < LNERF_MAX_LEVELS) s_lmax[tid] = 0u;
-    if (blockIdx.x == 0 && tid == 0) *items_out = (M + BIN_T - 1) / BIN_T;  // pass 2 walks exactly these items
-    // ---- inputs of an item (5 dwords per lane), fetched while the previous item is processed
-    float n_x = 0.f, n_y = 0.f, n_z = 0.f;
-    float2 n_g = make_float2(0.f, 0.f);
-    auto fetch = [&](int lv, int tl) __attribute__((always_inline)) {
-        const int mm = tl * BIN_T + tid;
-        n_x = n_y = n_z = 0.f;
-        n_g = make_float2(0.f, 0.f);
-        if (mm < M) {
-            const float2 *gp = reinterpret_cast<const float2 *>(dfeat) + ((int64_t)lv * level_stride + mm);
-            if (LNERF_BIN_NT & 1) {   // (read once per step: keep it out of the caches the table and the records use)
-                const nt_f2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f2 *>(gp));
-                n_g = make_float2(v.x, v.y);
-            } else {
-                n_g = *gp;
-            }
-            n_x = xyzs[(int64_t)mm * 3]; n_y = xyzs[(int64_t)mm * 3 + 1]; n_z = xyzs[(int64_t)mm * 3 + 2];
-        }
-    };
-    int l = lv_lo + (int)(blockIdx.x % L);
-    int tile = (int)(blockIdx.x / L);
-    bool have = tile * BIN_T < M;
-    if (have) fetch(l, tile);
-    BIN_STAMP_INIT();
-    __syncthreads();
-    int hk = 0;  // items so far (selects the counter set)
-    while (have) {
-        const BinLevel lv = LNERF_BIN_LEVEL(l);
-        const int nb = lv.nb;
-        const int l_next = l + 1 == lv_hi ? lv_lo : l + 1;
-        const int tile_next = tile + tstep;
-        const bool have_next = tile_next * BIN_T < M;
-        BIN_STAMP(0);
-        // ---- A: cell, rows, runs, and WHICH lanes append records.  Samples behind a ray's termination point
-        // (T < T_thresh) get dsigma = drgb = 0 from the compositing backward, hence dfeat = 0 exactly: a run (or
-        // sample) whose gradients are all zero appends nothing, and a wavefront of 64 such samples skips its
-        // arithmetic altogether.
-        const int m = tile * BIN_T + tid;
-        const bool valid = m < M;
-        const float2 gg = n_g;
-        const bool nzg = valid && (gg.x != 0.f || gg.y != 0.f);
-        const unsigned long long nzmask = __ballot(nzg);
-        const bool wave_live = !skip_zero || nzmask != 0ull;
-        LevelPos p;
-        RunInfo ri;
-        ri.start = lane; ri.tail = true; ri.heads = ~0ull;
-        uint32_t row[8];
-        bool emit = false;
-        if (wave_live) {
-            {   // (lanes past the end hold zeros from the fetch: same arithmetic, nothing emitted)
-                float px = n_x + bound, py = n_y + bound, pz = n_z + bound;
-                if (pow2_bound) { px *= inv_two_b; py *= inv_two_b; pz *= inv_two_b; }   // == the division, exactly
-                else { px /= two_b; py /= two_b; pz /= two_b; }
-                px = px * lv.scale; py = py * lv.scale; pz = pz * lv.scale;
-                px = px + 0.5f; py = py + 0.5f; pz = pz + 0.5f;
-                const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
-                p.gx = (uint32_t)(int)flx; p.gy = (uint32_t)(int)fly; p.gz = (uint32_t)(int)flz;
-                p.fx = px - flx; p.fy = py - fly; p.fz = pz - flz;
-            }
-            corner_rows(p.gx, p.gy, p.gz, lv.res, lv.hsize, row, meta.blocked);
-            if (lv.compact) {  // wave-uniform: coarse level, merge runs of samples in the same cell first
-                // (the lane number is made opaque per item: the 64-bit lane masks derived from it are cheaper to
-                // recompute than to keep -- hoisted out of the item loop they were spilled to scratch)
-                int lane_v = lane;
-                asm volatile("" : "+v"(lane_v));
-                ri = wave_cell_runs(p.gx, p.gy, p.gz, valid, lane_v);
-                const unsigned long long seg = (nzmask >> ri.start) & ((2ull << (lane_v - ri.start)) - 1ull);
-                emit = valid && ri.tail && (!skip_zero || seg != 0ull);
-            } else {
-                emit = valid && (!skip_zero || nzg);
-            }
-        } else {  // nothing is emitted: rows and position are never looked at (defined without an instruction)
-#pragma unroll
-            for (int c = 0; c < 8; ++c) asm("" : "=v"(row[c]));
-            asm("" : "=v"(p.gx), "=v"(p.gy), "=v"(p.gz), "=v"(p.fx), "=v"(p.fy), "=v"(p.fz));
-        }
-        // ---- D (a lambda: placed behind the ranking atomics): the values w * g (run sums on coarse levels), packed
-        // into records; the bound of |value| goes to the level's LDS maximum
-        REC rec[8];
-        auto values = [&]() __attribute__((always_inline)) {
-            if (!wave_live) return;
-            float v0[8], v1[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float wx = (c & 1) ? p.fx : 1.0f - p.fx;
-                const float wy = (c & 2) ? p.fy : 1.0f - p.fy;
-                const float wz = (c & 4) ? p.fz : 1.0f - p.fz;
-                const float w = (wx * wy) * wz;
-                v0[c] = w * gg.x;
-                v1[c] = w * gg.y;
-            }
-            float mx = fmaxf(fabsf(gg.x), fabsf(gg.y));  // weights are <= 1 ...
-            const bool odd = ((__float_as_uint(gg.x) & 0x7F800000u) == 0x7F800000u) ||
-                             ((__float_as_uint(gg.y) & 0x7F800000u) == 0x7F800000u);  // NaN / inf in the gradient
-            if (lv.compact) {
-                wave_run_sums_x16(v0, v1, ri, lane);          // the run's tail lane holds the run sum
-                mx *= 64.0f;                             // ... and a run sums at most 64 samples
-            }
-            const bool any_odd = __ballot(odd) != 0ull;
-            // (a per-lane LDS maximum, filtered by the current bound, measured 32 us SLOWER than this wave reduction)
-            const unsigned int mb = wave_max_u32(__float_as_uint(any_odd ? 3.0e38f : mx));  // (bits of floats >= 0 order as uints)
-            if (lane == 0 && mb != 0u) atomicMax(&s_lmax[lv.level], mb);
-            if (!any_odd) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) rec[c] = PackRec<REC, false>::make(row[c] & ((1u << 20) - 1u), v0[c], v1[c]);
-            } else {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) rec[c] = PackRec<REC, true>::make(row[c] & ((1u << 20) - 1u), v0[c], v1[c]);
-            }
-        };
-        // ranks the wavefront's records of corner c in `counters` (LDS): where the lanes of a wave mostly target one or
-        // two buckets (tiny tables) one LDS atomic per (wave, bucket) instead of one per lane -- same-address LDS
-        // atomics serialise
-        auto rank_by_ballot = [&](int *counters, int c) __attribute__((always_inline)) {
-            const int b = (int)(row[c] >> BK_SHIFT);
-            int rk = 0;
-            unsigned long long todo = __ballot(emit);
-            while (todo) {
-                const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
-                const int bl = __builtin_amdgcn_readlane(b, leader);
-                const unsigned long long mm = __ballot(emit && b == bl);
-                int base = 0;
-                if (lane == leader) base = atomicAdd(&counters[bl], __popcll(mm));
-                base = __builtin_amdgcn_readlane(base, leader);
-                if (emit && b == bl) rk = base + mbcnt(mm);
-                todo &= ~mm;
-            }
-            row[c] |= (uint32_t)rk << 20;
-        };
-        BIN_STAMP(1);
-        const int cur = hk & 1;
-        ++hk;
-        // ---- B: the rank of a record inside its bucket, among the item's records (< 4096), is kept in bits [20, 32) of
-        // its row (rows of a level are < 2^20: at most 256 buckets of 4096 rows)
-        constexpr uint32_t ROW_MASK = (1u << 20) - 1u;
-        if (nb <= 32 && !lv.compact) {  // wave-uniform: every lane emits into one or two buckets
-#pragma unroll
-            for (int c = 0; c < 8; ++c) rank_by_ballot(s_cnt[cur], c);
-        } else if (emit) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) row[c] |= (uint32_t)atomicAdd(&s_cnt[cur][row[c] >> BK_SHIFT], 1) << 20;
-        }
-        BIN_STAMP(2);
-        // the next item's inputs go into the memory queue now; they are consumed at the top of the next iteration
-        if (have_next) fetch(l_next, tile_next);
-        values();
-        BIN_STAMP(4);
-        __syncthreads();  // barrier 1: the item's bucket counts are final
-        BIN_STAMP(3);
-        // (the other set was last read behind barrier 2 of the previous item: clear it for the next one)
-        for (int i = tid; i < BK_MAX_PER_LEVEL; i += BIN_T) s_cnt[cur ^ 1][i] = 0;
-        // ---- E: exclusive scan of the bucket counts.  EVERY wave computes it (4 buckets per lane, one DPP scan) and
-        // writes the same offsets: a wave reads s_off only after its own writes, so no barrier and no idle waves
-        int total;
-        {
-            int c4[4], sum = 0;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int i = lane * 4 + kk;
-                c4[kk] = i < nb ? s_cnt[cur][i] : 0;
-                sum += c4[kk];
-            }
-            const int inc = wave_inclusive_sum_i(sum);
-            int run = inc - sum;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int i = lane * 4 + kk;
-                if (i < nb) s_off[i] = run;
-                run += c4[kk];
-            }
-            total = __builtin_amdgcn_readlane(inc, 63);
-        }
-        // ---- F: the records into their slot of the stage = of the chunk
-        if (emit) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int b = (int)((row[c] & ROW_MASK) >> BK_SHIFT);
-                s_stage[s_off[b] + (int)(row[c] >> 20)] = rec[c];
-            }
-        }
-        BIN_STAMP(5);
-        __syncthreads();  // barrier 2: the stage is complete
-        BIN_STAMP(7);
-        // the prefetched inputs are pinned in registers here, so that the next item starts without waiting for the
-        // stores below to be acknowledged (one in-order memory counter covers loads and stores)
-        asm volatile("" : "+v"(n_g.x), "+v"(n_g.y), "+v"(n_x), "+v"(n_y), "+v"(n_z));
-        // ---- G: the chunk, 16 bytes per lane (a chunk starts on a multiple of 16 bytes; the last unit may carry one
-        // stale record behind the item's last one: never read), and the segment table entries of the item
-        {
-            uint4 *dst = reinterpret_cast<uint4 *>(recs + ((int64_t)lv.level * bm.n_items + tile) * ITEM_RECS);
-            const uint4 *srcq = reinterpret_cast<const uint4 *>(s_stage);
-            const int n16 = (total * (int)sizeof(REC) + 15) >> 4;
-            for (int i = tid; i < n16; i += BIN_T) {
-                if (LNERF_BIN_NT & 2) {
-                    const uint4 q = srcq[i];
-                    nt_u4 v = {q.x, q.y, q.z, q.w};
-                    __builtin_nontemporal_store(v, reinterpret_cast<nt_u4 *>(dst + i));
-                } else {
-                    dst[i] = srcq[i];
-                }
-            }
-            if (tid < nb)
-                segtab[(int64_t)lv.b0 * bm.n_items + (int64_t)tile * nb + tid] =
-                    (uint32_t)s_off[tid] | ((uint32_t)s_cnt[cur][tid] << 16);
-        }
-        BIN_STAMP(8);
-        // (the next item rewrites s_off / s_stage only behind ITS barrier 1, which every wave reaches after finishing
-        // the copy above; it clears this item's counter set behind that barrier too)
-        l = l_next; tile = tile_next; have = have_next;
-    }
-    __syncthreads();
-    if (tid >= lv_lo && tid < lv_hi && s_lmax[tid] != 0u) atomicMax(&gmax[tid * CUR_STRIDE], s_lmax[tid]);  // one value per LEVEL and workgroup
-    BIN_STAMP_FLUSH();
-}
-#undef LNERF_BIN_LEVEL
 
 // Pass 2.  LDS float atomics run at ~0.5 lane/clk on gfx950 while integer LDS atomics run at the
 // plain-store rate (measured: profiles/README.md, "reduce_dbg"), so the tile accumulates in 64-bit
@@ -1586,23 +690,27 @@ k_step_tail(unsigned int *__restrict__ gmax, AdamArgs a, SlabAdam sa, int32_t *_
 extern int g_mlp_fwd_blocks, g_mlp_fwd_wps, g_mlp_bwd_blocks, g_mlp_bwd_variant;  // mlp.hip
 
 // levels up to this resolution merge per-wave runs before binning (tunable: lnerf_set_tuning)
-static int g_compact_max_res = 512;
+int g_compact_max_res = 512;
 // gather: fetch x-adjacent vertices with one load where they are adjacent rows (2: also aligned groups of four rows)
-static int g_gather_pairs = 2;
+int g_gather_pairs = 2;
 // gather variant 2: workgroups per XCD (each strides over the tiles of its XCD's levels)
-static int g_gather_wgs_per_xcd = 256;
+int g_gather_wgs_per_xcd = 256;
 // gather: levels with resolution <= this fetch a cell's vertices once per run of lanes in that cell (0 = off)
-static int g_gather_dedup_res = 512;
+int g_gather_dedup_res = 512;
+// gather: bytes of (unused) dynamic LDS per workgroup -- an EXPERIMENT knob that caps the resident wavefronts (160 KiB per CU:
+// 53 KiB leaves three 256-thread workgroups = three waves per SIMD): "what would the gather cost at the occupancy of a
+// kernel fused with the MLP forward?" 
+int g_gather_lds_pad = 0;
 // persistent workgroups of the binning pass per CU (3 fit its 44 KiB of LDS with the 8-byte records)
-static int g_bin_per_cu = 3;
+int g_bin_per_cu = 3;
 // persistent workgroups of the binning pass (0 = 256 CUs x g_bin_per_cu); rounded down to a multiple of the level count
-static int g_bin_wgs = 0;
+int g_bin_wgs = 0;
 // drop contributions that are exactly zero (samples behind a ray's termination point)
-static int g_skip_zero = 1;
+int g_skip_zero = 1;
 // threads per workgroup of the reduce pass (512 or 1024; two 64 KiB workgroups fit a CU either way)
-static int g_reduce_threads = 1024;
+int g_reduce_threads = 1024;
 // level groups of the whole-frame scatter: bin(group) -> reduce(group) per group (1 = bin everything, then reduce)
-static int g_scatter_groups = 1;
+int g_scatter_groups = 1;
 
 // workspace: [header: level maxima | item count | record count per bucket] [segment table] [record chunks] [partial tiles]
 static_assert(BK_MAX_PER_LEVEL == 256 && HDR_BUCKETN_OFF <= LNERF_SCATTER_ZERO_HEAD_BYTES,
@@ -1668,105 +776,11 @@ static int fill_bucket_meta(const GridMeta &meta, int64_t m_host, BucketMeta &bm
     return 0;
 }
 
-static int fill_meta(const char *who, GridMeta &meta, int num_levels, int level_dim, const int32_t *offsets_host,
-                     const float *scales_host, const int32_t *res_host, int layout_flags = 0) {
-    LNERF_REQUIRE(num_levels >= 1 && num_levels <= LNERF_MAX_LEVELS, "%s: num_levels out of range (%d)", who,
-                  num_levels);
-    LNERF_REQUIRE(level_dim == 2, "%s: only level_dim == 2 is built (got %d)", who, level_dim);
-    LNERF_REQUIRE(offsets_host && scales_host && res_host, "%s: null level metadata", who);
-    meta.num_levels = num_levels;
-    LNERF_REQUIRE((layout_flags & (LNERF_GRID_BLOCKED | LNERF_GRID_TILED)) != (LNERF_GRID_BLOCKED | LNERF_GRID_TILED),
-                  "%s: LNERF_GRID_BLOCKED and LNERF_GRID_TILED exclude each other", who);
-    const int blocked = (layout_flags & LNERF_GRID_BLOCKED) ? 1 : 0;
-    meta.blocked = blocked ? 1 : ((layout_flags & LNERF_GRID_TILED) ? 2 : 0);   // layout of the levels beyond their table: 0 hash, 1 blocked, 2 tiled
-    for (int l = 0; l <= num_levels; ++l) meta.offsets[l] = offsets_host[l];
-    for (int l = 0; l < num_levels; ++l) {
-        LNERF_REQUIRE(offsets_host[l + 1] > offsets_host[l], "%s: empty level %d", who, l);
-        LNERF_REQUIRE(!blocked || offsets_host[l + 1] - offsets_host[l] >= 16, "%s: blocked layout needs >= 16 rows per level", who);
-        LNERF_REQUIRE(res_host[l] >= 1 && res_host[l] <= 1 << 20, "%s: bad resolution at level %d", who, l);
-        meta.scales[l] = scales_host[l];
-        meta.res[l] = res_host[l];
-    }
-    return LNERF_OK;
-}
-
-static void launch_dims(int variant, int L, int64_t m_host, dim3 &grid) {
-    const int64_t tiles = div_up(m_host, 256);
-    if (variant == 0) {
-        int64_t gx = tiles < 1 ? 1 : tiles;
-        if (gx > 2048) gx = 2048;
-        grid = dim3((unsigned)gx, (unsigned)L, 1);
-    } else {
-        const int lv_per_xcd = (L + 7) / 8;
-        int64_t per_level = tiles < 1 ? 1 : tiles;
-        if (per_level > 256) per_level = 256;  // workgroups per level
-        grid = dim3((unsigned)(8 * lv_per_xcd * per_level), 1, 1);
-    }
-}
-
 }  // namespace lnerf
 
 using namespace lnerf;
 
 extern "C" {
-
-int lnerf_grid_encode_forward(const float *xyzs, float bound, const void *table, int table_dtype, int num_levels,
-                              int level_dim, const int32_t *offsets_host, const float *scales_host,
-                              const int32_t *res_host, int64_t m_host, const int32_t *m_dev, int64_t level_stride,
-                              void *feat, int feat_dtype, int variant, lnerf_stream_t stream) {
-    GridMeta meta;
-    const int blocked = variant & (LNERF_GRID_BLOCKED | LNERF_GRID_TILED);
-    variant &= ~(LNERF_GRID_BLOCKED | LNERF_GRID_TILED);
-    int rc = fill_meta("grid_encode_forward", meta, num_levels, level_dim, offsets_host, scales_host, res_host, blocked);
-    if (rc) return rc;
-    LNERF_REQUIRE(m_host >= 0 && level_stride >= m_host, "grid_encode_forward: need 0 <= m_host <= level_stride");
-    LNERF_REQUIRE(bound > 0.f, "grid_encode_forward: bound must be > 0");
-    LNERF_REQUIRE(variant >= 0 && variant <= 2, "grid_encode_forward: unknown variant %d", variant);
-#ifndef LNERF_EXPERIMENTS   // (XCD-pinned levels / XCD-owned level sets: measured no faster; experiment builds only)
-    LNERF_REQUIRE(variant == 0, "grid_encode_forward: variant %d is an experiment variant (build with -DLNERF_EXPERIMENTS)", variant);
-#endif
-    LNERF_REQUIRE((table_dtype == LNERF_F32 || table_dtype == LNERF_BF16) &&
-                      (feat_dtype == LNERF_F32 || feat_dtype == LNERF_BF16),
-                  "grid_encode_forward: bad dtype tag");
-    if (m_host == 0) return LNERF_OK;
-    LNERF_REQUIRE(xyzs && table && feat, "grid_encode_forward: null pointer");
-    dim3 grid;
-    launch_dims(variant == 2 ? 0 : variant, num_levels, m_host, grid);
-    XcdPlan plan;
-    memset(&plan, 0, sizeof(plan));
-    if (variant == 2) {
-        // longest-processing-time assignment of levels to XCDs; cost ~ cache lines a sample touches on the level
-        double cost[LNERF_MAX_LEVELS], load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        int order[LNERF_MAX_LEVELS];
-        for (int l = 0; l < num_levels; ++l) {
-            const double r = (double)res_host[l];
-            cost[l] = res_host[l] > g_gather_dedup_res ? 1.0 : (r < 64 ? 0.05 : r / (double)(g_gather_dedup_res > 0 ? g_gather_dedup_res : 512) * 0.9);
-            order[l] = l;
-        }
-        for (int a = 0; a < num_levels; ++a)
-            for (int b = a + 1; b < num_levels; ++b)
-                if (cost[order[b]] > cost[order[a]]) { const int t = order[a]; order[a] = order[b]; order[b] = t; }
-        for (int a = 0; a < num_levels; ++a) {
-            int best = -1;
-            for (int x = 0; x < 8; ++x)
-                if (plan.n[x] < LNERF_MAX_LEVELS / 8 + 2 && (best < 0 || load[x] < load[best])) best = x;
-            plan.lv[best][plan.n[best]++] = order[a];
-            load[best] += cost[order[a]];
-        }
-        grid = dim3((unsigned)(8 * g_gather_wgs_per_xcd), 1, 1);
-    }
-    hipStream_t s = as_stream(stream);
-#define LAUNCH_FWD(TT, TO)                                                                                         \
-    hipLaunchKernelGGL((k_grid_forward<TT, TO>), grid, dim3(256), 0, s, xyzs, bound, (const TT *)table, meta, m_host, \
-                       m_dev, level_stride, (TO *)feat, variant, g_gather_pairs, g_gather_dedup_res, plan)
-    if (table_dtype == LNERF_F32 && feat_dtype == LNERF_F32) LAUNCH_FWD(float, float);
-    else if (table_dtype == LNERF_F32) LAUNCH_FWD(float, uint16_t);
-    else if (feat_dtype == LNERF_F32) LAUNCH_FWD(uint16_t, float);
-    else LAUNCH_FWD(uint16_t, uint16_t);
-#undef LAUNCH_FWD
-    LNERF_CHECK_LAUNCH("grid_encode_forward");
-    return LNERF_OK;
-}
 
 int lnerf_set_tuning(const char *key, int value) {
     LNERF_REQUIRE(key, "set_tuning: null key");
@@ -1793,6 +807,11 @@ int lnerf_set_tuning(const char *key, int value) {
     if (strcmp(key, "gather_wgs_per_xcd") == 0) {
         LNERF_REQUIRE(value >= 1 && value <= 4096, "set_tuning: gather_wgs_per_xcd out of range");
         g_gather_wgs_per_xcd = value;
+        return LNERF_OK;
+    }
+    if (strcmp(key, "gather_lds_pad") == 0) {
+        LNERF_REQUIRE(value >= 0 && value <= 65536, "set_tuning: gather_lds_pad must be in [0, 65536] bytes");
+        g_gather_lds_pad = value;
         return LNERF_OK;
     }
     if (strcmp(key, "gather_pair_loads") == 0) {
@@ -1853,10 +872,13 @@ int lnerf_debug_wg_log(unsigned long long *out, int words) {   // reads AND clea
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_wg_log), zero, sizeof(zero)) != hipSuccess) return LNERF_ERR_HIP;
     return LNERF_OK;
 }
-int lnerf_debug_bin_stamps(unsigned long long *out16) {
-    unsigned long long z[16] = {0};
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_bin_stamps), sizeof(z)) != hipSuccess) return LNERF_ERR_HIP;
+int lnerf_debug_bin_stamps(unsigned long long *out16) {   // pass 1's totals (grid_bin.hip) + pass 2's (this file); clears both
+    unsigned long long z[16] = {0}, mine[16];
+    if (hipMemcpyFromSymbol(mine, HIP_SYMBOL(g_bin_stamps), sizeof(z)) != hipSuccess) return LNERF_ERR_HIP;
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_bin_stamps), z, sizeof(z)) != hipSuccess) return LNERF_ERR_HIP;
+    const int rc = bin_stamps_read(out16);
+    if (rc != LNERF_OK) return rc;
+    for (int k = 0; k < 16; ++k) out16[k] += mine[k];
     return LNERF_OK;
 }
 #endif
@@ -1918,11 +940,8 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
     LNERF_REQUIRE(lv_lo >= 0 && lv_lo <= lv_hi && lv_hi <= num_levels, "grid_encode_backward: bad level range");
     LNERF_REQUIRE(phases == 3 || variant >= 2, "grid_encode_backward: the split form needs the bucketed scatter");
     hipStream_t s = as_stream(stream);
-    dim3 grid;
     if (variant < 2) {
-        launch_dims(variant, num_levels, m_host, grid);
-        hipLaunchKernelGGL((k_grid_backward_atomic<float>), grid, dim3(256), 0, s, xyzs, bound, (const float *)dfeat,
-                           meta, m_host, m_dev, level_stride, dtable, variant);
+        launch_grid_backward_atomic(xyzs, bound, (const float *)dfeat, meta, m_host, m_dev, level_stride, dtable, variant, s);
         LNERF_CHECK_LAUNCH("grid_encode_backward");
         return LNERF_OK;
     }
@@ -1948,21 +967,9 @@ static int scatter_backward(const float *xyzs, float bound, const void *dfeat, i
         set_error("grid_encode_backward: hipMemsetAsync failed");
         return LNERF_ERR_HIP;
     }
-    auto launch_bin = [&](int l0, int l1) {
-        // persistent: G workgroups, G a multiple of the launch's level count (item k of a workgroup: next tile group, next level)
-        const int nl = l1 - l0;
-        const int wgs = g_bin_wgs > 0 ? g_bin_wgs : 256 * g_bin_per_cu;
-        int64_t G = (int64_t)(wgs / nl) * nl;
-        const int64_t items = div_up(m_host, (int64_t)BIN_T) * nl;
-        if (G > items) G = items;
-        if (G < nl) G = nl;
-        const dim3 g((unsigned)G, 1, 1);
-        if (packed)
-            hipLaunchKernelGGL((k_scatter_bin<Rec8>), g, dim3(BIN_T), 0, s, xyzs, bound, (const float *)dfeat, meta, bm,
-                               m_host, m_dev, level_stride, gmax, items_dev, segtab, (Rec8 *)rec, g_skip_zero, l0, l1);
-        else
-            hipLaunchKernelGGL((k_scatter_bin<Rec12>), g, dim3(BIN_T), 0, s, xyzs, bound, (const float *)dfeat, meta, bm,
-                               m_host, m_dev, level_stride, gmax, items_dev, segtab, (Rec12 *)rec, g_skip_zero, l0, l1);
+    auto launch_bin = [&](int l0, int l1) {   // pass 1 (grid_bin.hip)
+        launch_scatter_bin(packed, xyzs, bound, (const float *)dfeat, meta, bm, m_host, m_dev, level_stride, gmax, items_dev,
+                           segtab, rec, l0, l1, s);
     };
     FusedUpdate fu0;
     memset(&fu0, 0, sizeof(fu0));
