@@ -75,10 +75,11 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=5, help="timed CPU frames (~2 s each on 16 cores; + 1 warm-up)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed companions (f32 step, occupancy refresh)")
     ap.add_argument("--gather-variant", type=int, default=0)
-    ap.add_argument("--gridtype", default="hash", choices=["hash", "blocked"],
-                    help="layout of the hashed levels: hash = Instant-NGP (the headline); blocked = opt-in 4 x 2 x 2 vertex "
-                         "blocks per 64-byte line (for profiling the variant through the whole step; the default run reports "
-                         "it as the `blocked` companion)")
+    ap.add_argument("--gridtype", default="auto", choices=["auto", "hash", "tiled", "blocked"],
+                    help="layout of the levels larger than their table: auto (default) = what TrainConfig picks -- `blocked` "
+                         "(4 x 2 x 2 vertex blocks hashed together, one 64-byte line of the bf16 table each) with the bf16 "
+                         "table, `hash` (Instant-NGP's vertex hash) with the f32 table; `tiled` = the upstream encoder's other "
+                         "layout.  The default run reports the OTHER of blocked / hash as the `layout_companion`")
     ap.add_argument("--fuse-table-update", default="auto", choices=["auto", "0", "1"],
                     help="hash-table Adam step applied inside the scatter's reduce pass (single GPU only; auto = on at N=1)")
     ap.add_argument("--jitter-rng", default="kernel", choices=["kernel", "torch"],
@@ -364,14 +365,15 @@ def load_pmc(build_tag):
     return d
 
 
-def companion_blocked(dev, rank, precision, steps=60, warmup=10):
-    """The opt-in `blocked` layout of the hashed levels (render.gridtype = "blocked": 4 x 2 x 2 vertex blocks in one
-    64-byte line of the bf16 table, 2.8 instead of 4.25 lines per sample and level) through the same captured step:
-    frames/s and the gather's kernel time beside the headline, which stays on Instant-NGP's hash."""
+def companion_layout(dev, rank, precision, gridtype, steps=60, warmup=10):
+    """The OTHER table layout through the same captured step, beside the headline: frames/s and the gather's kernel time.
+    `blocked` (render.gridtype = "blocked": 4 x 2 x 2 vertex blocks in one 64-byte line of the bf16 table, 2.8 instead of
+    4.25 lines per sample and level) is what the bf16 configuration trains with since round 4 (equal or better training
+    error in the A/B of profiles/r04_ab_layout.jsonl); `hash` is Instant-NGP's vertex hash."""
     from src.latent_nerf.raymarching import backend as B
     from src.latent_nerf.training.graph_step import GraphedTrainStep
     from src.latent_nerf.training.optimizer import FusedAdam
-    net, pose, intr, bg, grad = build(dev, precision, 0, rank, precision, gridtype="blocked")
+    net, pose, intr, bg, grad = build(dev, precision, 0, rank, precision, gridtype=gridtype)
     opt = FusedAdam(net.get_params(LR), betas=(0.9, 0.99), eps=1e-15, encoder=net.encoder, capturable=True,
                     fuse_table_update=True, mlp=net)
     step, fwd_bwd, opt_step, sync = make_step(net, pose, intr, bg, grad, opt, 1)
@@ -397,8 +399,9 @@ def companion_blocked(dev, rank, precision, steps=60, warmup=10):
     return {"value": steps / dt, "unit": "latent-frames/sec", "ms_per_step": 1e3 * dt / steps, "steps": steps,
             "samples_per_view": M, "gather_kernel_ms": g_ms, "gather_GBps": M * bps / (g_ms * 1e-3) / 1e9,
             "gather_frac_of_hbm_peak": M * bps / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "what": "render.gridtype = blocked (hashed levels: block of 4 x 2 x 2 vertices = one 64-byte line of the bf16 "
-                    "table); a different table layout, NOT the headline's Instant-NGP hash"}
+            "gridtype": gridtype,
+            "what": "render.gridtype = %s: the same step on the other table layout (hash = Instant-NGP's vertex hash; blocked "
+                    "= 4 x 2 x 2 vertex blocks hashed together, one 64-byte line of the bf16 table each)" % gridtype}
 
 
 def companion_views(args, dev, rank, k=8, steps=30, warmup=6):
@@ -614,6 +617,8 @@ def build_step(args, dev, rank, world, dist_on):
     """Model, optimiser and the step closures of this rank."""
     from src.latent_nerf.training.optimizer import FusedAdam
     table = args.precision if args.table == "auto" else args.table
+    if args.gridtype == "auto":   # (TrainConfig's rule: the blocked layout goes with the bf16 table)
+        args.gridtype = "blocked" if table == "bf16" else "hash"
     net, pose, intr, bg, grad = build(dev, args.precision, args.gather_variant, rank, table, args.jitter_rng, args.gridtype,
                                       views=args.views_per_rank)
     fuse = (not dist_on) if args.fuse_table_update == "auto" else (args.fuse_table_update == "1")
@@ -924,8 +929,8 @@ def main():
             "dtype": args.precision,
             "data": "synthetic",
             "config": {"workload": "configs[1]: unconstrained latent-NeRF 64x64x4, 128^3 occupancy grid, hash grid "
-                                   "L=16 F=2 T=2^19, %d view%s/GPU/step, fwd+bwd+grad all-reduce+Adam, occupancy refresh every "
-                                   "%d steps" % (kv, "" if kv == 1 else "s (one batch)", iv),
+                                   "L=16 F=2 T=2^19 (%s layout), %d view%s/GPU/step, fwd+bwd+grad all-reduce+Adam, occupancy refresh every "
+                                   "%d steps" % (args.gridtype, kv, "" if kv == 1 else "s (one batch)", iv),
                        "rays_per_view": H * W, "samples_per_view": M // kv, "sample_capacity": int(net.cfg.max_samples),
                        "views_per_step": world * kv, "views_per_rank": kv,
                        "parallelism": "dp%d (%d view%s per GPU, RCCL all-reduce of gradients, %s on the wire%s)%s"
@@ -953,7 +958,7 @@ def main():
             res["preflight"] = preflight
         if tuned:
             res["tuning_overrides"] = tuned
-        if not args.no_extras and not dist_on and args.gridtype == "hash" and kv == 1:
+        if not args.no_extras and not dist_on and args.gridtype in ("hash", "blocked") and kv == 1:
             if args.trainer_steps > 0:
                 # the product loop twice: on the bench's own view (same GPU work per step as the headline: what the loop
                 # itself costs) and on the training pose distribution (random radius / angles / field of view per step)
@@ -961,7 +966,8 @@ def main():
                 res["trainer"]["frac_of_value"] = res["trainer"]["value"] / res["value"]
                 res["trainer_random_views"] = trainer_companion(dev, args.trainer_steps, args.precision)
             res["views8"] = companion_views(args, dev, rank, 8)
-            res["blocked"] = companion_blocked(dev, rank, args.precision)
+            res["layout_companion"] = companion_layout(dev, rank, args.precision,
+                                                       "hash" if args.gridtype == "blocked" else "blocked")
             res["f32"] = companion_f32(dev, rank)
         if not args.no_cpu_baseline and not dist_on:
             res["cpu_baseline"] = cpu_baseline(args.cpu_frames)

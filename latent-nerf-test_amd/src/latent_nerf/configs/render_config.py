@@ -62,7 +62,10 @@ class RenderConfig:
     # variant that hashes 4 x 2 x 2 vertex BLOCKS and keeps a block's 16 rows in one 64-byte line of the bf16 table
     # (2.8 instead of 4.25 cache lines per sample and level in the gather; a different collision pattern, so tables are
     # not interchangeable between the two)
-    gridtype: str = "hash"
+    # "auto" (default): decided by the owner like the precisions -- TrainConfig picks "blocked" with the bf16 table (its
+    # 64-byte-line blocks are cut for 4-byte rows; measured: gather 75 -> 67 us at equal or better training error,
+    # profiles/r04_ab_layout.jsonl) and "hash" with the f32 parity configuration; a bare RenderConfig means "hash"
+    gridtype: str = "auto"
     # workgroup -> (level, tile) mapping of the gather/scatter: 0 = level on grid.y (measured 1.8x faster), 1 = XCD-pinned levels
     gather_variant: int = 0
     # hash-grid backward: 0/1 = global float atomics, 2 = two-pass bucketed scatter (LDS reduction, exact f32
@@ -76,6 +79,12 @@ class RenderConfig:
     # has read the march counters back, then 1.5 x the largest sample count seen between refreshes (rounded up to
     # 64 Ki; rays that do not fit are dropped by the march's scan pass and counted, never written out of bounds)
     max_samples: int = 0
+
+    def layout(self) -> str:
+        """Resolved `gridtype` ("auto" on a bare RenderConfig = Instant-NGP's vertex hash)."""
+        if self.gridtype not in ("auto", "hash", "tiled", "blocked"):
+            raise ValueError("render.gridtype must be 'auto', 'hash', 'tiled' or 'blocked' (got %r)" % (self.gridtype,))
+        return "hash" if self.gridtype == "auto" else self.gridtype
 
     def precision(self, name: str) -> str:
         """Resolved value of `mlp_precision` / `table_dtype` ("auto" on a bare RenderConfig = the f32 parity path)."""

@@ -117,10 +117,19 @@ class TrainConfig:
             setattr(self.render, n, "bf16" if self.optim.fp16 else "f32")
         for n in ("mlp_precision", "table_dtype"):
             self.render.precision(n)  # validates
+        # the table layout follows the table's dtype where the user left render.gridtype on "auto": the blocked layout
+        # with the bf16 shadow (a block = one 64-byte line of 4-byte rows), Instant-NGP's vertex hash with the f32 table
+        if not hasattr(self, "_auto_layout"):
+            self._auto_layout = self.render.gridtype == "auto"
+        if self._auto_layout:
+            self.render.gridtype = "blocked" if self.render.table_dtype == "bf16" else "hash"
+        self.render.layout()  # validates
 
     def note_explicit(self, key, value):
         """config_cli.apply_overrides tells us which fields the user set."""
         section, _, name = key.partition(".")
+        if section == "render" and name == "gridtype":
+            self._auto_layout = value == "auto"
         if section == "render" and name in ("mlp_precision", "table_dtype"):
             if not hasattr(self, "_auto_precision"):
                 self._auto_precision = set()

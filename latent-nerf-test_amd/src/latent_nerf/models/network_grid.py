@@ -183,7 +183,7 @@ class NeRFNetwork(NeRFRenderer):
                                    table_dtype=table_dtype, variant=cfg.gather_variant,
                                    scatter_variant=(cfg.scatter_variant if cfg.scatter_variant >= 0
                                                     else (3 if self.precision == "bf16" else 2)),
-                                   gridtype=getattr(cfg, "gridtype", "hash"))
+                                   gridtype=cfg.layout() if hasattr(cfg, "layout") else getattr(cfg, "gridtype", "hash"))
         in_dim, out_dim = self.encoder.out_dim, 1 + self.img_dims
         # nn.Linear default init, kept as bare parameters: the fused kernel takes all six at once
         self.w1 = nn.Parameter(torch.empty(hidden_dim, in_dim))

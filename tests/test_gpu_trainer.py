@@ -90,7 +90,11 @@ def test_checkpoint_records_the_table_layout_and_refuses_another(dev, tmp_path):
                                    "optim.fp16": True, "log.full_eval_size": 1}), device=dev)
     tr.train()
     path = tr.save_checkpoint(full=True)
-    other = Trainer(_cfg(tmp_path, **{"optim.iters": 2, "log.exp_name": "lay_h", "optim.fp16": True}), device=dev)
+    other = Trainer(_cfg(tmp_path, **{"optim.iters": 2, "log.exp_name": "lay_h", "optim.fp16": True,
+                                      "render.gridtype": "hash"}), device=dev)
+    auto = _cfg(tmp_path, **{"optim.fp16": True, "log.exp_name": "lay_a"})
+    assert auto.render.gridtype == "blocked"          # bf16 table: the blocked layout is the default ...
+    assert _cfg(tmp_path, **{"optim.fp16": False, "log.exp_name": "lay_a2"}).render.gridtype == "hash"   # ... f32: Instant-NGP's
     with pytest.raises(ValueError, match="not interchangeable"):
         other.load_checkpoint(path, model_only=True)
     same = Trainer(_cfg(tmp_path, **{"optim.iters": 2, "log.exp_name": "lay_b2", "render.gridtype": "blocked",

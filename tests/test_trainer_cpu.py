@@ -78,6 +78,17 @@ def test_precision_follows_fp16_only_where_left_on_auto():
     assert r.mlp_precision == "auto" and r.precision("mlp_precision") == "f32" and r.precision("table_dtype") == "f32"
     with pytest.raises(ValueError):
         load_config(["--render.mlp_precision", "fp8"])
+    # the table LAYOUT follows the table's dtype the same way: blocked (64-byte-line blocks of 4-byte rows) with the
+    # bf16 shadow, Instant-NGP's vertex hash with the f32 table; an explicit render.gridtype always wins
+    assert TrainConfig().render.gridtype == "blocked" and r.gridtype == "auto" and r.layout() == "hash"
+    assert load_config(["--optim.fp16", "false"]).render.gridtype == "hash"
+    assert load_config(["--render.table_dtype", "f32"]).render.gridtype == "hash"
+    assert load_config(["--render.gridtype", "hash"]).render.gridtype == "hash"
+    assert load_config(["--render.gridtype", "tiled", "--optim.fp16", "false"]).render.gridtype == "tiled"
+    c = apply_overrides(load_config(["--optim.fp16", "false"]), {"optim.fp16": True})
+    assert c.render.gridtype == "blocked"
+    with pytest.raises(ValueError):
+        load_config(["--render.gridtype", "morton"])
 
 
 def test_write_video_writes_every_frame(tmp_path):
