@@ -106,8 +106,10 @@ def test_render_train_bf16_matches_bf16_oracle(dev):
     compositing) against the oracle with the SAME roundings in both directions: bf16 operands of every forward product,
     and in the backward pass the pre-activation gradients rounded once to bf16 before they feed dX / dW / db
     (oracle _Bf16Linear), the table gradient's addends rounded to the 26-bit record format (oracle _CornerGather).  With
-    the rounding points restated, what is left is f32 summation order: discrete outputs bit-exact, images within 2e-2 of
-    the value range (a bf16 feature is 2^-9), every gradient within 1e-2 of its maximum."""
+    the rounding points restated, what is left is f32 summation order: discrete outputs bit-exact; forward outputs within
+    1e-4 of the value range for the composited image and opacity and 5e-4 of the largest density for the per-sample
+    sigmas (measured on three seeds: 2e-6, 8e-7 and 3e-5 -- round 3 still allowed 2e-2 here); every gradient within
+    1e-2 of its maximum."""
     G, HW, log2_T, base = 64, 32, 14, 16
     net, cfg, lv, table, params, grid = _make(dev, G, HW, log2_T, base, seed=2, mlp_precision="bf16", table_dtype="bf16")
     net.train()
@@ -123,9 +125,11 @@ def test_render_train_bf16_matches_bf16_oracle(dev):
     ref["image"].backward(g[0])
     assert int(out["counter"][0]) == ref["M"] and torch.equal(out["rays"].cpu(), ref["rays"])
     e, s = _err(out["image"][0], ref["image"])
-    assert e <= 2e-2 * max(s, 1.0), ("image", e, s)
+    assert e <= 1e-4 * max(s, 1.0), ("image", e, s)
     e, s = _err(out["weights_sum"][0], ref["weights_sum"])
-    assert e <= 2e-2, ("weights_sum", e)
+    assert e <= 1e-4, ("weights_sum", e)
+    e, s = _err(out["sigmas"][:ref["M"]], ref["sigmas"])
+    assert e <= 5e-4 * s, ("sigmas", e, s)
     e, s = _err(net.encoder.embeddings.grad, table.grad)
     assert e <= 1e-2 * s, ("dtable", e, s)
     for k in ("w1", "b1", "w2", "b2", "w3", "b3"):
@@ -453,7 +457,8 @@ def test_full_size_bf16_step_with_fused_adam_matches_oracle(dev):
     M = ref["M"]
     assert int(out["counter"][0]) == M and M > 300000 and torch.equal(out["rays"].cpu(), ref["rays"])
     e, s = _err(out["image"][0], ref["image"])
-    assert e <= 2e-2 * max(s, 1.0), ("image", e, s)
+    print("full-size bf16 step: image error %.3e (scale %.3f)" % (e, s))
+    assert e <= 1e-3 * max(s, 1.0), ("image", e, s)
     gt = table.grad
     p1, m1, v1 = O.adam_step(t0, gt, torch.zeros_like(gt), torch.zeros_like(gt), 1, lr)
     emb = net.encoder.embeddings.detach().cpu()

@@ -13,7 +13,7 @@ import bench
 from src.latent_nerf.raymarching import backend as B
 from src.latent_nerf.training.optimizer import FusedAdam
 dev = torch.device("cuda:0")
-net, pose, intr, bg, grad = bench.build(dev, "bf16", 0, 0, "bf16")
+net, pose, intr, bg, grad = bench.build(dev, "bf16", 0, 0, "bf16", gridtype=os.environ.get("LNERF_GRIDTYPE", "blocked"))
 opt = FusedAdam(net.get_params(1e-7), betas=(0.9, 0.99), eps=1e-15, encoder=net.encoder, capturable=True,
                 fuse_table_update=True, mlp=net)
 def step():
