@@ -36,7 +36,7 @@ def main():
         "render.eval_h": 32, "render.eval_w": 32, "render.grid_size": 64, "optim.iters": steps, "optim.lr": 5e-3,
         "log.save_interval": 10000, "log.eval_size": 1, "log.full_eval_size": 2, "optim.fp16": precision == "bf16",
         "guide.text": "a lego man",
-        "optim.views_per_step": world, "optim.exchange_groups": groups,
+        "optim.views_per_step": world * int(os.environ.get("LNERF_TEST_VIEWS_PER_RANK", "1")), "optim.exchange_groups": groups,
         "optim.graph_collectives": os.environ.get("LNERF_TEST_GRAPH_COLLECTIVES", "1") != "0",
         "optim.shard_table_optimizer": os.environ.get("LNERF_TEST_SHARD", "0") == "1"})
     tr = Trainer(cfg, device=dev)
@@ -73,6 +73,7 @@ def main():
             state = torch.load(path, map_location="cpu", weights_only=True)
             res["ckpt_table"] = hashlib.sha256(state["model"]["encoder.embeddings"].contiguous().numpy().tobytes()).hexdigest()
             res["ckpt_m"] = hashlib.sha256(state["optimizer"]["exp_avg"][0].contiguous().numpy().tobytes()).hexdigest()
+    res["views"] = list(tr.views)
     res["exchange"] = bool(tr.exchange)
     res["capture_exchange"] = bool(tr.capture_exchange)
     res["graph_stats"] = dict(tr.graph_stats)

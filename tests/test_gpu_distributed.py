@@ -22,7 +22,7 @@ def _free_port():
 
 
 def _run(tmp_path, world, groups, steps=20, precision="bf16", backend="gloo", force=False, save=False, tag="",
-         graph_collectives=True, shard=False):
+         graph_collectives=True, shard=False, views_per_rank=1):
     out = tmp_path / ("w%d_g%d_%s%s" % (world, groups, precision, tag))
     out.mkdir()
     port = _free_port()
@@ -32,7 +32,7 @@ def _run(tmp_path, world, groups, steps=20, precision="bf16", backend="gloo", fo
                    MASTER_PORT=str(port), LNERF_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0",
                    LNERF_FORCE_DIST="1" if force else "0",
                    LNERF_TEST_GRAPH_COLLECTIVES="1" if graph_collectives else "0",
-                   LNERF_TEST_SHARD="1" if shard else "0")
+                   LNERF_TEST_SHARD="1" if shard else "0", LNERF_TEST_VIEWS_PER_RANK=str(views_per_rank))
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(out), str(groups),
                                        str(steps), precision] + (["save"] if save else []), env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
@@ -82,6 +82,18 @@ def test_row_sharded_table_optimiser_two_ranks(built_lib, tmp_path):
     # the exchange also runs un-sharded in the same worker (default): same shadows on both ranks there as well
     c, d = _run(tmp_path, 2, 4, tag="_plain")
     assert not c["sharded"] and c["shadow"] == d["shadow"] and c["table"] == d["table"]
+
+
+def test_two_ranks_two_views_each(built_lib, tmp_path):
+    """optim.views_per_step = 4 on two ranks: every rank renders its two views as ONE batch (one backward into the wire
+    buffer, one exchange, one optimiser step with grad_scale 1/4); the ranks' view sets partition the step's views and the
+    replicas stay bit-identical."""
+    a, b = _run(tmp_path, 2, 4, steps=12, views_per_rank=2, tag="_v2")
+    assert a["views"] == [0, 2] and b["views"] == [1, 3] and a["pipelined"] and a["steps"] == 12
+    for key in ("table", "mlp", "density_grid", "bitfield", "shadow"):
+        assert a[key] == b[key], key
+    assert a["finite"] and a["table_moved"] > 0
+    assert a["graph_stats"]["replayed_steps"] >= 8
 
 
 def test_f32_exchange_and_single_rank_paths(built_lib, tmp_path):
