@@ -64,20 +64,27 @@ __device__ __forceinline__ void corner_rows(uint32_t gx, uint32_t gy, uint32_t g
     if (blocked) {  // wave-uniform
         const uint32_t nblk = hsize >> 4;
         const uint32_t x1 = gx + 1u;
-        const uint32_t hx[2] = {gx >> 2, x1 >> 2};
         const uint32_t y0 = (gy >> 1) * 2654435761u, z0 = (gz >> 1) * 805459861u;
         // (y + 1) >> 1 is the next block exactly when y is odd
-        const uint32_t hy[2] = {y0, (gy & 1u) ? y0 + 2654435761u : y0};
-        const uint32_t hz[2] = {z0, (gz & 1u) ? z0 + 805459861u : z0};
-        const uint32_t wx[2] = {gx & 3u, x1 & 3u};
-        const uint32_t wy[2] = {(gy & 1u) << 2, ((gy + 1u) & 1u) << 2};
-        const uint32_t wz[2] = {(gz & 1u) << 3, ((gz + 1u) & 1u) << 3};
+        const uint32_t y1 = (gy & 1u) ? y0 + 2654435761u : y0, z1 = (gz & 1u) ? z0 + 805459861u : z0;
         if ((nblk & (nblk - 1u)) == 0u) {
+            // The position inside the block rides in the low four bits of the three hash terms: x in bits 0-1, y in bit
+            // 2, z in bit 3 -- disjoint, so their XOR is their OR -- and one mask keeps (block hash mod nblk) << 4 and
+            // the position: a corner costs one three-input XOR and one AND, as on the vertex-hash path.  (The binning
+            // pass is bound by vector issue: the shift / or / or per corner of the plain form cost it 7 us.)
+            const uint32_t HX[2] = {((gx & ~3u) << 2) | (gx & 3u), ((x1 & ~3u) << 2) | (x1 & 3u)};
+            const uint32_t HY[2] = {(y0 << 4) | ((gy & 1u) << 2), (y1 << 4) | (((gy + 1u) & 1u) << 2)};
+            const uint32_t HZ[2] = {(z0 << 4) | ((gz & 1u) << 3), (z1 << 4) | (((gz + 1u) & 1u) << 3)};
+            const uint32_t mask = ((nblk - 1u) << 4) | 15u;
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
-                row[c] = (((hx[c & 1] ^ hy[(c >> 1) & 1] ^ hz[(c >> 2) & 1]) & (nblk - 1u)) << 4) |
-                         (wx[c & 1] | wy[(c >> 1) & 1] | wz[(c >> 2) & 1]);
+            for (int c = 0; c < 8; ++c) row[c] = (HX[c & 1] ^ HY[(c >> 1) & 1] ^ HZ[(c >> 2) & 1]) & mask;
         } else {
+            const uint32_t hx[2] = {gx >> 2, x1 >> 2};
+            const uint32_t hy[2] = {y0, y1};
+            const uint32_t hz[2] = {z0, z1};
+            const uint32_t wx[2] = {gx & 3u, x1 & 3u};
+            const uint32_t wy[2] = {(gy & 1u) << 2, ((gy + 1u) & 1u) << 2};
+            const uint32_t wz[2] = {(gz & 1u) << 3, ((gz + 1u) & 1u) << 3};
 #pragma unroll
             for (int c = 0; c < 8; ++c)
                 row[c] = (((hx[c & 1] ^ hy[(c >> 1) & 1] ^ hz[(c >> 2) & 1]) % nblk) << 4) |
