@@ -77,3 +77,27 @@ def test_bench_views_per_rank_goes_through_the_fused_step(built_lib):
     assert res["step_tail"] == "inside the scatter's pass 2" and res["launch"] == "hipgraph"
     assert res["roofline"]["samples_per_launch"] > 4 * 300000       # four views' samples in one gather launch
     assert abs(res["value"] - 4e3 / res["ms_per_step"]) < 1e-6 * res["value"]
+
+
+def test_bench_under_torch_distributed_run(built_lib):
+    """The driver's own form for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...` -- the ranks arrive with WORLD_SIZE set (no self-launch), join the
+    agent's store, and rank 0 prints the one line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LNERF_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        e.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10",
+                        "--warmup", "3", "--no-cpu-baseline", "--no-extras"], env=e, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    out, err = p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
+    assert p.returncode == 0, err[-3000:]
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 10 and res["config"]["views_per_step"] == 2
+    assert "starting 2 ranks" not in err

@@ -535,6 +535,47 @@ def test_closing_scatter_refuses_what_it_cannot_do(dev):
 
 
 @pytest.mark.gpu
+def test_step_tail_without_an_mlp_still_ticks_and_clears(dev):
+    """lnerf_step_tail with mlp_workspace = NULL (a C-ABI caller whose step has no fused MLP): the tick of the device step
+    counter and the clearing of the scatter's level maxima it asked for still happen -- one workgroup arrives on its own.
+    (Through ABI 5 the call returned LNERF_OK without a launch: a stalled counter, wrong Adam bias corrections.)  A call
+    with nothing to do at all launches nothing and is not an error; flags without the scatter workspace are refused."""
+    import ctypes
+    from src.latent_nerf.models import encoding as E
+    from src.latent_nerf.raymarching import backend as B
+    from src.latent_nerf.raymarching.raymarching import _p, _stream
+    levels = E.GridLevels(16, 2, 16, 2048, 14)
+    M = 4096
+    wst = E.scatter_workspace(levels, M, dev)
+    n = levels.n_rows
+    table = torch.zeros(n, 2, device=dev)
+    m, v, zero = torch.zeros_like(table), torch.zeros_like(table), torch.zeros_like(table)
+    step_dev = torch.tensor([7, 0], device=dev, dtype=torch.int32)
+    wst[:4096].view(torch.int32)[::32][:16] = 0x3F800000          # the level maxima: something to clear
+    torch.cuda.synchronize()
+
+    def tail(flags, ws=wst, nl=levels.num_levels):
+        B.call("lnerf_step_tail", nl, levels.level_dim, levels.c_offsets, levels.c_scales, levels.c_res, M, 3,
+               _p(ws), 0 if ws is None else ws.numel(), _p(zero), _p(table), _p(m), _p(v), None, 1e-2, None, 0, B.BF16, 5,
+               None, None, None, 1e-3, None, 0.9, 0.99, 1e-15, 1, _p(step_dev), 1.0, flags, _stream())
+
+    tail(B.TAIL_TICK | B.TAIL_CLEAR_SCATTER)
+    torch.cuda.synchronize()
+    assert step_dev.tolist() == [8, 0]
+    assert int(wst[:4096].view(torch.int32)[::32][:16].abs().sum()) == 0
+    tail(B.TAIL_TICK)
+    torch.cuda.synchronize()
+    assert step_dev.tolist() == [9, 0]
+    tail(0)                                                        # nothing to do: no launch, no error
+    torch.cuda.synchronize()
+    assert step_dev.tolist() == [9, 0]
+    with pytest.raises(B.LnerfError):
+        tail(B.TAIL_TICK, ws=None, nl=0)                           # the arrival counters live in the scatter workspace
+    assert float(table.abs().max()) == 0.0
+    E.ws_mark_dirty(dev)      # (this test wrote the shared workspace's header by hand)
+
+
+@pytest.mark.gpu
 def test_fused_table_update_arming(dev):
     """Only an armed backward applies the fused update; an unarmed one yields the ordinary table gradient, and a step
     that mixes both is refused."""

@@ -74,3 +74,34 @@ def test_pose_uniforms_are_a_function_of_seed_step_view():
     one = [D.pose_uniforms(3, 9, v) for v in D.views_for_rank(8, 0, 1)]
     many = {v: D.pose_uniforms(3, 9, v) for r in range(4) for v in D.views_for_rank(8, r, 4)}
     assert [many[v] for v in range(8)] == one
+
+
+def test_store_and_agree_under_torchrun_agent_store(tmp_path):
+    """The driver starts N > 1 ranks with `python -m torch.distributed.run`: its agent hosts the c10d store and the ranks
+    are clients (TORCHELASTIC_USE_AGENT_STORE).  open_store() must join THAT store, the pre-group exchange must work over
+    it, and init_process_group(store=...) must build the group on it -- no second rendezvous, no fixed port."""
+    import subprocess
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import os, sys\n"
+        "sys.path[:0] = %r\n"
+        "import torch, torch.distributed as dist\n"
+        "from src.latent_nerf.training import launch as L\n"
+        "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "assert os.environ.get('TORCHELASTIC_USE_AGENT_STORE') == 'True'\n"
+        "st = L.open_store(r, w, timeout_s=60)\n"
+        "if r == 0: st.set('port', str(L.free_port()))\n"
+        "port = int(st.get('port').decode())\n"
+        "votes = L.agree(st, 'v', r, w, 7 * r, timeout_s=60)\n"
+        "assert votes == ['0', '7'], votes\n"
+        "dist.init_process_group('gloo', store=st, rank=r, world_size=w)\n"
+        "t = torch.tensor([float(r + 1)]); dist.all_reduce(t)\n"
+        "assert float(t) == 3.0 and port > 1024\n"
+        "dist.barrier(); dist.destroy_process_group()\n"
+        "open(os.path.join(%r, 'ok%%d' %% r), 'w').write('ok')\n" % ([_ROOT, os.path.join(_ROOT, "latent-nerf-test_amd")],
+                                                                    str(tmp_path)))
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(L.free_port()), str(script)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=180)
+    assert p.returncode == 0, p.stdout.decode(errors="replace")[-2000:]
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()

@@ -15,9 +15,15 @@ def main():
     steps = [rows[a:b] for a, b in zip(starts[:-1], starts[1:])]
     cnt = Counter(len(s) for s in steps)
     print("kernels per step histogram:", sorted(cnt.items()))
-    # the trainer's steps: the most common count above the bench's 9
-    n = max((k for k in cnt if 9 < k < 40), key=lambda k: cnt[k])
-    idx = [j for j, s in enumerate(steps) if len(s) == n]
+    # the trainer's steps: the ones that contain the guidance launch (one HIP kernel since round 4; the torch form is
+    # recognised by its kernel count: the most common one above the bench's 9)
+    guided = [j for j, s in enumerate(steps) if any(r[2].startswith('k_synthetic_guidance') for r in s)]
+    if guided:
+        n = Counter(len(steps[j]) for j in guided).most_common(1)[0][0]
+        idx = [j for j in guided if len(steps[j]) == n]
+    else:
+        n = max((k for k in cnt if 9 < k < 40), key=lambda k: cnt[k])
+        idx = [j for j, s in enumerate(steps) if len(s) == n]
     good = [steps[j] for j in idx][-40:]
     spans = sorted(s[-1][1] - s[0][0] for s in good)
     med = spans[len(spans) // 2]
