@@ -119,7 +119,8 @@ def parse():
                          "ranks agree on the outcome -- captured == eager bit for bit and replicas identical, on all of "
                          "them -- before the timed run picks its form (`preflight` on the output line)")
     ap.add_argument("--preflight", action="store_true", help=argparse.SUPPRESS)   # (the pre-flight child itself)
-    ap.add_argument("--preflight-timeout", type=float, default=300.0)
+    ap.add_argument("--preflight-timeout", type=float, default=120.0,
+                    help="seconds until a pre-flight child is killed and its verdict is 'no' (it takes 3-7 s on one rank)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0,
                     help="--gpus N > 1 started without a launcher: seconds until the parent kills every rank")
     ap.add_argument("--refresh", type=int, default=1,
