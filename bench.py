@@ -662,10 +662,17 @@ def preflight_main(args):
     torch.cuda.set_stream(stream)
 
     def digest(S):
+        # (row-sharded optimiser: every rank steps only the rows it owns -- the f32 master is whole again after the gather,
+        # a collective every rank reaches here; the bf16 shadow, what renders, is hashed as well)
+        if args.shard_optimizer and S["groups"]:
+            S["sync"].gather_rows([S["net"].encoder.embeddings.data])
         torch.cuda.synchronize()
         h = hashlib.sha256()
         for p in S["net"].parameters():
             h.update(p.detach().contiguous().cpu().numpy().tobytes())
+        sh = S["net"].encoder.shadow()
+        if sh is not None:
+            h.update(sh.detach().contiguous().view(torch.int16).cpu().numpy().tobytes())
         return h.hexdigest()
 
     K = 4

@@ -101,3 +101,16 @@ def test_bench_under_torch_distributed_run(built_lib):
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 10 and res["config"]["views_per_step"] == 2
     assert "starting 2 ranks" not in err
+
+
+def test_bench_two_ranks_row_sharded_optimiser_and_two_views_each(built_lib):
+    """`--shard-optimizer 1 --views-per-rank 2` on two gloo ranks: reduce-scatter of the bf16 gradient, every rank steps the
+    rows it owns, all-gather of the shadow; the run's own end-of-run check (masters gathered, checksums of master, MLP and
+    shadow equal on both ranks) has passed when the line appears."""
+    rc, out, err = _bench(["--gpus", "2", "--steps", "12", "--warmup", "4", "--no-cpu-baseline", "--no-extras",
+                           "--shard-optimizer", "1", "--views-per-rank", "2"], env={"LNERF_DIST_BACKEND": "gloo"})
+    assert rc == 0, err[-3000:]
+    res = json.loads(out.strip().splitlines()[-1])
+    assert res["n_gpus"] == 2 and res["config"]["views_per_step"] == 4 and res["config"]["views_per_rank"] == 2
+    assert "row-sharded table optimiser" in res["config"]["parallelism"]
+    assert abs(res["value"] - 4e3 / res["ms_per_step"]) < 1e-6 * res["value"]
