@@ -239,6 +239,7 @@ def make_step(net, pose, intr, bg, grad, opt, world, transport=torch.float32, pe
         opt_step()
         return out
 
+    allreduce.gradsync = sync     # (the GradSync behind the exchange: gather_rows() of the row-sharded optimiser)
     return step, fwd_bwd, opt_step, allreduce
 
 
@@ -665,7 +666,7 @@ def preflight_main(args):
         # (row-sharded optimiser: every rank steps only the rows it owns -- the f32 master is whole again after the gather,
         # a collective every rank reaches here; the bf16 shadow, what renders, is hashed as well)
         if args.shard_optimizer and S["groups"]:
-            S["sync"].gather_rows([S["net"].encoder.embeddings.data])
+            S["sync"].gradsync.gather_rows([S["net"].encoder.embeddings.data])
         torch.cuda.synchronize()
         h = hashlib.sha256()
         for p in S["net"].parameters():
@@ -843,7 +844,7 @@ def main():
     if not bool(torch.isfinite(emb).all()) or not all(bool(torch.isfinite(p.detach()).all()) for p in net.parameters()):
         raise SystemExit("bench: non-finite parameters after the timed steps")
     if dist_on and args.shard_optimizer and groups:   # the owners' rows of the f32 master, whole again for the checks
-        sync.gather_rows([net.encoder.embeddings.data])
+        sync.gradsync.gather_rows([net.encoder.embeddings.data])
     if world > 1:  # data parallel: every rank applied the same update, the replicas must still be bit-identical
         sh = net.encoder.shadow()
         chk = torch.stack([emb.double().sum(), emb.double().abs().sum(), net.w2.detach().double().sum(),
