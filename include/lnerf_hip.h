@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define LNERF_ABI_VERSION 6
+#define LNERF_ABI_VERSION 7
 
 #define LNERF_OK 0
 #define LNERF_ERR_INVALID_ARG (-1)
@@ -342,10 +342,12 @@ int lnerf_composite_rays_train_backward(const float *grad_weights_sum, const flo
  * its new densities, the mean is summed in a fixed order. */
 int lnerf_occ_cell_points(const uint32_t *indices, int64_t n, int cascade_level, int grid_size, float bound,
                           const float *noise, float *xyzs, lnerf_stream_t stream);
-/* Steady-state cell sampling of the refresh, on the device: indices [2*n_rand] = n_rand uniformly random cells followed by
- * n_rand cells drawn uniformly from the occupied ones (grid > 0; all uniform when none is), xyzs [2*n_rand, 3] = a
- * jittered point in each (the formula of lnerf_occ_cell_points).  Random numbers: u = hash(i, seed, step, k), restated in
- * oracle/nerf_oracle.py `occ_sample`.  The occupied list is built in ascending cell order and its length never visits
+/* Steady-state cell sampling of the refresh, on the device: indices [2*n_rand] = n_rand random cells followed by n_rand
+ * cells of the occupied ones (grid > 0; of all cells when none is), xyzs [2*n_rand, 3] = a jittered point in each (the
+ * formula of lnerf_occ_cell_points).  The draws are STRATIFIED (ABI 7): draw j of a half takes one element, uniformly, from
+ * the j-th of n_rand equal strata of its population (the cells in Morton order; the ascending list of occupied cells) --
+ * the marginal probabilities of independent draws, ascending output, neighbouring cells on neighbouring lanes of the
+ * density query that follows.  Random numbers: u = hash(i, seed, step, k), restated in oracle/nerf_oracle.py `occ_sample`.  The occupied list is built in ascending cell order and its length never visits
  * the host (the upstream form synchronises on torch.nonzero).  scratch: lnerf_occ_sample_scratch_bytes(n_cells). */
 size_t lnerf_occ_sample_scratch_bytes(int64_t n_cells);
 int lnerf_occ_sample(const float *grid_level, int64_t n_cells, int cascade_level, int grid_size, float bound,

@@ -41,7 +41,7 @@ _F = _c.c_float
 _Z = _c.c_size_t
 _U = _c.c_uint32
 
-ABI_VERSION = 6  # LNERF_ABI_VERSION of include/lnerf_hip.h this host side was written against
+ABI_VERSION = 7  # LNERF_ABI_VERSION of include/lnerf_hip.h this host side was written against
 
 # name -> argtypes (return type int unless listed in _RESTYPES)
 _SIGNATURES = {

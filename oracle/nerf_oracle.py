@@ -620,19 +620,27 @@ def occ_hash(i, seed: int, step: int, k: int):
 
 
 def occ_sample(grid_level: torch.Tensor, cascade_level: int, G: int, bound: float, n_rand: int, seed: int, step: int):
-    """Steady-state cell sampling of the occupancy refresh (lnerf_occ_sample): indices [2*n_rand] = n_rand uniform cells
-    then n_rand cells drawn uniformly from the occupied ones (ascending list of cells with grid > 0; all uniform when
-    the list is empty), and a jittered point in every cell (occ_cell_points' formula).  Draws: u = occ_hash(i, seed,
-    step, k); a 32-bit value h picks element (h * n) >> 32 of n."""
+    """Steady-state cell sampling of the occupancy refresh (lnerf_occ_sample; our own definition -- the upstream refresh
+    draws independently with torch.randint): indices [2*n_rand] = n_rand cells, then n_rand cells of the occupied ones
+    (ascending list of cells with grid > 0; all cells when the list is empty), STRATIFIED: draw j of a half takes element
+    lo + (h * (hi - lo) >> 32) of its population of n, lo = j n // n_rand, hi = (j + 1) n // n_rand, h = occ_hash(i, seed,
+    step, 0) -- same marginal probabilities as independent draws, ascending by construction; and a jittered point in every
+    cell (occ_cell_points' formula)."""
     import numpy as np
     n_cells = grid_level.numel()
     i = np.arange(2 * n_rand, dtype=np.uint64)
     h = occ_hash(i, seed, step, 0)
-    idx = (h * np.uint64(n_cells)) >> np.uint64(32)
+    j = np.where(i < n_rand, i, i - np.uint64(n_rand)).astype(np.uint64)
     occ = torch.nonzero(grid_level > 0).squeeze(-1).numpy().astype(np.uint64)
+    second = (i >= n_rand) & (occ.size > 0)
+    pop = np.where(second, np.uint64(max(occ.size, 1)), np.uint64(n_cells)).astype(np.uint64)
+    lo = j * pop // np.uint64(n_rand)
+    hi = (j + np.uint64(1)) * pop // np.uint64(n_rand)
+    pick = lo + ((h * (hi - lo)) >> np.uint64(32))
+    pick = np.minimum(pick, pop - np.uint64(1))
+    idx = pick.copy()
     if occ.size > 0:
-        pick = (h[n_rand:] * np.uint64(occ.size)) >> np.uint64(32)
-        idx[n_rand:] = occ[pick.astype(np.int64)]
+        idx[n_rand:] = occ[pick[n_rand:].astype(np.int64)]
     noise = np.stack([(occ_hash(i, seed, step, k) >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
                       for k in (1, 2, 3)], axis=-1)
     indices = torch.from_numpy(idx.astype(np.int64))

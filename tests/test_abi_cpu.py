@@ -24,7 +24,7 @@ def test_header_symbols_all_exported(built_lib):
 
 def test_library_loads_and_reports_gfx950(built_lib):
     lib = B.get_lib()
-    assert lib.lnerf_abi_version() == B.ABI_VERSION == 6
+    assert lib.lnerf_abi_version() == B.ABI_VERSION == 7
     assert lib.lnerf_build_info().decode().startswith("gfx950;")
     assert lib.lnerf_mlp_backward_workspace_bytes(5) > 0
 

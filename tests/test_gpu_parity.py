@@ -518,8 +518,15 @@ def test_occ_sample_matches_oracle(dev):
         ref_idx, ref_xyz = O.occ_sample(level, cas, G, bound, n_rand, 0x5EED, 37)
         assert torch.equal(idx.cpu().long(), ref_idx)
         assert torch.equal(xyz.cpu(), ref_xyz)
+        # stratified: both halves ascending (neighbouring cells on neighbouring lanes of the density query), the first
+        # half exactly one cell out of every aligned group of G3 / n_rand
+        assert bool((ref_idx[:n_rand][1:] > ref_idx[:n_rand][:-1]).all())
+        assert torch.equal(ref_idx[:n_rand] // (G3 // n_rand), torch.arange(n_rand))
+        assert bool((ref_idx[n_rand:][1:] >= ref_idx[n_rand:][:-1]).all())
         if float(level.max()) > 0:
             assert bool((level[ref_idx[n_rand:]] > 0).all())       # the second half sits in occupied cells
+            occ = int((level > 0).sum())
+            assert len(set(ref_idx[n_rand:].tolist())) == min(occ, n_rand)    # fewer occupied cells than draws: ALL of them
             assert 0.2 < float((ref_idx[:n_rand].float() / G3).mean()) < 0.8
 
 
