@@ -240,3 +240,40 @@ def test_row_sharded_table_optimiser_gloo(world):
     out = mgr.dict()
     mp.spawn(_shard_worker, args=(world, port, out), nprocs=world, join=True)
     assert dict(out) == {r: "ok" for r in range(world)}
+
+
+def test_shard_plan_on_the_bench_table_for_eight_ranks():
+    """Row-shard boundaries of the default table (L = 16, T = 2^19: 6 119 864 rows) for 8 ranks and 4 level groups: every
+    exchange range starts and ends on a multiple of 4 x 8 rows (a rank's shard starts on a multiple of 4 rows: 16-byte
+    accesses on the bf16 gradient), ranges are contiguous from row 0, a range never reaches past the rows its level group
+    (and the groups before it) have summed, and the replicated remainder is shorter than one granule."""
+    from oracle import nerf_oracle as O
+
+    class _Sink:
+        pass
+
+    lv = O.make_grid_levels()
+    assert lv.n_rows == 6119864
+    for world in (2, 4, 8, 3):
+        sync = D.GradSync([torch.nn.Parameter(torch.zeros(8, 2))], [], transport=torch.bfloat16, shard_optimizer=True)
+        sync.world, sync.rank = world, world - 1
+        sync._sink_levels = lv
+        sink = _Sink()
+        # level groups of roughly equal rows, as encoding.level_groups makes them
+        target, groups, lo = lv.n_rows / 4, [], 0
+        for l in range(16):
+            if lv.offsets[l + 1] >= target * (len(groups) + 1) - 1e-9 or l == 15:
+                if len(groups) < 3 or l == 15:
+                    groups.append((lo, l + 1))
+                    lo = l + 1
+        sink.groups = groups
+        sync._plan_shards(sink, torch.empty(lv.n_rows, 0))
+        gran = 4 * world
+        prev = 0
+        for (a, b), (_glo, ghi) in zip(sink.shard_ranges, groups):
+            assert a == prev and a % gran == 0 and b % gran == 0 and b <= lv.offsets[ghi]
+            r0, r1 = sync.my_rows(a, b)
+            assert r0 % 4 == 0 and (r1 - r0) * world == b - a and a <= r0 < r1 <= b
+            prev = b
+        ra, rb = sink.shard_rest
+        assert ra == prev and rb == lv.n_rows and 0 <= rb - ra < gran
