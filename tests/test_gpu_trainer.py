@@ -119,8 +119,12 @@ def test_batched_views_render_like_separate_views(dev):
     net.encoder.embeddings.data.normal_(0, 0.1)
     net = net.to(dev).train()
     net.seed_density_grid(lambda x: (x.norm(dim=-1) < 0.5).float() * 10.0, thresh=0.01)
+    # (the last view looks AWAY from the volume: every one of its rays misses the box -- a ragged batch: a view with no
+    # sample at all in the middle of the sample region's bookkeeping)
+    away = torch.tensor([[1.0, 0.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0], [0.0, 0.0, 1.0, 3.0], [0.0, 0.0, 0.0, 1.0]])
+    k = k + 1
     poses = torch.stack([pose_from_angles(math.radians(50.0 + 20 * v), math.radians(70.0 * v), 1.2 + 0.1 * v)
-                         for v in range(k)]).to(dev)
+                         for v in range(k - 1)] + [away]).to(dev)
     intr = intrinsics_from_fov(55.0, HW, HW)
     bg = torch.rand(k * HW * HW, 4, device=dev)
     g = torch.randn(k, HW * HW, 4, device=dev)
@@ -148,6 +152,7 @@ def test_batched_views_render_like_separate_views(dev):
         gv = grads()
         gs = gv if gs is None else [a + b for a, b in zip(gs, gv)]
     assert Ms == M
+    assert int(o["counter"][0]) == 0 and torch.equal(img[k - 1], bg[(k - 1) * HW * HW:].reshape(HW * HW, 4))   # pure background
     for a, b in zip(gb, gs):
         scale = float(b.abs().max())
         assert scale > 0 and float((a - b).abs().max()) <= 2e-5 * scale, (float((a - b).abs().max()), scale)
