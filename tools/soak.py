@@ -2,7 +2,7 @@
 """GPU box: soak of the captured trainer step (closing scatter pass, whole-step graph): N steps with random views, then
 the invariants a lost arrival or a stale counter would break: the device step counter equals the number of steps + 1,
 every arrival counter of the scatter workspace is zero, parameters are finite, the table moved.
-    python3 tools/soak.py [steps]"""
+    python3 tools/soak.py [steps] [views per step]"""
 import os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for _p in (ROOT, os.path.join(ROOT, "latent-nerf-test_amd")):
@@ -13,11 +13,12 @@ from src.latent_nerf.models import encoding as E
 from src.latent_nerf.training.trainer import Trainer
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+views = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 dev = torch.device("cuda:0")
 with tempfile.TemporaryDirectory() as d:
     cfg = apply_overrides(TrainConfig(), {"log.exp_name": "soak", "log.exp_root": d, "optim.iters": steps, "optim.fp16": True,
                                           "log.save_interval": 10 ** 9, "log.eval_size": 1, "log.full_eval_size": 1,
-                                          "log.quiet": True, "guide.text": "a lego man"})
+                                          "log.quiet": True, "guide.text": "a lego man", "optim.views_per_step": views})
     tr = Trainer(cfg, device=dev)
     tr.full_eval = lambda: None
     t0 = tr.nerf.encoder.embeddings.detach().clone()
