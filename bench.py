@@ -705,7 +705,10 @@ def main():
     args = parse()
     if args.preflight:
         raise SystemExit(preflight_main(args))
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1") or "1") == 1:
+        # no launcher started N ranks (WORLD_SIZE unset -- or a stray WORLD_SIZE=1 in the environment): start them here
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            os.environ.pop(k, None)
         raise SystemExit(self_launch(args))
     import torch.distributed as dist
     rank, world, _local, dev, backend, dist_on, store = dist_setup(args)
