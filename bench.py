@@ -135,9 +135,13 @@ def parse():
                     help="views every rank renders per optimisation step, as ONE batch through the fused captured step "
                          "(render.batch_size of the reference's fork: src/latent_paint_mesh/configs/train_config.py:32); "
                          "`value` counts every view")
-    ap.add_argument("--exchange-groups", type=int, default=4,
+    ap.add_argument("--exchange-groups", default="auto",
                     help="N > 1, bf16 on the wire: level groups the table gradient is exchanged in, each group's all-reduce "
-                         "launched behind its own sums (0 = one collective after the whole scatter)")
+                         "launched behind its own sums (0 = one collective after the whole scatter).  auto (default): the "
+                         "ranks TIME the step with 1, 2, 4 and 8 groups on the job's own links before the timed region "
+                         "(a dozen replays each, maximum over ranks) and take the fastest -- more groups start the wire "
+                         "earlier and cost ~20 us of launch tails each, so the best depth depends on which all-reduce RCCL "
+                         "picks over xGMI (on one rank, where nothing travels: 1); `exchange_tuning` on the output line")
     return ap.parse_args()
 
 
@@ -597,7 +601,8 @@ def decide_graph_collectives(args, store, rank, world, backend):
     env = dict(os.environ, MASTER_PORT=port, LNERF_BENCH_PREFLIGHT="1")
     env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
     argv = [sys.executable, os.path.abspath(__file__), "--preflight", "--gpus", str(world), "--precision", args.precision,
-            "--table", args.table, "--grad-transport", args.grad_transport, "--exchange-groups", str(args.exchange_groups),
+            "--table", args.table, "--grad-transport", args.grad_transport,
+            "--exchange-groups", "4" if str(args.exchange_groups) == "auto" else str(args.exchange_groups),
             "--gridtype", args.gridtype, "--views-per-rank", str(args.views_per_rank), "--perturb", str(args.perturb),
             "--shard-optimizer", str(args.shard_optimizer)]
     if args.force_dist:
@@ -632,7 +637,7 @@ def build_step(args, dev, rank, world, dist_on):
                     tail=bool(args.tail) and fuse and bool(args.fragment_shadow))
     opt.grad_scale = 1.0 / (world * args.views_per_rank)
     tr = args.precision if args.grad_transport == "auto" else args.grad_transport
-    groups = args.exchange_groups if (dist_on and tr == "bf16") else 0
+    groups = int(args.exchange_groups) if (dist_on and tr == "bf16") else 0
     prefetch = bool(args.prefetch_rays)
     if prefetch and (dist_on or args.views_per_rank != 1):
         raise SystemExit("--prefetch-rays 1 needs one rank without --force-dist and one view per rank")
@@ -648,6 +653,35 @@ def make_gstep(S, dist_on, in_graph, stream):
     kw = dict(sync=S["sync"], world=2 if dist_on else 1, warmup=3, stream=stream, opt_in_graph=not S["groups"],
               steps_per_graph=2 if S["prefetch"] else 1)
     return GraphedTrainStep(S["fwd_bwd"], S["opt_step"], list(S["net"].parameters()), sync_in_graph=bool(in_graph), **kw)
+
+
+def tune_exchange_groups(args, dev, rank, world, in_graph, stream, candidates=(1, 2, 4, 8), steps=12):
+    """`--exchange-groups auto`: the step with each candidate depth of the pipelined exchange, on the job's own ranks and
+    links: build, capture, `steps` replays between barriers, maximum over ranks; every rank gets the same timings (one
+    all-reduce each) and so the same choice.  Outside the timed region.  -> (best, {depth: ms per step})."""
+    import torch.distributed as dist
+    timings = {}
+    for G in candidates:
+        a = argparse.Namespace(**vars(args))
+        a.exchange_groups = G
+        S = build_step(a, dev, rank, world, True)
+        g = make_gstep(S, True, in_graph, stream)
+        for _ in range(3):
+            g()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        timings[G] = 1e3 * float(t.item()) / steps
+        del S, g
+        torch.cuda.empty_cache()
+    best = min(timings, key=lambda k: (timings[k], k))
+    return best, timings
 
 
 def preflight_main(args):
@@ -728,6 +762,18 @@ def main():
     # everything (eager steps, graph capture, replays, collectives) runs on one non-default stream
     main_stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(main_stream)
+    exchange_tuning = None
+    if str(args.exchange_groups) == "auto":
+        tr0 = args.precision if args.grad_transport == "auto" else args.grad_transport
+        if dist_on and tr0 == "bf16" and args.graph:
+            best, timings = tune_exchange_groups(args, dev, rank, world, in_graph, main_stream)
+            exchange_tuning = {"chosen": best, "ms_per_step": {str(k): round(v, 4) for k, v in timings.items()},
+                               "what": "refresh-free step with 1 / 2 / 4 / 8 level groups, 12 replays each on this job's "
+                                       "ranks and links, maximum over ranks; the fastest is what the timed region runs"}
+            log("exchange groups: %s -> %d" % (exchange_tuning["ms_per_step"], best))
+            args.exchange_groups = best
+        else:
+            args.exchange_groups = 4
     S = build_step(args, dev, rank, world, dist_on)
     net, opt, step, sync = S["net"], S["opt"], S["step"], S["sync"]
     table, fuse, tr, groups, prefetch = S["table"], S["fuse"], S["tr"], S["groups"], S["prefetch"]
@@ -968,6 +1014,8 @@ def main():
         res["build"] = build_tag
         if preflight is not None:
             res["preflight"] = preflight
+        if exchange_tuning is not None:
+            res["exchange_tuning"] = exchange_tuning
         if tuned:
             res["tuning_overrides"] = tuned
         if not args.no_extras and not dist_on and args.gridtype in ("hash", "blocked") and kv == 1:

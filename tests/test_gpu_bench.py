@@ -61,6 +61,12 @@ def test_preflight_picks_the_captured_exchange_on_rccl(built_lib):
     assert pf["ran"] and pf["passed"] and pf["exit_codes"] == [0], pf
     assert "captured ==" in err and "exchange + optimiser captured" in res["launch"]
     assert res["n_gpus"] == 1 and "force-dist" in res["config"]["parallelism"]
+    # the depth of the pipelined exchange was timed on the job's own ranks (1 / 2 / 4 / 8 level groups) and the fastest
+    # taken: on ONE rank nothing travels, so fewer launches win
+    et = res["exchange_tuning"]
+    assert set(et["ms_per_step"]) == {"1", "2", "4", "8"} and et["chosen"] in (1, 2)
+    assert et["ms_per_step"][str(et["chosen"])] == min(et["ms_per_step"].values())
+    assert ("table in %d pipelined level groups" % et["chosen"]) in res["config"]["parallelism"]
     # and the operator's switch: no pre-flight, eager exchange
     rc, out, err = _bench(["--force-dist", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-extras"],
                           env={"LNERF_GRAPH_COLLECTIVES": "0"})
